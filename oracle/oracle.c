@@ -1,0 +1,1071 @@
+/* TEST INFRASTRUCTURE ONLY -- see oracle.h for scope and pinning status.
+ *
+ * Plain-C restatement of the reference hot path.  Compiled WITHOUT
+ * -ffast-math and without FP contraction: every float operation below is
+ * written in the order the reference's release build executes it (where that
+ * could be observed in oracle/_ref) or in source order (where the reference
+ * cannot be compiled here).  FTZ/DAZ is switched on explicitly because the
+ * reference's -ffast-math link pulls in crtfastmath.o.
+ */
+#include "oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <xmmintrin.h>
+
+#include "ref_tables.h"
+
+/* ------------------------------------------------------------------------ */
+/* helpers                                                                  */
+
+static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+
+unsigned orc_ftz_enable(void) {
+    unsigned saved = _mm_getcsr();
+    _mm_setcsr(saved | 0x8040u); /* FTZ | DAZ, as crtfastmath.o does */
+    return saved;
+}
+void orc_ftz_restore(unsigned saved) { _mm_setcsr(saved); }
+
+__attribute__((constructor)) static void orc_ctor(void) { orc_ftz_enable(); }
+
+#define LOGT(i) u2f(DIST_REF_LOG_TABLE[i])
+
+/* ------------------------------------------------------------------------ */
+/* special.hpp                                                              */
+
+/* special.hpp:57-67 (FastLog::log, N=14), table special.cc:35-44 */
+float orc_fast_log(float x) {
+    int32_t intx = (int32_t)f2u(x);
+    const int exp = ((intx >> 23) & 255) - 127;
+    const int man = (intx & 0x7FFFFF) >> (23 - 14);
+    return ((float)exp + LOGT(man)) * 0.69314718055994529f;
+}
+
+/* vendor/fmath.hpp:438-459 (fmath::exp, the SSE branch), special.hpp:87-89 */
+float orc_fast_exp(float x) {
+    const float a = u2f(DIST_REF_EXP_AB[0]); /* 1024 / logf(2) */
+    const float b = u2f(DIST_REF_EXP_AB[1]); /* logf(2) / 1024 */
+    __m128 x1 = _mm_set_ss(x);
+    int limit = _mm_cvtss_si32(x1) & 0x7fffffff;
+    if (limit > 0x42b00000) {
+        x1 = _mm_min_ss(x1, _mm_set_ss(88.0f));
+        x1 = _mm_max_ss(x1, _mm_set_ss(-88.0f));
+    }
+    int r = _mm_cvtss_si32(_mm_mul_ss(x1, _mm_set_ss(a)));
+    unsigned v = (unsigned)r & 1023u;
+    int u = r >> 10;
+    uint32_t bits = ((uint32_t)(u + 127) << 23) | DIST_REF_EXP_TABLE[v];
+    /* source: t = x - r*b; return (1 + t) * fi.  The release build
+     * (-ffast-math) evaluates (x + 1) - r*b, observed in oracle/_ref for
+     * vector_exp (vector_math.cc:190-221) and the shim loop. */
+    return ((_mm_cvtss_f32(x1) + 1.0f) - (float)r * b) * u2f(bits);
+}
+
+/* special.hpp:114-171, coefficients special.cc:144-211 */
+float orc_fast_lgamma(float y) {
+    if (y < 2.5f || 4294967295.0f <= y) {
+        return lgammaf(y); /* glibc libm, as the reference */
+    }
+    int32_t x = (int32_t)f2u(y);
+    int c = (x >> 23) - 127; /* y >= 2.5: normal, positive */
+    int pos = c * 6;
+    float a5 = u2f(DIST_REF_LGAMMA_COEFF5[pos]);
+    float a4 = u2f(DIST_REF_LGAMMA_COEFF5[pos + 1]);
+    float a3 = u2f(DIST_REF_LGAMMA_COEFF5[pos + 2]);
+    float a2 = u2f(DIST_REF_LGAMMA_COEFF5[pos + 3]);
+    float a1 = u2f(DIST_REF_LGAMMA_COEFF5[pos + 4]);
+    float a0 = u2f(DIST_REF_LGAMMA_COEFF5[pos + 5]);
+    double yprod = y;
+    double sum = a0;
+    sum += a1 * yprod;
+    yprod *= y;
+    sum += a2 * yprod;
+    yprod *= y;
+    sum += a3 * yprod;
+    yprod *= y;
+    sum += a4 * yprod;
+    yprod *= y;
+    sum += a5 * yprod;
+    return (float)sum;
+}
+
+/* special.hpp:208-214, table special.cc:213-230 */
+float orc_fast_log_factorial(uint32_t n) {
+    if (n < 64) {
+        return u2f(DIST_REF_LOG_FACTORIAL[n]);
+    }
+    return orc_fast_lgamma((float)(n + 1u));
+}
+
+/* special.hpp:224-273, coefficients special.cc:232-269 */
+float orc_fast_lgamma_nu(float nu) {
+    if (nu < 0.0625f || 4294967295.0f <= nu) {
+        /* source: lgammaf(nu*0.5f + 0.5f) - lgammaf(nu*0.5f); release build
+         * forms the first argument as (nu + 1) * 0.5 */
+        return lgammaf((nu + 1.0f) * 0.5f) - lgammaf(nu * 0.5f);
+    }
+    int32_t x = (int32_t)f2u(nu);
+    int c = (x >> 23) - 127;
+    int pos = ((c + 4) / 2) * 4;
+    float a3 = u2f(DIST_REF_LGAMMA_NU_COEFF3[pos]);
+    float a2 = u2f(DIST_REF_LGAMMA_NU_COEFF3[pos + 1]);
+    float a1 = u2f(DIST_REF_LGAMMA_NU_COEFF3[pos + 2]);
+    float a0 = u2f(DIST_REF_LGAMMA_NU_COEFF3[pos + 3]);
+    /* source (special.hpp:234): a0 + x*a1 + x*x*a2 + x*x*x*a3.  The release
+     * build (-ffast-math) evaluates (a0 + xx*a2) + x*(a1 + xx*a3), xx = x*x,
+     * observed in oracle/_ref. */
+    float xx = nu * nu;
+    float p = xx * a3 + a1;
+    float q = xx * a2 + a0;
+    return q + p * nu;
+}
+
+void orc_vec_fast_log(size_t n, const float * in, float * out) {
+    for (size_t i = 0; i < n; ++i) out[i] = orc_fast_log(in[i]);
+}
+void orc_vec_fast_exp(size_t n, const float * in, float * out) {
+    for (size_t i = 0; i < n; ++i) out[i] = orc_fast_exp(in[i]);
+}
+void orc_vec_fast_lgamma(size_t n, const float * in, float * out) {
+    for (size_t i = 0; i < n; ++i) out[i] = orc_fast_lgamma(in[i]);
+}
+void orc_vec_fast_lgamma_nu(size_t n, const float * in, float * out) {
+    for (size_t i = 0; i < n; ++i) out[i] = orc_fast_lgamma_nu(in[i]);
+}
+void orc_vec_fast_log_factorial(size_t n, const uint32_t * in, float * out) {
+    for (size_t i = 0; i < n; ++i) out[i] = orc_fast_log_factorial(in[i]);
+}
+
+/* special.cc:35-44 with scalar log2f (what the source says; the release
+ * build calls libmvec instead, see gen_ref_tables.py) */
+void orc_formula_log_table(float * out) {
+    for (int i = 0; i < 16384; ++i) {
+        float v = 1.0f + ((float)i * (float)(1 << 9)) / (float)(1 << 23);
+        out[i] = log2f(v);
+    }
+}
+/* vendor/fmath.hpp:165-172 with scalar powf */
+void orc_formula_exp_table(uint32_t * out) {
+    for (int i = 0; i < 1024; ++i) {
+        float y = powf(2.0f, (float)i / 1024);
+        out[i] = f2u(y) & 0x7fffffu;
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* vector_math.cc (operation order as compiled: checked against _ref)       */
+
+/* vector_math.cc:160-168; release build evaluates (io + in1) - in2 */
+void orc_vector_add_subtract(size_t n, float * io, const float * a,
+                             const float * b) {
+    for (size_t i = 0; i < n; ++i) io[i] = (io[i] + a[i]) - b[i];
+}
+/* vector_math.cc:170-178 */
+void orc_vector_add_subtract_scalar(size_t n, float * io, float a,
+                                    const float * b) {
+    for (size_t i = 0; i < n; ++i) io[i] = (io[i] + a) - b[i];
+}
+/* vector_math.cc:132-139 */
+void orc_vector_add(size_t n, float * io, const float * a) {
+    for (size_t i = 0; i < n; ++i) io[i] += a[i];
+}
+/* vector_math.cc:74-83 */
+float orc_vector_max(size_t n, const float * in) {
+    float res = in[0];
+    for (size_t i = 0; i < n; ++i) {
+        float x = in[i];
+        res = x > res ? x : res;
+    }
+    return res;
+}
+
+/* ------------------------------------------------------------------------ */
+/* random_fwd.hpp:34 rng_t = std::default_random_engine = minstd_rand0      */
+
+#define ORC_M 2147483647ull
+#define ORC_A 16807ull
+
+/* libstdc++ linear_congruential_engine::seed */
+uint32_t orc_rng_seed(uint64_t seed) {
+    uint64_t s = seed % ORC_M;
+    return (uint32_t)(s == 0 ? 1 : s);
+}
+uint32_t orc_rng_next(uint32_t * state) {
+    *state = (uint32_t)((ORC_A * (uint64_t)*state) % ORC_M);
+    return *state;
+}
+/* random.hpp:47-50: std::uniform_real_distribution<float>(0,1) over one
+ * engine step = generate_canonical<float,24>: float(x - min) / 2^31, clamped
+ * below 1 */
+float orc_sample_unif01(uint32_t * state) {
+    uint32_t x = orc_rng_next(state);
+    float ret = (float)(uint64_t)(x - 1u) / 2147483648.0f;
+    if (ret >= 1.0f) ret = u2f(0x3f7fffffu); /* nextafter(1, 0) */
+    return ret;
+}
+/* state after `steps` further engine steps: state * a^steps mod m */
+uint32_t orc_rng_jump(uint32_t state, uint64_t steps) {
+    uint64_t result = state, base = ORC_A;
+    while (steps) {
+        if (steps & 1) result = (result * base) % ORC_M;
+        base = (base * base) % ORC_M;
+        steps >>= 1;
+    }
+    return (uint32_t)result;
+}
+
+/* random.cc:94-106 */
+float orc_scores_to_likelihoods(size_t n, float * scores) {
+    float max_score = orc_vector_max(n, scores);
+    float total = 0;
+    for (size_t i = 0; i < n; ++i) {
+        total += scores[i] = orc_fast_exp(scores[i] - max_score);
+    }
+    return total;
+}
+static size_t sample_from_likelihoods_u(size_t n, const float * l,
+                                        float total, float u) {
+    float t = total * u;
+    for (size_t i = 0; i < n; ++i) {
+        t -= l[i];
+        if (t <= 0) return i;
+    }
+    return n - 1;
+}
+/* random.hpp:316-333 */
+size_t orc_sample_from_likelihoods(uint32_t * rng, size_t n, const float * l,
+                                   float total) {
+    return sample_from_likelihoods_u(n, l, total, orc_sample_unif01(rng));
+}
+/* random.hpp:361-366 */
+size_t orc_sample_from_scores_overwrite(uint32_t * rng, size_t n,
+                                        float * scores) {
+    float total = orc_scores_to_likelihoods(n, scores);
+    return orc_sample_from_likelihoods(rng, n, scores, total);
+}
+size_t orc_sample_from_scores_u(size_t n, float * scores, float u) {
+    float total = orc_scores_to_likelihoods(n, scores);
+    return sample_from_likelihoods_u(n, scores, total, u);
+}
+/* random.cc:77-92 */
+float orc_log_sum_exp(size_t n, const float * scores) {
+    if (n == 0) return 0.f;
+    float max_score = orc_vector_max(n, scores);
+    float total = 0;
+    for (size_t i = 0; i < n; ++i) {
+        total += orc_fast_exp(scores[i] - max_score);
+    }
+    return orc_fast_log(total) + max_score;
+}
+/* random.hpp:300-313 */
+size_t orc_sample_discrete(uint32_t * rng, size_t dim, const float * probs) {
+    float t = orc_sample_unif01(rng);
+    for (size_t i = 0; i + 1 < dim; ++i) {
+        t -= probs[i];
+        if (t < 0) return i;
+    }
+    return dim - 1;
+}
+
+/* ------------------------------------------------------------------------ */
+/* clustering.hpp:81-123                                                    */
+
+float orc_py_score_add_value(float alpha, float d, int group_size,
+                             int nonempty_group_count, int sample_size,
+                             int empty_group_count) {
+    if (group_size == 0) {
+        float numer = alpha + d * (float)nonempty_group_count;
+        float denom = ((float)sample_size + alpha) * (float)empty_group_count;
+        return orc_fast_log(numer / denom);
+    }
+    return orc_fast_log(((float)group_size - d) / ((float)sample_size + alpha));
+}
+float orc_py_score_remove_value(float alpha, float d, int group_size,
+                                int nonempty_group_count, int sample_size,
+                                int empty_group_count) {
+    group_size -= 1;
+    if (group_size == 0) nonempty_group_count -= 1;
+    sample_size -= 1;
+    return -orc_py_score_add_value(alpha, d, group_size, nonempty_group_count,
+                                   sample_size, empty_group_count);
+}
+
+/* ------------------------------------------------------------------------ */
+/* feature slaves                                                           */
+
+typedef struct {
+    orc_shared sh;
+    float * betas;   /* DPD: owned copy */
+    float alpha_sum; /* DD: dd.hpp:403-406; DPD: alpha */
+    int K, cap;
+    /* suffstats, SoA over groups */
+    int32_t * i0;    /* DD/DPD count_sum|total, BB heads, GP count, NICH count */
+    int32_t * i1;    /* BB tails, GP sum */
+    float * f0;      /* GP log_prod, NICH mean */
+    float * f1;      /* NICH count_times_variance */
+    int32_t * cnt;   /* DD/DPD counts[cap][dim] */
+    /* value-scorer caches */
+    float * c0;      /* DD/DPD shift, BB heads, GP score, NICH score */
+    float * c1;      /* BB tails, GP post_alpha, NICH log_coeff */
+    float * c2;      /* GP score_coeff, NICH precision */
+    float * c3;      /* NICH mean */
+    float * S;       /* DD/DPD scores_[dim][cap] */
+} feat;
+
+struct orc_mix {
+    float alpha, d;
+    int K, cap;
+    int32_t * counts;
+    float * shifted;
+    int n_empty;
+    int64_t sample_size;
+    int F;
+    feat * f;
+    /* tracker */
+    uint32_t * p2g;
+    int p2g_size, p2g_cap;
+    int32_t * g2p;
+    uint32_t global_size;
+    int g2p_cap;
+};
+
+static int is_cat(int kind) { return kind == ORC_DD || kind == ORC_DPD; }
+
+static void feat_reserve(feat * f, int need) {
+    if (need <= f->cap) return;
+    int ncap = f->cap ? f->cap : 16;
+    while (ncap < need) ncap *= 2;
+    int dim = f->sh.dim;
+    f->i0 = realloc(f->i0, sizeof(int32_t) * ncap);
+    f->i1 = realloc(f->i1, sizeof(int32_t) * ncap);
+    f->f0 = realloc(f->f0, sizeof(float) * ncap);
+    f->f1 = realloc(f->f1, sizeof(float) * ncap);
+    f->c0 = realloc(f->c0, sizeof(float) * ncap);
+    f->c1 = realloc(f->c1, sizeof(float) * ncap);
+    f->c2 = realloc(f->c2, sizeof(float) * ncap);
+    f->c3 = realloc(f->c3, sizeof(float) * ncap);
+    if (is_cat(f->sh.kind)) {
+        f->cnt = realloc(f->cnt, sizeof(int32_t) * (size_t)ncap * dim);
+        float * nS = malloc(sizeof(float) * (size_t)ncap * dim);
+        for (int v = 0; v < dim && f->S; ++v)
+            memcpy(nS + (size_t)v * ncap, f->S + (size_t)v * f->cap,
+                   sizeof(float) * f->K);
+        free(f->S);
+        f->S = nS;
+    }
+    f->cap = ncap;
+}
+
+static float cat_prior(const feat * f, uint32_t v) {
+    /* DD: alphas[v] (dd.hpp:376); DPD: alpha * betas[v] (dpd.hpp:424) */
+    if (f->sh.kind == ORC_DD) return f->sh.alphas[v];
+    return f->sh.p[0] * f->betas[v];
+}
+
+/* Group::init (dd.hpp:113-121, bb.hpp:95-100, gp.hpp:103-107,
+ * nich.hpp:117-123, dpd.hpp:182-186) */
+static void group_init(feat * f, int k) {
+    f->i0[k] = 0;
+    f->i1[k] = 0;
+    f->f0[k] = 0.f;
+    f->f1[k] = 0.f;
+    if (is_cat(f->sh.kind))
+        memset(f->cnt + (size_t)k * f->sh.dim, 0, sizeof(int32_t) * f->sh.dim);
+}
+
+/* Group::add_value (dd.hpp:123-130, bb.hpp:102-107, gp.hpp:109-116,
+ * nich.hpp:125-133, dpd.hpp:188-195) */
+static void group_add(feat * f, int k, uint32_t value) {
+    switch (f->sh.kind) {
+    case ORC_DD:
+    case ORC_DPD:
+        f->i0[k] += 1;
+        f->cnt[(size_t)k * f->sh.dim + value] += 1;
+        break;
+    case ORC_BB:
+        if (value) f->i0[k] += 1; else f->i1[k] += 1;
+        break;
+    case ORC_GP:
+        f->i0[k] = (int32_t)((uint32_t)f->i0[k] + 1u);
+        f->i1[k] = (int32_t)((uint32_t)f->i1[k] + value);
+        f->f0[k] += orc_fast_log_factorial(value);
+        break;
+    case ORC_NICH: {
+        float x = u2f(value);
+        f->i0[k] += 1;
+        float delta = x - f->f0[k];
+        f->f0[k] += delta / (float)f->i0[k];
+        f->f1[k] += delta * (x - f->f0[k]);
+        break;
+    }
+    }
+}
+
+/* Group::remove_value (dd.hpp:142-149, bb.hpp:117-122, gp.hpp:128-135,
+ * nich.hpp:146-165, dpd.hpp:207-214) */
+static void group_remove(feat * f, int k, uint32_t value) {
+    switch (f->sh.kind) {
+    case ORC_DD:
+    case ORC_DPD:
+        f->i0[k] -= 1;
+        f->cnt[(size_t)k * f->sh.dim + value] -= 1;
+        break;
+    case ORC_BB:
+        if (value) f->i0[k] -= 1; else f->i1[k] -= 1;
+        break;
+    case ORC_GP:
+        f->i0[k] = (int32_t)((uint32_t)f->i0[k] - 1u);
+        f->i1[k] = (int32_t)((uint32_t)f->i1[k] - value);
+        f->f0[k] -= orc_fast_log_factorial(value);
+        break;
+    case ORC_NICH: {
+        float x = u2f(value);
+        float total = f->f0[k] * (float)f->i0[k];
+        float delta = x - f->f0[k];
+        f->i0[k] -= 1;
+        if (f->i0[k] == 0) {
+            f->f0[k] = 0.f;
+        } else {
+            f->f0[k] = (total - x) / (float)f->i0[k];
+        }
+        if (f->i0[k] <= 1) {
+            f->f1[k] = 0.f;
+        } else {
+            f->f1[k] -= delta * (x - f->f0[k]);
+        }
+        break;
+    }
+    }
+}
+
+/* the per-group cache entries as a pure function of the group's suffstats */
+typedef struct { float c0, c1, c2, c3; } scorer4;
+
+/* bb.hpp:189-197, gp.hpp:198-207 (+ :56-61), nich.hpp:239-250 (+ :58-69) */
+static scorer4 scorer_init(const orc_shared * sh, int32_t i0, int32_t i1,
+                           float f0, float f1) {
+    scorer4 s = {0, 0, 0, 0};
+    switch (sh->kind) {
+    case ORC_BB: {
+        float alpha = sh->p[0] + (float)i0;
+        float beta = sh->p[1] + (float)i1;
+        s.c0 = orc_fast_log(alpha / (alpha + beta));
+        s.c1 = orc_fast_log(beta / (alpha + beta));
+        break;
+    }
+    case ORC_GP: {
+        float post_alpha = sh->p[0] + (float)(uint32_t)i1;
+        float post_inv_beta = sh->p[1] + (float)(uint32_t)i0;
+        float score_coeff = -orc_fast_log(1.f + post_inv_beta);
+        s.c0 = -orc_fast_lgamma(post_alpha)
+             + post_alpha * (orc_fast_log(post_inv_beta) + score_coeff);
+        s.c1 = post_alpha;
+        s.c2 = score_coeff;
+        break;
+    }
+    case ORC_NICH: {
+        float mu = sh->p[0], kappa = sh->p[1], sigmasq = sh->p[2],
+              nu = sh->p[3];
+        float count = (float)i0, mean = f0, ctv = f1;
+        float mu_1 = mu - mean;
+        float post_kappa = kappa + count;
+        float post_mu = (kappa * mu + mean * count) / post_kappa;
+        float post_nu = nu + count;
+        float post_sigmasq = 1.f / post_nu * (
+            nu * sigmasq + ctv + (count * kappa * mu_1 * mu_1) / post_kappa);
+        float lambda = post_kappa / ((post_kappa + 1.f) * post_sigmasq);
+        s.c0 = orc_fast_lgamma_nu(post_nu)
+             + 0.5f * orc_fast_log(lambda / (3.14159265358979f * post_nu));
+        s.c1 = -0.5f * post_nu - 0.5f;
+        s.c2 = lambda / post_nu;
+        s.c3 = post_mu;
+        break;
+    }
+    }
+    return s;
+}
+
+/* MixtureValueScorer::update_group (dd.hpp:369-379, bb.hpp:247-256,
+ * gp.hpp:262-273, nich.hpp:312-324, dpd.hpp:414-428) */
+static void cache_update_group(feat * f, int k) {
+    if (is_cat(f->sh.kind)) {
+        f->c0[k] = orc_fast_log(f->alpha_sum + (float)f->i0[k]);
+        for (int v = 0; v < f->sh.dim; ++v) {
+            f->S[(size_t)v * f->cap + k] = orc_fast_log(
+                cat_prior(f, v) + (float)f->cnt[(size_t)k * f->sh.dim + v]);
+        }
+    } else {
+        scorer4 s = scorer_init(&f->sh, f->i0[k], f->i1[k], f->f0[k], f->f1[k]);
+        f->c0[k] = s.c0; f->c1[k] = s.c1; f->c2[k] = s.c2; f->c3[k] = s.c3;
+    }
+}
+
+/* MixtureValueScorer::add_value/remove_value: dd.hpp:381-397,458-467 (only
+ * the touched value's entry and the shift); others = update_group */
+static void cache_update_value(feat * f, int k, uint32_t value) {
+    if (is_cat(f->sh.kind)) {
+        f->S[(size_t)value * f->cap + k] = orc_fast_log(
+            cat_prior(f, value)
+            + (float)f->cnt[(size_t)k * f->sh.dim + value]);
+        f->c0[k] = orc_fast_log(f->alpha_sum + (float)f->i0[k]);
+    } else {
+        cache_update_group(f, k);
+    }
+}
+
+/* MixtureSlave::init = resize + update_all (mixture.hpp:354-359;
+ * dd.hpp:399-421, bb.hpp:276-291, gp.hpp/nich.hpp update_all) */
+static void cache_update_all(feat * f) {
+    if (f->sh.kind == ORC_DD) {
+        f->alpha_sum = 0;
+        for (int v = 0; v < f->sh.dim; ++v) f->alpha_sum += f->sh.alphas[v];
+    } else if (f->sh.kind == ORC_DPD) {
+        f->alpha_sum = f->sh.p[0];
+    }
+    for (int k = 0; k < f->K; ++k) cache_update_group(f, k);
+}
+
+static void feat_add_group(feat * f) {   /* mixture.hpp:361-368 */
+    feat_reserve(f, f->K + 1);
+    int k = f->K++;
+    group_init(f, k);
+    cache_update_group(f, k);
+}
+
+static void feat_remove_group(feat * f, int k) {   /* mixture.hpp:370-375 */
+    int last = f->K - 1;
+    if (k != last) {
+        f->i0[k] = f->i0[last]; f->i1[k] = f->i1[last];
+        f->f0[k] = f->f0[last]; f->f1[k] = f->f1[last];
+        f->c0[k] = f->c0[last]; f->c1[k] = f->c1[last];
+        f->c2[k] = f->c2[last]; f->c3[k] = f->c3[last];
+        if (is_cat(f->sh.kind)) {
+            int dim = f->sh.dim;
+            memcpy(f->cnt + (size_t)k * dim, f->cnt + (size_t)last * dim,
+                   sizeof(int32_t) * dim);
+            for (int v = 0; v < dim; ++v)
+                f->S[(size_t)v * f->cap + k] = f->S[(size_t)v * f->cap + last];
+        }
+    }
+    f->K = last;
+}
+
+/* score of `value` under a group given its four cache entries
+ * (gp.hpp:209-217 / gp.cc:57-66, nich.hpp:252-259 / nich.cc:60-66,
+ * bb.hpp:199-204) -- the term that is added to the accumulator */
+static inline float noncat_term(int kind, scorer4 s, uint32_t value,
+                                float log_factorial_value) {
+    switch (kind) {
+    case ORC_BB:
+        return value ? s.c0 : s.c1;
+    case ORC_GP: {
+        float fv = (float)value;
+        return s.c0 + orc_fast_lgamma(s.c1 + fv) - log_factorial_value
+             + s.c2 * fv;
+    }
+    default: { /* ORC_NICH */
+        float x = u2f(value);
+        float d = x - s.c3;
+        float temp = 1.f + s.c2 * (d * d);
+        return s.c0 + s.c1 * orc_fast_log(temp);
+    }
+    }
+}
+
+/* row-score of a categorical value: which table row, or the scalar fallback
+ * of dpd.hpp:534-542 for OTHER */
+static inline float cat_entry(const feat * f, uint32_t value, int k) {
+    if (f->sh.kind == ORC_DPD && value == 0xFFFFFFFFu)
+        return orc_fast_log(f->sh.p[0] * f->sh.p[1]);
+    return f->S[(size_t)value * f->cap + k];
+}
+
+/* MixtureValueScorer::score_value (dd.hpp:433-445 -> vector_add_subtract,
+ * bb.hpp:303-313 -> vector_add, gp.cc:32-67, nich.cc:33-66, dpd.hpp:517-543) */
+static void feat_score_value(const feat * f, uint32_t value, float * acc) {
+    if (is_cat(f->sh.kind)) {
+        for (int k = 0; k < f->K; ++k)
+            acc[k] = (acc[k] + cat_entry(f, value, k)) - f->c0[k];
+        return;
+    }
+    float lf = f->sh.kind == ORC_GP ? orc_fast_log_factorial(value) : 0.f;
+    for (int k = 0; k < f->K; ++k) {
+        scorer4 s = {f->c0[k], f->c1[k], f->c2[k], f->c3[k]};
+        acc[k] += noncat_term(f->sh.kind, s, value, lf);
+    }
+}
+
+/* MixtureValueScorer::score_value_group (dd.hpp:423-431, bb.hpp:293-301,
+ * gp.hpp:300-310, nich.hpp:351-360, dpd.hpp:499-515) */
+static float feat_score_value_group(const feat * f, int k, uint32_t value) {
+    if (is_cat(f->sh.kind)) return cat_entry(f, value, k) - f->c0[k];
+    float lf = f->sh.kind == ORC_GP ? orc_fast_log_factorial(value) : 0.f;
+    scorer4 s = {f->c0[k], f->c1[k], f->c2[k], f->c3[k]};
+    return noncat_term(f->sh.kind, s, value, lf);
+}
+
+/* ------------------------------------------------------------------------ */
+/* driver: clustering.hpp:126-234 over mixture.hpp:48-163                   */
+
+static void py_reserve(orc_mix * m, int need) {
+    if (need <= m->cap) return;
+    int ncap = m->cap ? m->cap : 16;
+    while (ncap < need) ncap *= 2;
+    m->counts = realloc(m->counts, sizeof(int32_t) * ncap);
+    m->shifted = realloc(m->shifted, sizeof(float) * ncap);
+    m->cap = ncap;
+}
+/* clustering.hpp:215-219 */
+static void py_update_nonempty(orc_mix * m, int k) {
+    m->shifted[k] = orc_fast_log((float)m->counts[k] - m->d);
+}
+static float py_empty_score(float alpha, float d, int nonempty, int empty) {
+    float numer = alpha + d * (float)(uint64_t)nonempty;
+    float denom = (float)(uint64_t)empty;
+    return orc_fast_log(numer / denom);
+}
+/* clustering.hpp:221-230 */
+static void py_update_empty(orc_mix * m) {
+    float s = py_empty_score(m->alpha, m->d, m->K - m->n_empty, m->n_empty);
+    for (int k = 0; k < m->K; ++k)
+        if (m->counts[k] == 0) m->shifted[k] = s;
+}
+
+void orc_mix_driver_init(orc_mix * m, const int * counts, int group_count) {
+    py_reserve(m, group_count);
+    m->K = group_count;
+    m->sample_size = 0;
+    m->n_empty = 0;
+    for (int k = 0; k < group_count; ++k) {
+        m->counts[k] = counts[k];
+        m->sample_size += counts[k];
+        if (counts[k] == 0) m->n_empty += 1;
+    }
+    for (int k = 0; k < group_count; ++k)
+        if (m->counts[k]) py_update_nonempty(m, k);
+    py_update_empty(m);
+}
+
+/* clustering.hpp:163-176 + mixture.hpp:73-92 */
+int orc_mix_driver_add_value(orc_mix * m, int g) {
+    int add_group = (m->counts[g] == 0);
+    m->counts[g] += 1;
+    m->sample_size += 1;
+    if (add_group) {
+        py_reserve(m, m->K + 1);
+        m->counts[m->K] = 0;   /* the filled group leaves the empty set, */
+        m->K += 1;             /* a fresh empty group joins it at the end */
+        py_update_empty(m);
+    }
+    py_update_nonempty(m, g);
+    return add_group;
+}
+
+/* clustering.hpp:178-193 + mixture.hpp:94-122 */
+int orc_mix_driver_remove_value(orc_mix * m, int g) {
+    m->counts[g] -= 1;
+    m->sample_size -= 1;
+    int remove_group = (m->counts[g] == 0);
+    if (remove_group) {
+        int last = m->K - 1;
+        if (g != last) {
+            m->counts[g] = m->counts[last];
+            m->shifted[g] = m->shifted[last];
+        }
+        m->K = last;
+        py_update_empty(m);
+    } else {
+        py_update_nonempty(m, g);
+    }
+    return remove_group;
+}
+
+/* clustering.hpp:195-208 */
+void orc_mix_driver_score_value(const orc_mix * m, float * scores) {
+    const float shift =
+        -orc_fast_log((float)(uint64_t)m->sample_size + m->alpha);
+    for (int k = 0; k < m->K; ++k) scores[k] = m->shifted[k] + shift;
+}
+
+int orc_mix_size(const orc_mix * m) { return m->K; }
+int orc_mix_sample_size(const orc_mix * m) { return (int)m->sample_size; }
+int orc_mix_empty_count(const orc_mix * m) { return m->n_empty; }
+void orc_mix_get_counts(const orc_mix * m, int * out) {
+    memcpy(out, m->counts, sizeof(int) * m->K);
+}
+void orc_mix_get_shifted(const orc_mix * m, float * out) {
+    memcpy(out, m->shifted, sizeof(float) * m->K);
+}
+
+/* ------------------------------------------------------------------------ */
+/* id tracker: mixture.hpp:460-521                                          */
+
+void orc_mix_tracker_add_group(orc_mix * m) {
+    if (m->p2g_size + 1 > m->p2g_cap) {
+        m->p2g_cap = m->p2g_cap ? 2 * m->p2g_cap : 16;
+        m->p2g = realloc(m->p2g, sizeof(uint32_t) * m->p2g_cap);
+    }
+    if ((int)m->global_size + 1 > m->g2p_cap) {
+        m->g2p_cap = m->g2p_cap ? 2 * m->g2p_cap : 16;
+        m->g2p = realloc(m->g2p, sizeof(int32_t) * m->g2p_cap);
+    }
+    uint32_t packed = (uint32_t)m->p2g_size;
+    uint32_t global = m->global_size++;
+    m->p2g[m->p2g_size++] = global;
+    m->g2p[global] = (int32_t)packed;
+}
+void orc_mix_tracker_init(orc_mix * m, int group_count) {
+    m->p2g_size = 0;
+    m->global_size = 0;
+    for (int i = 0; i < group_count; ++i) orc_mix_tracker_add_group(m);
+}
+void orc_mix_tracker_remove_group(orc_mix * m, uint32_t packed) {
+    uint32_t global = m->p2g[packed];
+    m->g2p[global] = -1;
+    m->p2g[packed] = m->p2g[m->p2g_size - 1];
+    m->p2g_size -= 1;
+    if ((int)packed != m->p2g_size) {
+        m->g2p[m->p2g[packed]] = (int32_t)packed;
+    }
+}
+uint32_t orc_mix_packed_to_global(const orc_mix * m, uint32_t packed) {
+    return m->p2g[packed];
+}
+uint32_t orc_mix_global_to_packed(const orc_mix * m, uint32_t global) {
+    return (uint32_t)m->g2p[global];
+}
+
+/* ------------------------------------------------------------------------ */
+/* construction / slave API                                                 */
+
+orc_mix * orc_mix_create(float alpha, float d, int F,
+                         const orc_shared * shareds) {
+    orc_mix * m = calloc(1, sizeof(orc_mix));
+    m->alpha = alpha;
+    m->d = d;
+    m->F = F;
+    m->f = calloc(F > 0 ? F : 1, sizeof(feat));
+    for (int i = 0; i < F; ++i) {
+        m->f[i].sh = shareds[i];
+        if (shareds[i].kind == ORC_DPD) {
+            m->f[i].betas = malloc(sizeof(float) * shareds[i].dim);
+            memcpy(m->f[i].betas, shareds[i].betas,
+                   sizeof(float) * shareds[i].dim);
+            m->f[i].sh.betas = m->f[i].betas;
+        }
+    }
+    return m;
+}
+void orc_mix_destroy(orc_mix * m) {
+    if (!m) return;
+    for (int i = 0; i < m->F; ++i) {
+        feat * f = &m->f[i];
+        free(f->i0); free(f->i1); free(f->f0); free(f->f1); free(f->cnt);
+        free(f->c0); free(f->c1); free(f->c2); free(f->c3); free(f->S);
+        free(f->betas);
+    }
+    free(m->f); free(m->counts); free(m->shifted); free(m->p2g); free(m->g2p);
+    free(m);
+}
+
+void orc_mix_slave_clear(orc_mix * m, int fi) { m->f[fi].K = 0; }
+void orc_mix_slave_append_empty(orc_mix * m, int fi) {
+    feat * f = &m->f[fi];
+    feat_reserve(f, f->K + 1);
+    group_init(f, f->K);
+    f->K += 1;
+}
+void orc_mix_slave_group_add_value(orc_mix * m, int fi, int g, uint32_t v) {
+    group_add(&m->f[fi], g, v);
+}
+void orc_mix_slave_init(orc_mix * m, int fi) { cache_update_all(&m->f[fi]); }
+void orc_mix_slave_add_group(orc_mix * m, int fi) { feat_add_group(&m->f[fi]); }
+void orc_mix_slave_remove_group(orc_mix * m, int fi, int g) {
+    feat_remove_group(&m->f[fi], g);
+}
+/* mixture.hpp:377-384 */
+void orc_mix_slave_add_value(orc_mix * m, int fi, int g, uint32_t v) {
+    group_add(&m->f[fi], g, v);
+    cache_update_value(&m->f[fi], g, v);
+}
+/* mixture.hpp:386-398 */
+void orc_mix_slave_remove_value(orc_mix * m, int fi, int g, uint32_t v) {
+    group_remove(&m->f[fi], g, v);
+    cache_update_value(&m->f[fi], g, v);
+}
+float orc_mix_slave_score_value_group(const orc_mix * m, int fi, int g,
+                                      uint32_t v) {
+    return feat_score_value_group(&m->f[fi], g, v);
+}
+void orc_mix_slave_score_value(const orc_mix * m, int fi, uint32_t v,
+                               float * acc) {
+    feat_score_value(&m->f[fi], v, acc);
+}
+int orc_mix_slave_size(const orc_mix * m, int fi) { return m->f[fi].K; }
+void orc_mix_slave_get_group(const orc_mix * m, int fi, int g,
+                             uint32_t * out) {
+    const feat * f = &m->f[fi];
+    switch (f->sh.kind) {
+    case ORC_DD:
+    case ORC_DPD:
+        out[0] = (uint32_t)f->i0[g];
+        memcpy(out + 1, f->cnt + (size_t)g * f->sh.dim, 4 * f->sh.dim);
+        break;
+    case ORC_BB:
+        out[0] = (uint32_t)f->i0[g]; out[1] = (uint32_t)f->i1[g];
+        break;
+    case ORC_GP:
+        out[0] = (uint32_t)f->i0[g]; out[1] = (uint32_t)f->i1[g];
+        out[2] = f2u(f->f0[g]);
+        break;
+    case ORC_NICH:
+        out[0] = (uint32_t)f->i0[g]; out[1] = f2u(f->f0[g]);
+        out[2] = f2u(f->f1[g]);
+        break;
+    }
+}
+
+/* Group::score_value = Scorer::init + Scorer::eval (dd.hpp:222-245,
+ * bb.hpp:185-205, gp.hpp:194-217, nich.hpp:232-259); `group` laid out as
+ * orc_mix_slave_get_group writes it */
+float orc_group_score_value(const orc_shared * sh, const uint32_t * group,
+                            uint32_t value) {
+    if (sh->kind == ORC_DD) {
+        float alpha_sum = 0, mine = 0;
+        for (int v = 0; v < sh->dim; ++v) {
+            float alpha = sh->alphas[v] + (float)(int32_t)group[1 + v];
+            if ((uint32_t)v == value) mine = alpha;
+            alpha_sum += alpha;
+        }
+        return orc_fast_log(mine / alpha_sum);
+    }
+    if (sh->kind == ORC_DPD) { /* dpd.hpp:223-232 */
+        float alpha = sh->p[0];
+        float numer = value == 0xFFFFFFFFu
+            ? alpha * sh->p[1]
+            : alpha * sh->betas[value] + (float)(int32_t)group[1 + value];
+        float denom = alpha + (float)(int32_t)group[0];
+        return orc_fast_log(numer / denom);
+    }
+    scorer4 s;
+    if (sh->kind == ORC_NICH)
+        s = scorer_init(sh, (int32_t)group[0], 0, u2f(group[1]), u2f(group[2]));
+    else
+        s = scorer_init(sh, (int32_t)group[0], (int32_t)group[1], 0.f, 0.f);
+    float lf = sh->kind == ORC_GP ? orc_fast_log_factorial(value) : 0.f;
+    return noncat_term(sh->kind, s, value, lf);
+}
+
+/* ------------------------------------------------------------------------ */
+/* whole-path drivers                                                       */
+
+void orc_mix_init_from_assignments(orc_mix * m, size_t n_rows,
+                                   const uint32_t * const * values,
+                                   const uint32_t * assign_packed,
+                                   int nonempty_groups, int empty_groups,
+                                   uint32_t * assign_global_out) {
+    unsigned saved = orc_ftz_enable();
+    int K = nonempty_groups + empty_groups;
+    int * counts = calloc(K, sizeof(int));
+    for (int fi = 0; fi < m->F; ++fi) {
+        m->f[fi].K = 0;
+        for (int k = 0; k < K; ++k) orc_mix_slave_append_empty(m, fi);
+    }
+    for (size_t i = 0; i < n_rows; ++i) {
+        uint32_t g = assign_packed[i];
+        counts[g] += 1;
+        for (int fi = 0; fi < m->F; ++fi) group_add(&m->f[fi], g, values[fi][i]);
+    }
+    orc_mix_driver_init(m, counts, K);
+    for (int fi = 0; fi < m->F; ++fi) cache_update_all(&m->f[fi]);
+    orc_mix_tracker_init(m, K);
+    if (assign_global_out)
+        for (size_t i = 0; i < n_rows; ++i)
+            assign_global_out[i] = m->p2g[assign_packed[i]];
+    free(counts);
+    orc_ftz_restore(saved);
+}
+
+void orc_mix_gibbs_sequential(orc_mix * m, size_t row_begin, size_t row_end,
+                              const uint32_t * const * values,
+                              uint32_t * assign, uint32_t * rng_state) {
+    unsigned saved = orc_ftz_enable();
+    int scap = m->K + 64;
+    float * scores = malloc(sizeof(float) * scap);
+    for (size_t i = row_begin; i < row_end; ++i) {
+        int g = (int)orc_mix_global_to_packed(m, assign[i]);
+        int removed = orc_mix_driver_remove_value(m, g);
+        for (int fi = 0; fi < m->F; ++fi)
+            orc_mix_slave_remove_value(m, fi, g, values[fi][i]);
+        if (removed) {
+            for (int fi = 0; fi < m->F; ++fi) feat_remove_group(&m->f[fi], g);
+            orc_mix_tracker_remove_group(m, (uint32_t)g);
+        }
+        if (m->K > scap) {
+            scap = 2 * m->K;
+            scores = realloc(scores, sizeof(float) * scap);
+        }
+        orc_mix_driver_score_value(m, scores);
+        for (int fi = 0; fi < m->F; ++fi)
+            feat_score_value(&m->f[fi], values[fi][i], scores);
+        int g2 = (int)orc_sample_from_scores_overwrite(rng_state, m->K, scores);
+        int added = orc_mix_driver_add_value(m, g2);
+        for (int fi = 0; fi < m->F; ++fi)
+            orc_mix_slave_add_value(m, fi, g2, values[fi][i]);
+        if (added) {
+            for (int fi = 0; fi < m->F; ++fi) feat_add_group(&m->f[fi]);
+            orc_mix_tracker_add_group(m);
+        }
+        assign[i] = orc_mix_packed_to_global(m, (uint32_t)g2);
+    }
+    free(scores);
+    orc_ftz_restore(saved);
+}
+
+/* Batch-semantics scores of one row whose current group is `g`: the state at
+ * entry with the row itself taken out.  Nothing is mutated.
+ *   n_g >= 2: group order unchanged, entry g re-derived from (stats - row)
+ *             exactly as remove_value + cache refresh would leave it.
+ *   n_g == 1: the group disappears as MixtureDriver::remove_value does it
+ *             (last group moves into slot g, one group fewer) and the empty
+ *             groups' prior is re-derived with one non-empty group fewer. */
+int orc_mix_batch_row_scores(const orc_mix * m, const uint32_t * x, uint32_t g,
+                             float * scores) {
+    const int K = m->K;
+    const int singleton = (m->counts[g] == 1);
+    const int Kl = singleton ? K - 1 : K;
+    const float shift =
+        -orc_fast_log((float)(uint64_t)(m->sample_size - 1) + m->alpha);
+    float empty_score = 0.f;
+    if (singleton)
+        empty_score = py_empty_score(m->alpha, m->d,
+                                     K - m->n_empty - 1, m->n_empty);
+    for (int k = 0; k < Kl; ++k) {
+        int src = (singleton && k == (int)g) ? K - 1 : k;
+        float c;
+        if (!singleton && k == (int)g) {
+            c = orc_fast_log((float)(m->counts[g] - 1) - m->d);
+        } else if (singleton && m->counts[src] == 0) {
+            c = empty_score;
+        } else {
+            c = m->shifted[src];
+        }
+        scores[k] = c + shift;
+    }
+    for (int fi = 0; fi < m->F; ++fi) {
+        const feat * f = &m->f[fi];
+        uint32_t v = x[fi];
+        float lf = f->sh.kind == ORC_GP ? orc_fast_log_factorial(v) : 0.f;
+        /* the self-removed entry for slot g */
+        float S_g = 0, H_g = 0;
+        scorer4 s_g = {0, 0, 0, 0};
+        if (!singleton) {
+            if (is_cat(f->sh.kind)) {
+                H_g = orc_fast_log(f->alpha_sum + (float)(f->i0[g] - 1));
+                if (f->sh.kind == ORC_DPD && v == 0xFFFFFFFFu)
+                    S_g = cat_entry(f, v, g);
+                else
+                    S_g = orc_fast_log(cat_prior(f, v) + (float)(
+                        f->cnt[(size_t)g * f->sh.dim + v] - 1));
+            } else {
+                feat tmp = *f; /* one-group scratch copy of the stats */
+                int32_t i0 = f->i0[g], i1 = f->i1[g];
+                float f0 = f->f0[g], f1 = f->f1[g];
+                tmp.i0 = &i0; tmp.i1 = &i1; tmp.f0 = &f0; tmp.f1 = &f1;
+                group_remove(&tmp, 0, v);
+                s_g = scorer_init(&f->sh, i0, i1, f0, f1);
+            }
+        }
+        for (int k = 0; k < Kl; ++k) {
+            int src = (singleton && k == (int)g) ? K - 1 : k;
+            int patched = (!singleton && k == (int)g);
+            if (is_cat(f->sh.kind)) {
+                float S = patched ? S_g : cat_entry(f, v, src);
+                float H = patched ? H_g : f->c0[src];
+                scores[k] = (scores[k] + S) - H;
+            } else {
+                scorer4 s = {f->c0[src], f->c1[src], f->c2[src], f->c3[src]};
+                if (patched) s = s_g;
+                scores[k] += noncat_term(f->sh.kind, s, v, lf);
+            }
+        }
+    }
+    return Kl;
+}
+
+void orc_mix_gibbs_batch(orc_mix * m, size_t row_begin, size_t row_end,
+                         const uint32_t * const * values, uint32_t * assign,
+                         uint32_t seed_state, uint64_t draw_base) {
+    unsigned saved = orc_ftz_enable();
+    const int K = m->K;
+    const size_t B = row_end - row_begin;
+    float * scores = malloc(sizeof(float) * (K + 1));
+    uint32_t * old_p = malloc(sizeof(uint32_t) * (B + 1));
+    uint32_t * new_p = malloc(sizeof(uint32_t) * (B + 1));
+    uint32_t x[64];
+    /* phase 1: score + sample every row against the frozen state */
+    for (size_t i = row_begin; i < row_end; ++i) {
+        uint32_t g = orc_mix_global_to_packed(m, assign[i]);
+        for (int fi = 0; fi < m->F; ++fi) x[fi] = values[fi][i];
+        int Kl = orc_mix_batch_row_scores(m, x, g, scores);
+        uint32_t st = orc_rng_jump(seed_state, draw_base + i);
+        float u = orc_sample_unif01(&st);
+        uint32_t g2 = (uint32_t)orc_sample_from_scores_u(Kl, scores, u);
+        if (Kl != K && g2 == g) g2 = (uint32_t)(K - 1); /* slot g held K-1 */
+        old_p[i - row_begin] = g;
+        new_p[i - row_begin] = g2;
+    }
+    /* phase 2: apply all moves in row order (remove, then add, per row) */
+    int32_t * snap_counts = malloc(sizeof(int32_t) * K);
+    memcpy(snap_counts, m->counts, sizeof(int32_t) * K);
+    for (size_t i = row_begin; i < row_end; ++i) {
+        uint32_t g = old_p[i - row_begin], g2 = new_p[i - row_begin];
+        m->counts[g] -= 1;
+        m->counts[g2] += 1;
+        for (int fi = 0; fi < m->F; ++fi) {
+            group_remove(&m->f[fi], g, values[fi][i]);
+            group_add(&m->f[fi], g2, values[fi][i]);
+        }
+        assign[i] = m->p2g[g2];
+    }
+    /* phase 3: normalise the group set.  Groups that lost their last member
+     * are swap-removed in descending slot order; one new empty group is
+     * appended for every previously empty group that gained members. */
+    int created = 0;
+    for (int k = 0; k < K; ++k)
+        if (snap_counts[k] == 0 && m->counts[k] > 0) created += 1;
+    for (int k = K - 1; k >= 0; --k) {
+        if (snap_counts[k] > 0 && m->counts[k] == 0) {
+            int last = m->K - 1;
+            if (k != last) m->counts[k] = m->counts[last];
+            m->K = last;
+            for (int fi = 0; fi < m->F; ++fi) feat_remove_group(&m->f[fi], k);
+            orc_mix_tracker_remove_group(m, (uint32_t)k);
+        }
+    }
+    for (int c = 0; c < created; ++c) {
+        py_reserve(m, m->K + 1);
+        m->counts[m->K] = 0;
+        m->K += 1;
+        for (int fi = 0; fi < m->F; ++fi) {
+            feat * f = &m->f[fi];
+            feat_reserve(f, f->K + 1);
+            group_init(f, f->K);
+            f->K += 1;
+        }
+        orc_mix_tracker_add_group(m);
+    }
+    /* phase 4: caches are pure functions of the statistics */
+    {
+        int * counts = malloc(sizeof(int) * m->K);
+        memcpy(counts, m->counts, sizeof(int) * m->K);
+        orc_mix_driver_init(m, counts, m->K);
+        free(counts);
+    }
+    for (int fi = 0; fi < m->F; ++fi) cache_update_all(&m->f[fi]);
+    free(snap_counts); free(scores); free(old_p); free(new_p);
+    orc_ftz_restore(saved);
+}
