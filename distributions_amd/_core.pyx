@@ -1,0 +1,722 @@
+# cython: language_level=3, boundscheck=False, wraparound=False
+"""Cython binding of libdistributions_hip's C ABI (include/distributions_hip.h).
+
+This is the one extension module of the package; the modules under
+distributions_amd/lp re-export its classes under the names of the reference's
+distributions.lp wrappers (distributions/lp/models/_dd.pyx etc.).  It does no
+arithmetic of its own: every score, cache entry and sample comes from the HIP
+library.  Errors of the library surface as RuntimeError, like the reference's
+`except +` translation of std::runtime_error.
+"""
+from libc.stdint cimport uint32_t, uint64_t, int32_t
+from libc.stddef cimport size_t
+from libc.string cimport memset, memcpy
+from libc.stdlib cimport malloc, free
+
+import numpy as np
+cimport numpy as cnp
+
+cnp.import_array()
+
+cdef extern from "distributions_hip.h" nogil:
+    enum:
+        DIST_DD
+        DIST_BB
+        DIST_GP
+        DIST_NICH
+        DIST_DPD
+    ctypedef struct dist_shared_t:
+        int kind
+        int dim
+        float p[4]
+        float alphas[256]
+        const float * betas
+    size_t dist_group_words(const dist_shared_t *)
+    int dist_abi_version()
+    const char * dist_last_error()
+    int dist_device_count(int *)
+    int dist_set_device(int)
+    int dist_synchronize()
+    uint32_t dist_rng_seed(uint64_t)
+    uint32_t dist_rng_next(uint32_t *)
+    float dist_rng_unif01(uint32_t *)
+    uint32_t dist_rng_jump(uint32_t, uint64_t)
+    int dist_vector_log(size_t, const float *, float *)
+    int dist_vector_exp(size_t, const float *, float *)
+    int dist_vector_lgamma(size_t, const float *, float *)
+    int dist_vector_lgamma_nu(size_t, const float *, float *)
+    int dist_vector_log_factorial(size_t, const uint32_t *, float *)
+    int dist_sample_from_scores_overwrite(uint32_t *, size_t, float *, size_t *)
+    int dist_scores_to_likelihoods(size_t, float *, float *)
+    int dist_sample_from_likelihoods(uint32_t *, size_t, const float *, float,
+                                     size_t *)
+    int dist_log_sum_exp(size_t, const float *, float *)
+    int dist_py_score_add_value(float, float, int, int, int, int, float *)
+    int dist_py_score_remove_value(float, float, int, int, int, int, float *)
+
+    ctypedef struct dist_py_mixture_t:
+        pass
+    dist_py_mixture_t * dist_py_mixture_create()
+    void dist_py_mixture_destroy(dist_py_mixture_t *)
+    int dist_py_mixture_init(dist_py_mixture_t *, float, float, const int *,
+                             size_t)
+    int dist_py_mixture_add_value(dist_py_mixture_t *, float, float, size_t,
+                                  int *)
+    int dist_py_mixture_remove_value(dist_py_mixture_t *, float, float, size_t,
+                                     int *)
+    int dist_py_mixture_score_value(const dist_py_mixture_t *, float, float,
+                                    float *, size_t)
+    size_t dist_py_mixture_size(const dist_py_mixture_t *)
+    size_t dist_py_mixture_sample_size(const dist_py_mixture_t *)
+    int dist_py_mixture_counts(const dist_py_mixture_t *, int *)
+    size_t dist_py_mixture_empty_groupids(const dist_py_mixture_t *, size_t *,
+                                          size_t)
+
+    ctypedef struct dist_mixture_t:
+        pass
+    dist_mixture_t * dist_mixture_create(const dist_shared_t *)
+    void dist_mixture_destroy(dist_mixture_t *)
+    int dist_mixture_clear(dist_mixture_t *)
+    int dist_mixture_append(dist_mixture_t *, const uint32_t *)
+    int dist_mixture_get_group(const dist_mixture_t *, size_t, uint32_t *)
+    size_t dist_mixture_size(const dist_mixture_t *)
+    int dist_mixture_init(dist_mixture_t *)
+    int dist_mixture_add_group(dist_mixture_t *)
+    int dist_mixture_remove_group(dist_mixture_t *, size_t)
+    int dist_mixture_add_value(dist_mixture_t *, size_t, uint32_t)
+    int dist_mixture_remove_value(dist_mixture_t *, size_t, uint32_t)
+    int dist_mixture_score_value_group(const dist_mixture_t *, size_t,
+                                       uint32_t, float *)
+    int dist_mixture_score_value(const dist_mixture_t *, uint32_t, float *,
+                                 size_t)
+
+    int dist_group_init(const dist_shared_t *, uint32_t *)
+    int dist_group_add_value(const dist_shared_t *, uint32_t *, uint32_t)
+    int dist_group_remove_value(const dist_shared_t *, uint32_t *, uint32_t)
+    int dist_group_score_value(const dist_shared_t *, const uint32_t *,
+                               uint32_t, float *)
+
+    ctypedef struct dist_id_tracker_t:
+        pass
+    dist_id_tracker_t * dist_id_tracker_create()
+    void dist_id_tracker_destroy(dist_id_tracker_t *)
+    int dist_id_tracker_init(dist_id_tracker_t *, size_t)
+    int dist_id_tracker_add_group(dist_id_tracker_t *)
+    int dist_id_tracker_remove_group(dist_id_tracker_t *, uint32_t)
+    int dist_id_tracker_packed_to_global(const dist_id_tracker_t *, uint32_t,
+                                         uint32_t *)
+    int dist_id_tracker_global_to_packed(const dist_id_tracker_t *, uint32_t,
+                                         uint32_t *)
+    size_t dist_id_tracker_packed_size(const dist_id_tracker_t *)
+    size_t dist_id_tracker_global_size(const dist_id_tracker_t *)
+
+    ctypedef struct dist_gibbs_t:
+        pass
+    dist_gibbs_t * dist_gibbs_create(float, float, int, const dist_shared_t *)
+    void dist_gibbs_destroy(dist_gibbs_t *)
+    int dist_gibbs_load_rows(dist_gibbs_t *, size_t, const uint32_t * const *,
+                             const uint32_t *, int, int, uint64_t)
+    int dist_gibbs_load_rows_dev(dist_gibbs_t *, size_t,
+                                 const uint32_t * const *, uint32_t *, int,
+                                 int, uint64_t)
+    size_t dist_gibbs_stat_words(const dist_gibbs_t *)
+    int dist_gibbs_export_stats_dev(const dist_gibbs_t *, int32_t *)
+    int dist_gibbs_import_stats_dev(dist_gibbs_t *, const int32_t *)
+    int dist_gibbs_sweep(dist_gibbs_t *, size_t, size_t, size_t, uint32_t,
+                         uint64_t)
+    int dist_gibbs_sweep_sequential(dist_gibbs_t *, size_t, size_t, uint32_t *)
+    int dist_gibbs_batch_sample(dist_gibbs_t *, size_t, size_t, uint32_t,
+                                uint64_t)
+    int dist_gibbs_batch_delta_dev(dist_gibbs_t *, int32_t *)
+    int dist_gibbs_batch_apply_delta_dev(dist_gibbs_t *, const int32_t *)
+    int dist_gibbs_batch_apply_local(dist_gibbs_t *)
+    int dist_gibbs_batch_finish(dist_gibbs_t *)
+    int dist_gibbs_row_scores(dist_gibbs_t *, size_t, float *, size_t *)
+    int dist_gibbs_score_rows_dev(dist_gibbs_t *, size_t, size_t, float *,
+                                  size_t)
+    size_t dist_gibbs_group_count(const dist_gibbs_t *)
+    size_t dist_gibbs_row_count(const dist_gibbs_t *)
+    int dist_gibbs_counts(const dist_gibbs_t *, int *)
+    int dist_gibbs_assignments(const dist_gibbs_t *, uint32_t *)
+    int dist_gibbs_get_group(const dist_gibbs_t *, int, size_t, uint32_t *)
+    int dist_gibbs_packed_to_global(const dist_gibbs_t *, uint32_t, uint32_t *)
+    int dist_gibbs_global_to_packed(const dist_gibbs_t *, uint32_t, uint32_t *)
+    int dist_gibbs_kernel_stats(dist_gibbs_t *, double *, uint64_t *,
+                                uint64_t *, int)
+
+
+KIND_DD = DIST_DD
+KIND_BB = DIST_BB
+KIND_GP = DIST_GP
+KIND_NICH = DIST_NICH
+KIND_DPD = DIST_DPD
+DPD_OTHER = 0xFFFFFFFF
+
+
+cdef inline int check(int rc) except -1:
+    if rc != 0:
+        raise RuntimeError(dist_last_error().decode("utf-8", "replace"))
+    return 0
+
+
+def abi_version():
+    return dist_abi_version()
+
+
+def device_count():
+    cdef int n = 0
+    check(dist_device_count(&n))
+    return n
+
+
+def set_device(int device):
+    check(dist_set_device(device))
+
+
+def synchronize():
+    check(dist_synchronize())
+
+
+# ---------------------------------------------------------------------------
+# Shared: the hyper-parameters of one feature
+
+cdef class SharedParams:
+    """dist_shared_t plus the storage it points at."""
+    cdef dist_shared_t c
+    cdef object _betas
+
+    def __cinit__(self):
+        memset(&self.c, 0, sizeof(dist_shared_t))
+        self._betas = None
+
+    @staticmethod
+    def make(int kind, p=(), alphas=(), betas=None):
+        cdef SharedParams s = SharedParams()
+        cdef int i
+        cdef cnp.ndarray[cnp.float32_t, ndim=1] b
+        s.c.kind = kind
+        for i in range(len(p)):
+            s.c.p[i] = p[i]
+        if kind == DIST_DD:
+            if not 1 <= len(alphas) <= 256:
+                raise RuntimeError("expected 1 <= dim <= 256")
+            s.c.dim = len(alphas)
+            for i in range(len(alphas)):
+                s.c.alphas[i] = alphas[i]
+        if kind == DIST_DPD:
+            b = np.ascontiguousarray(betas, dtype=np.float32)
+            s._betas = b
+            s.c.dim = b.shape[0]
+            s.c.betas = <const float *> b.data
+        return s
+
+    property kind:
+        def __get__(self):
+            return self.c.kind
+
+    property dim:
+        def __get__(self):
+            return self.c.dim
+
+    property p:
+        def __get__(self):
+            return [self.c.p[i] for i in range(4)]
+
+    property alphas:
+        def __get__(self):
+            return [self.c.alphas[i] for i in range(self.c.dim)]
+
+    property betas:
+        def __get__(self):
+            return None if self._betas is None else self._betas.copy()
+
+    def group_words(self):
+        return dist_group_words(&self.c)
+
+    # Model::Group scalar operations on a words array
+    def group_init(self):
+        cdef cnp.ndarray[cnp.uint32_t, ndim=1] g = np.zeros(
+            self.group_words(), np.uint32)
+        check(dist_group_init(&self.c, <uint32_t *> g.data))
+        return g
+
+    def group_add_value(self, cnp.ndarray[cnp.uint32_t, ndim=1] g,
+                        uint32_t value):
+        check(dist_group_add_value(&self.c, <uint32_t *> g.data, value))
+
+    def group_remove_value(self, cnp.ndarray[cnp.uint32_t, ndim=1] g,
+                           uint32_t value):
+        check(dist_group_remove_value(&self.c, <uint32_t *> g.data, value))
+
+    def group_score_value(self, cnp.ndarray[cnp.uint32_t, ndim=1] g,
+                          uint32_t value):
+        cdef float out = 0
+        check(dist_group_score_value(&self.c, <const uint32_t *> g.data, value,
+                                     &out))
+        return out
+
+
+# ---------------------------------------------------------------------------
+# entropy and sampling
+
+def rng_seed(seed):
+    return dist_rng_seed(<uint64_t> seed)
+
+
+def rng_next(uint32_t state):
+    """-> (raw engine output == new state)"""
+    cdef uint32_t s = state
+    dist_rng_next(&s)
+    return s
+
+
+def rng_unif01(uint32_t state):
+    """-> (u, new state)"""
+    cdef uint32_t s = state
+    cdef float u = dist_rng_unif01(&s)
+    return u, s
+
+
+def rng_jump(uint32_t state, steps):
+    return dist_rng_jump(state, <uint64_t> steps)
+
+
+def _vector(int op, x):
+    cdef cnp.ndarray[cnp.float32_t, ndim=1] a
+    cdef cnp.ndarray[cnp.uint32_t, ndim=1] u
+    cdef cnp.ndarray[cnp.float32_t, ndim=1] out
+    if op == 4:
+        u = np.ascontiguousarray(x, dtype=np.uint32)
+        out = np.zeros(u.shape[0], np.float32)
+        check(dist_vector_log_factorial(u.shape[0], <const uint32_t *> u.data,
+                                        <float *> out.data))
+        return out
+    a = np.ascontiguousarray(x, dtype=np.float32)
+    out = np.zeros(a.shape[0], np.float32)
+    if op == 0:
+        check(dist_vector_log(a.shape[0], <const float *> a.data, <float *> out.data))
+    elif op == 1:
+        check(dist_vector_exp(a.shape[0], <const float *> a.data, <float *> out.data))
+    elif op == 2:
+        check(dist_vector_lgamma(a.shape[0], <const float *> a.data, <float *> out.data))
+    else:
+        check(dist_vector_lgamma_nu(a.shape[0], <const float *> a.data, <float *> out.data))
+    return out
+
+
+def vector_log(x):
+    return _vector(0, x)
+
+
+def vector_exp(x):
+    return _vector(1, x)
+
+
+def vector_lgamma(x):
+    return _vector(2, x)
+
+
+def vector_lgamma_nu(x):
+    return _vector(3, x)
+
+
+def vector_log_factorial(x):
+    return _vector(4, x)
+
+
+def sample_from_scores_overwrite(uint32_t state,
+                                 cnp.ndarray[cnp.float32_t, ndim=1] scores):
+    """-> (sample, new state); scores become likelihoods in place"""
+    cdef uint32_t s = state
+    cdef size_t sample = 0
+    check(dist_sample_from_scores_overwrite(&s, scores.shape[0],
+                                            <float *> scores.data, &sample))
+    return sample, s
+
+
+def scores_to_likelihoods(cnp.ndarray[cnp.float32_t, ndim=1] scores):
+    cdef float total = 0
+    check(dist_scores_to_likelihoods(scores.shape[0], <float *> scores.data,
+                                     &total))
+    return total
+
+
+def sample_from_likelihoods(uint32_t state,
+                            cnp.ndarray[cnp.float32_t, ndim=1] likelihoods,
+                            float total):
+    cdef uint32_t s = state
+    cdef size_t sample = 0
+    check(dist_sample_from_likelihoods(&s, likelihoods.shape[0],
+                                       <const float *> likelihoods.data, total,
+                                       &sample))
+    return sample, s
+
+
+def log_sum_exp(scores):
+    cdef cnp.ndarray[cnp.float32_t, ndim=1] a = np.ascontiguousarray(
+        scores, dtype=np.float32)
+    cdef float out = 0
+    check(dist_log_sum_exp(a.shape[0], <const float *> a.data, &out))
+    return out
+
+
+def py_score_add_value(float alpha, float d, int group_size,
+                       int nonempty_group_count, int sample_size,
+                       int empty_group_count=1):
+    cdef float out = 0
+    check(dist_py_score_add_value(alpha, d, group_size, nonempty_group_count,
+                                  sample_size, empty_group_count, &out))
+    return out
+
+
+def py_score_remove_value(float alpha, float d, int group_size,
+                          int nonempty_group_count, int sample_size,
+                          int empty_group_count=1):
+    cdef float out = 0
+    check(dist_py_score_remove_value(alpha, d, group_size,
+                                     nonempty_group_count, sample_size,
+                                     empty_group_count, &out))
+    return out
+
+
+# ---------------------------------------------------------------------------
+# PitmanYor::Mixture
+
+cdef class PyMixture:
+    cdef dist_py_mixture_t * ptr
+
+    def __cinit__(self):
+        self.ptr = dist_py_mixture_create()
+        if self.ptr == NULL:
+            raise RuntimeError(dist_last_error().decode())
+
+    def __dealloc__(self):
+        if self.ptr != NULL:
+            dist_py_mixture_destroy(self.ptr)
+
+    def __len__(self):
+        return dist_py_mixture_size(self.ptr)
+
+    def init(self, float alpha, float d, counts):
+        cdef cnp.ndarray[cnp.int32_t, ndim=1] c = np.ascontiguousarray(
+            counts, dtype=np.int32)
+        check(dist_py_mixture_init(self.ptr, alpha, d, <const int *> c.data,
+                                   c.shape[0]))
+
+    def add_value(self, float alpha, float d, size_t groupid):
+        cdef int added = 0
+        check(dist_py_mixture_add_value(self.ptr, alpha, d, groupid, &added))
+        return bool(added)
+
+    def remove_value(self, float alpha, float d, size_t groupid):
+        cdef int removed = 0
+        check(dist_py_mixture_remove_value(self.ptr, alpha, d, groupid,
+                                           &removed))
+        return bool(removed)
+
+    def score_value(self, float alpha, float d,
+                    cnp.ndarray[cnp.float32_t, ndim=1] scores):
+        check(dist_py_mixture_score_value(self.ptr, alpha, d,
+                                          <float *> scores.data,
+                                          scores.shape[0]))
+
+    def sample_size(self):
+        return dist_py_mixture_sample_size(self.ptr)
+
+    def counts(self):
+        cdef cnp.ndarray[cnp.int32_t, ndim=1] out = np.zeros(len(self),
+                                                            np.int32)
+        if len(self):
+            check(dist_py_mixture_counts(self.ptr, <int *> out.data))
+        return out
+
+    def empty_groupids(self):
+        cdef size_t n = dist_py_mixture_empty_groupids(self.ptr, NULL, 0)
+        cdef size_t * buf = <size_t *> malloc(sizeof(size_t) * (n + 1))
+        dist_py_mixture_empty_groupids(self.ptr, buf, n)
+        out = [buf[i] for i in range(n)]
+        free(buf)
+        return out
+
+
+# ---------------------------------------------------------------------------
+# Model::Mixture
+
+cdef class SlaveMixture:
+    cdef dist_mixture_t * ptr
+    cdef SharedParams shared
+
+    def __cinit__(self, SharedParams shared):
+        self.shared = shared
+        self.ptr = dist_mixture_create(&shared.c)
+        if self.ptr == NULL:
+            raise RuntimeError(dist_last_error().decode())
+
+    def __dealloc__(self):
+        if self.ptr != NULL:
+            dist_mixture_destroy(self.ptr)
+
+    def __len__(self):
+        return dist_mixture_size(self.ptr)
+
+    def clear(self):
+        check(dist_mixture_clear(self.ptr))
+
+    def append(self, cnp.ndarray[cnp.uint32_t, ndim=1] group):
+        if group.shape[0] != <Py_ssize_t> self.shared.group_words():
+            raise RuntimeError("group has the wrong size")
+        check(dist_mixture_append(self.ptr, <const uint32_t *> group.data))
+
+    def get_group(self, size_t groupid):
+        cdef cnp.ndarray[cnp.uint32_t, ndim=1] g = np.zeros(
+            self.shared.group_words(), np.uint32)
+        check(dist_mixture_get_group(self.ptr, groupid, <uint32_t *> g.data))
+        return g
+
+    def init(self):
+        check(dist_mixture_init(self.ptr))
+
+    def add_group(self):
+        check(dist_mixture_add_group(self.ptr))
+
+    def remove_group(self, size_t groupid):
+        check(dist_mixture_remove_group(self.ptr, groupid))
+
+    def add_value(self, size_t groupid, uint32_t value):
+        check(dist_mixture_add_value(self.ptr, groupid, value))
+
+    def remove_value(self, size_t groupid, uint32_t value):
+        check(dist_mixture_remove_value(self.ptr, groupid, value))
+
+    def score_value_group(self, size_t groupid, uint32_t value):
+        cdef float out = 0
+        check(dist_mixture_score_value_group(self.ptr, groupid, value, &out))
+        return out
+
+    def score_value(self, uint32_t value,
+                    cnp.ndarray[cnp.float32_t, ndim=1] scores_accum):
+        check(dist_mixture_score_value(self.ptr, value,
+                                       <float *> scores_accum.data,
+                                       scores_accum.shape[0]))
+
+
+# ---------------------------------------------------------------------------
+# MixtureIdTracker
+
+cdef class IdTracker:
+    cdef dist_id_tracker_t * ptr
+
+    def __cinit__(self):
+        self.ptr = dist_id_tracker_create()
+
+    def __dealloc__(self):
+        if self.ptr != NULL:
+            dist_id_tracker_destroy(self.ptr)
+
+    def init(self, size_t group_count=0):
+        check(dist_id_tracker_init(self.ptr, group_count))
+
+    def add_group(self):
+        check(dist_id_tracker_add_group(self.ptr))
+
+    def remove_group(self, uint32_t packed):
+        check(dist_id_tracker_remove_group(self.ptr, packed))
+
+    def packed_to_global(self, uint32_t packed):
+        cdef uint32_t out = 0
+        check(dist_id_tracker_packed_to_global(self.ptr, packed, &out))
+        return out
+
+    def global_to_packed(self, uint32_t global_):
+        cdef uint32_t out = 0
+        check(dist_id_tracker_global_to_packed(self.ptr, global_, &out))
+        return out
+
+    def packed_size(self):
+        return dist_id_tracker_packed_size(self.ptr)
+
+    def global_size(self):
+        return dist_id_tracker_global_size(self.ptr)
+
+
+# ---------------------------------------------------------------------------
+# the batched row engine
+
+def value_words(int kind, values):
+    """Values of one feature as the 32-bit words the ABI takes."""
+    if kind == DIST_NICH:
+        return np.ascontiguousarray(values, dtype=np.float32).view(np.uint32)
+    return np.ascontiguousarray(values).astype(np.uint32)
+
+
+cdef class GibbsEngine:
+    cdef dist_gibbs_t * ptr
+    cdef list shareds
+    cdef object _keep   # device tensors / arrays the engine points into
+
+    def __cinit__(self, float alpha, float d, shareds):
+        cdef int n = len(shareds)
+        cdef dist_shared_t * arr = <dist_shared_t *> malloc(
+            sizeof(dist_shared_t) * (n + 1))
+        cdef SharedParams s
+        cdef int i
+        for i in range(n):
+            s = shareds[i]
+            memcpy(&arr[i], &s.c, sizeof(dist_shared_t))
+        self.shareds = list(shareds)
+        self.ptr = dist_gibbs_create(alpha, d, n, arr)
+        free(arr)
+        if self.ptr == NULL:
+            raise RuntimeError(dist_last_error().decode())
+
+    def __dealloc__(self):
+        if self.ptr != NULL:
+            dist_gibbs_destroy(self.ptr)
+
+    def load_rows(self, values, assign_packed, int nonempty_groups,
+                  int empty_groups=1, row_offset=0):
+        """values: one host array per feature; assign_packed: host uint32."""
+        cdef int n = len(self.shareds)
+        cdef cnp.ndarray[cnp.uint32_t, ndim=1] a = np.ascontiguousarray(
+            assign_packed, dtype=np.uint32)
+        cdef const uint32_t ** ptrs = <const uint32_t **> malloc(
+            sizeof(void *) * (n + 1))
+        cdef cnp.ndarray[cnp.uint32_t, ndim=1] w
+        cdef SharedParams s
+        words = []
+        cdef int i
+        for i in range(n):
+            s = self.shareds[i]
+            w = value_words(s.c.kind, values[i])
+            if w.shape[0] != a.shape[0]:
+                free(ptrs)
+                raise RuntimeError("feature columns differ in length")
+            words.append(w)
+            ptrs[i] = <const uint32_t *> w.data
+        cdef int rc = dist_gibbs_load_rows(self.ptr, a.shape[0], ptrs,
+                                           <const uint32_t *> a.data,
+                                           nonempty_groups, empty_groups,
+                                           <uint64_t> row_offset)
+        free(ptrs)
+        check(rc)
+
+    def load_rows_dev(self, value_ptrs, size_t assign_ptr, size_t n_rows,
+                      int nonempty_groups, int empty_groups=1, row_offset=0,
+                      keep=None):
+        """Device pointers (e.g. torch tensor data_ptr()); `keep` holds the
+        owners alive for the lifetime of the engine."""
+        cdef int n = len(self.shareds)
+        cdef const uint32_t ** ptrs = <const uint32_t **> malloc(
+            sizeof(void *) * (n + 1))
+        cdef int i
+        cdef size_t addr
+        for i in range(n):
+            addr = value_ptrs[i]
+            ptrs[i] = <const uint32_t *> addr
+        self._keep = keep
+        cdef int rc = dist_gibbs_load_rows_dev(
+            self.ptr, n_rows, ptrs, <uint32_t *> assign_ptr, nonempty_groups,
+            empty_groups, <uint64_t> row_offset)
+        free(ptrs)
+        check(rc)
+
+    def stat_words(self):
+        return dist_gibbs_stat_words(self.ptr)
+
+    def export_stats_dev(self, size_t ptr):
+        check(dist_gibbs_export_stats_dev(self.ptr, <int32_t *> ptr))
+
+    def import_stats_dev(self, size_t ptr):
+        check(dist_gibbs_import_stats_dev(self.ptr, <const int32_t *> ptr))
+
+    def sweep(self, size_t row_begin, size_t row_end, size_t batch_rows,
+              uint32_t seed_state, draw_base=0):
+        cdef uint64_t db = <uint64_t> draw_base
+        cdef int rc
+        with nogil:
+            rc = dist_gibbs_sweep(self.ptr, row_begin, row_end, batch_rows,
+                                  seed_state, db)
+        check(rc)
+
+    def sweep_sequential(self, size_t row_begin, size_t row_end,
+                         uint32_t rng_state):
+        """-> new rng state"""
+        cdef uint32_t s = rng_state
+        cdef int rc
+        with nogil:
+            rc = dist_gibbs_sweep_sequential(self.ptr, row_begin, row_end, &s)
+        check(rc)
+        return s
+
+    def batch_sample(self, size_t row_begin, size_t row_end,
+                     uint32_t seed_state, draw_base=0):
+        check(dist_gibbs_batch_sample(self.ptr, row_begin, row_end, seed_state,
+                                      <uint64_t> draw_base))
+
+    def batch_delta_dev(self, size_t ptr):
+        check(dist_gibbs_batch_delta_dev(self.ptr, <int32_t *> ptr))
+
+    def batch_apply_delta_dev(self, size_t ptr):
+        check(dist_gibbs_batch_apply_delta_dev(self.ptr, <const int32_t *> ptr))
+
+    def batch_apply_local(self):
+        check(dist_gibbs_batch_apply_local(self.ptr))
+
+    def batch_finish(self):
+        check(dist_gibbs_batch_finish(self.ptr))
+
+    def row_scores(self, size_t row):
+        cdef cnp.ndarray[cnp.float32_t, ndim=1] out = np.zeros(
+            self.group_count() + 1, np.float32)
+        cdef size_t n = 0
+        check(dist_gibbs_row_scores(self.ptr, row, <float *> out.data, &n))
+        return out[:n].copy()
+
+    def score_rows_dev(self, size_t row_begin, size_t row_end, size_t ptr,
+                       size_t ld):
+        check(dist_gibbs_score_rows_dev(self.ptr, row_begin, row_end,
+                                        <float *> ptr, ld))
+
+    def group_count(self):
+        return dist_gibbs_group_count(self.ptr)
+
+    def row_count(self):
+        return dist_gibbs_row_count(self.ptr)
+
+    def counts(self):
+        cdef cnp.ndarray[cnp.int32_t, ndim=1] out = np.zeros(
+            self.group_count(), np.int32)
+        check(dist_gibbs_counts(self.ptr, <int *> out.data))
+        return out
+
+    def assignments(self):
+        cdef cnp.ndarray[cnp.uint32_t, ndim=1] out = np.zeros(
+            max(1, self.row_count()), np.uint32)
+        check(dist_gibbs_assignments(self.ptr, <uint32_t *> out.data))
+        return out[:self.row_count()]
+
+    def get_group(self, int feature, size_t groupid):
+        cdef SharedParams s = self.shareds[feature]
+        cdef cnp.ndarray[cnp.uint32_t, ndim=1] g = np.zeros(s.group_words(),
+                                                            np.uint32)
+        check(dist_gibbs_get_group(self.ptr, feature, groupid,
+                                   <uint32_t *> g.data))
+        return g
+
+    def packed_to_global(self, uint32_t packed):
+        cdef uint32_t out = 0
+        check(dist_gibbs_packed_to_global(self.ptr, packed, &out))
+        return out
+
+    def global_to_packed(self, uint32_t global_):
+        cdef uint32_t out = 0
+        check(dist_gibbs_global_to_packed(self.ptr, global_, &out))
+        return out
+
+    def kernel_stats(self, reset=False):
+        """-> (ms, launches, rows) of the score+sample kernel (HIP events)"""
+        cdef double ms = 0
+        cdef uint64_t launches = 0, rows = 0
+        check(dist_gibbs_kernel_stats(self.ptr, &ms, &launches, &rows,
+                                      1 if reset else 0))
+        return ms, launches, rows

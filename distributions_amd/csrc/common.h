@@ -1,0 +1,106 @@
+// Shared host-side plumbing of libdistributions_hip: error reporting, device
+// buffers, one-time table upload.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/distributions_hip.h"
+#include "special.h"
+
+namespace dist {
+
+struct Error : std::runtime_error {
+    explicit Error(const std::string & what) : std::runtime_error(what) {}
+};
+
+#define DIST_REQUIRE(cond, msg)                                              \
+    do {                                                                     \
+        if (!(cond)) throw ::dist::Error(std::string("ERROR ") + (msg));     \
+    } while (0)
+
+#define HIP_CHECK(expr)                                                      \
+    do {                                                                     \
+        hipError_t err_ = (expr);                                            \
+        if (err_ != hipSuccess)                                              \
+            throw ::dist::Error(std::string("HIP error: ") +                 \
+                                hipGetErrorString(err_) + " at " #expr);     \
+    } while (0)
+
+void set_last_error(const std::string & what);
+
+// Runs `body`, converting exceptions into the C ABI's status + message.
+template <class F>
+int guarded(F && body) {
+    try {
+        body();
+        return 0;
+    } catch (const std::exception & e) {
+        set_last_error(e.what());
+        return 1;
+    } catch (...) {
+        set_last_error("unknown error");
+        return 1;
+    }
+}
+
+// Uploads the special-function tables to the current device (once per device)
+// and fails loudly when there is no usable GPU: there is no CPU fallback.
+void ensure_device_ready();
+hipStream_t stream();
+
+template <class T>
+struct DeviceBuf {
+    T * p = nullptr;
+    size_t cap = 0;
+    DeviceBuf() = default;
+    DeviceBuf(const DeviceBuf &) = delete;
+    DeviceBuf & operator=(const DeviceBuf &) = delete;
+    DeviceBuf(DeviceBuf && o) noexcept : p(o.p), cap(o.cap) {
+        o.p = nullptr;
+        o.cap = 0;
+    }
+    ~DeviceBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    // grows to at least n elements, keeping the first `keep` elements
+    void reserve(size_t n, size_t keep) {
+        if (n <= cap) return;
+        T * q = nullptr;
+        HIP_CHECK(hipMalloc(&q, n * sizeof(T)));
+        HIP_CHECK(hipMemsetAsync(q, 0, n * sizeof(T), stream()));
+        if (p && keep)
+            HIP_CHECK(hipMemcpyAsync(q, p, keep * sizeof(T),
+                                     hipMemcpyDeviceToDevice, stream()));
+        HIP_CHECK(hipStreamSynchronize(stream()));
+        if (p) (void)hipFree(p);
+        p = q;
+        cap = n;
+    }
+    void upload(const T * host, size_t n) {
+        reserve(n, 0);
+        if (n)
+            HIP_CHECK(hipMemcpyAsync(p, host, n * sizeof(T),
+                                     hipMemcpyHostToDevice, stream()));
+    }
+    void download(T * host, size_t n) const {
+        if (n)
+            HIP_CHECK(hipMemcpyAsync(host, p, n * sizeof(T),
+                                     hipMemcpyDeviceToHost, stream()));
+        HIP_CHECK(hipStreamSynchronize(stream()));
+    }
+};
+
+inline size_t grow_capacity(size_t need) {
+    size_t c = 64;
+    while (c < need) c *= 2;
+    return c;
+}
+
+}  // namespace dist

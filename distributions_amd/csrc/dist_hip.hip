@@ -1,0 +1,1365 @@
+// libdistributions_hip.so -- host side: device-resident mixture objects and
+// the C ABI declared in include/distributions_hip.h.  gfx950 only.
+//
+// Structure mirrors the reference's objects, not its code:
+//   PyDriver  ~ Clustering<int>::PitmanYor::CachedMixture (clustering.hpp:126-234)
+//   Slave     ~ MixtureSlave<Model,...>                    (mixture.hpp:340-450)
+//   Tracker   ~ MixtureIdTracker                           (mixture.hpp:460-521)
+//   Gibbs     = the three together over a resident row table (extension)
+// All numeric state is in HBM; the host keeps structure (group count, the
+// empty-group set, id maps) and a mirror of the integer group sizes.
+#include <algorithm>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <set>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace dist {
+
+__device__ Tables g_tables_dev;
+static Tables g_tables_host_storage;
+const Tables * g_tables_host = nullptr;
+
+static thread_local std::string t_last_error;
+void set_last_error(const std::string & what) { t_last_error = what; }
+
+static std::mutex g_init_mutex;
+static std::set<int> g_ready_devices;
+
+static void fill_host_tables() {
+    Tables & t = g_tables_host_storage;
+    memcpy(t.log_table, DIST_REF_LOG_TABLE, sizeof(t.log_table));
+    memcpy(t.exp_table, DIST_REF_EXP_TABLE, sizeof(t.exp_table));
+    memcpy(t.lgamma_coeff5, DIST_REF_LGAMMA_COEFF5, sizeof(t.lgamma_coeff5));
+    memcpy(t.lgamma_nu_coeff3, DIST_REF_LGAMMA_NU_COEFF3,
+           sizeof(t.lgamma_nu_coeff3));
+    memcpy(t.log_factorial, DIST_REF_LOG_FACTORIAL, sizeof(t.log_factorial));
+    memcpy(t.exp_ab, DIST_REF_EXP_AB, sizeof(t.exp_ab));
+    g_tables_host = &g_tables_host_storage;
+}
+
+static void ensure_host_tables() {
+    std::lock_guard<std::mutex> lock(g_init_mutex);
+    if (!g_tables_host) fill_host_tables();
+}
+
+void ensure_device_ready() {
+    std::lock_guard<std::mutex> lock(g_init_mutex);
+    if (!g_tables_host) fill_host_tables();
+    int n = 0;
+    hipError_t err = hipGetDeviceCount(&n);
+    if (err != hipSuccess || n == 0)
+        throw Error("no HIP device: libdistributions_hip has no CPU path");
+    int dev = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    if (g_ready_devices.count(dev)) return;
+    hipDeviceProp_t prop;
+    HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+        throw Error(std::string("built for gfx950, found ") + prop.gcnArchName);
+    HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_tables_dev),
+                                &g_tables_host_storage, sizeof(Tables)));
+    HIP_CHECK(hipDeviceSynchronize());
+    g_ready_devices.insert(dev);
+}
+
+hipStream_t stream() { return nullptr; }   // the per-thread default stream
+
+static inline dim3 grid_for(size_t n, int block = kBlock) {
+    return dim3((unsigned)std::max<size_t>(1, (n + block - 1) / block));
+}
+#define LAUNCH(kernel, n, ...)                                               \
+    do {                                                                     \
+        hipLaunchKernelGGL(kernel, grid_for(n), dim3(kBlock), 0, stream(),   \
+                           __VA_ARGS__);                                     \
+        HIP_CHECK(hipGetLastError());                                        \
+    } while (0)
+#define LAUNCH1(kernel, ...)                                                 \
+    do {                                                                     \
+        hipLaunchKernelGGL(kernel, dim3(1), dim3(1), 0, stream(),            \
+                           __VA_ARGS__);                                     \
+        HIP_CHECK(hipGetLastError());                                        \
+    } while (0)
+
+static void sync() { HIP_CHECK(hipStreamSynchronize(stream())); }
+
+static size_t group_words(const dist_shared_t & sh) {
+    return is_cat(sh.kind) ? 1 + (size_t)sh.dim
+                           : (sh.kind == DIST_BB ? 2 : 3);
+}
+
+static void check_shared(const dist_shared_t & sh) {
+    DIST_REQUIRE(sh.kind >= DIST_DD && sh.kind <= DIST_DPD, "bad model kind");
+    if (sh.kind == DIST_DD)
+        DIST_REQUIRE(sh.dim >= 1 && sh.dim <= DIST_DD_MAX_DIM,
+                     "expected 1 <= dim <= 256");
+    if (sh.kind == DIST_DPD)
+        DIST_REQUIRE(sh.dim >= 1 && sh.betas != nullptr, "DPD needs betas");
+}
+
+// a reusable scratch of device floats for the per-call API paths
+struct Scratch {
+    DeviceBuf<float> f;
+    DeviceBuf<SampleOut> s;
+};
+static Scratch & scratch() {
+    static thread_local Scratch sc;
+    return sc;
+}
+
+// ---------------------------------------------------------------------------
+// Slave: one feature's groups in HBM
+
+struct Slave {
+    dist_shared_t sh;
+    std::vector<float> betas;
+    float alpha_sum = 0.f;
+    int K = 0;
+    int cap = 0;
+    DeviceBuf<int32_t> i0, i1, cnt;
+    DeviceBuf<float> f0, f1, c0, c1, c2, c3, S, prior, other;
+    float other_host = 0.f;
+
+    explicit Slave(const dist_shared_t & shared) : sh(shared) {
+        check_shared(sh);
+        ensure_device_ready();
+        if (sh.kind == DIST_DD) {
+            // dd.hpp:403-406: alpha_sum_ accumulates in index order
+            alpha_sum = 0.f;
+            for (int v = 0; v < sh.dim; ++v) alpha_sum += sh.alphas[v];
+            prior.upload(sh.alphas, sh.dim);
+        } else if (sh.kind == DIST_DPD) {
+            betas.assign(sh.betas, sh.betas + sh.dim);
+            sh.betas = betas.data();
+            alpha_sum = sh.p[0];
+            DeviceBuf<float> b;
+            b.upload(betas.data(), sh.dim);
+            prior.reserve(sh.dim, 0);
+            LAUNCH(k_dpd_prior, sh.dim, sh.p[0], b.p, prior.p, sh.dim);
+            other.reserve(1, 0);
+            LAUNCH1(k_dpd_other, sh.p[0], sh.p[1], other.p);
+            other.download(&other_host, 1);   // also drains the stream
+        }
+        sync();
+    }
+
+    int dim() const { return is_cat(sh.kind) ? sh.dim : 0; }
+
+    SlaveView view() const {
+        SlaveView v;
+        v.kind = sh.kind;
+        v.dim = sh.dim;
+        for (int i = 0; i < 4; ++i) v.p[i] = sh.p[i];
+        v.alpha_sum = alpha_sum;
+        v.other = other_host;
+        v.K = K;
+        v.cap = cap;
+        v.i0 = i0.p; v.i1 = i1.p; v.f0 = f0.p; v.f1 = f1.p; v.cnt = cnt.p;
+        v.c0 = c0.p; v.c1 = c1.p; v.c2 = c2.p; v.c3 = c3.p; v.S = S.p;
+        v.prior = prior.p;
+        return v;
+    }
+
+    void reserve(int need) {
+        if (need <= cap) return;
+        const int ncap = (int)grow_capacity((size_t)need);
+        i0.reserve(ncap, K); i1.reserve(ncap, K);
+        f0.reserve(ncap, K); f1.reserve(ncap, K);
+        c0.reserve(ncap, K); c1.reserve(ncap, K);
+        c2.reserve(ncap, K); c3.reserve(ncap, K);
+        if (is_cat(sh.kind)) {
+            cnt.reserve((size_t)ncap * sh.dim, (size_t)K * sh.dim);
+            // S is [dim][cap]: re-pitch the rows
+            DeviceBuf<float> nS;
+            nS.reserve((size_t)ncap * sh.dim, 0);
+            if (S.p && K)
+                HIP_CHECK(hipMemcpy2DAsync(
+                    nS.p, (size_t)ncap * sizeof(float), S.p,
+                    (size_t)cap * sizeof(float), (size_t)K * sizeof(float),
+                    sh.dim, hipMemcpyDeviceToDevice, stream()));
+            sync();
+            std::swap(S.p, nS.p);
+            std::swap(S.cap, nS.cap);
+        }
+        cap = ncap;
+    }
+
+    void check_group(size_t g) const {
+        DIST_REQUIRE(g < (size_t)K, "bad groupid: " + std::to_string(g));
+    }
+    void check_value(uint32_t value) const {
+        if (sh.kind == DIST_DD)
+            DIST_REQUIRE(value < (uint32_t)sh.dim,
+                         "value out of bounds: " + std::to_string(value));
+        if (sh.kind == DIST_DPD)
+            DIST_REQUIRE(value < (uint32_t)sh.dim || value == DIST_DPD_OTHER,
+                         "unknown value: " + std::to_string(value));
+    }
+
+    void clear() { K = 0; }
+
+    void append_zero(int n) {
+        reserve(K + n);
+        const size_t width = is_cat(sh.kind) ? sh.dim : 1;
+        SlaveView v = view();
+        LAUNCH(k_slave_zero_groups, (size_t)n * width, v, K, K + n);
+        K += n;
+    }
+
+    // groups().push_back(group): statistics only; init() builds the caches
+    void append(const uint32_t * g) {
+        reserve(K + 1);
+        const int k = K;
+        int32_t a = (int32_t)g[0], b = 0;
+        float x = 0.f, y = 0.f;
+        switch (sh.kind) {
+        case DIST_DD:
+        case DIST_DPD:
+            HIP_CHECK(hipMemcpyAsync(cnt.p + (size_t)k * sh.dim, g + 1,
+                                     sizeof(int32_t) * sh.dim,
+                                     hipMemcpyHostToDevice, stream()));
+            break;
+        case DIST_BB:
+            b = (int32_t)g[1];
+            break;
+        case DIST_GP:
+            b = (int32_t)g[1];
+            memcpy(&x, &g[2], 4);
+            break;
+        default:
+            memcpy(&x, &g[1], 4);
+            memcpy(&y, &g[2], 4);
+            break;
+        }
+        HIP_CHECK(hipMemcpyAsync(i0.p + k, &a, 4, hipMemcpyHostToDevice, stream()));
+        HIP_CHECK(hipMemcpyAsync(i1.p + k, &b, 4, hipMemcpyHostToDevice, stream()));
+        HIP_CHECK(hipMemcpyAsync(f0.p + k, &x, 4, hipMemcpyHostToDevice, stream()));
+        HIP_CHECK(hipMemcpyAsync(f1.p + k, &y, 4, hipMemcpyHostToDevice, stream()));
+        sync();
+        K += 1;
+    }
+
+    void get_group(size_t g, uint32_t * out) const {
+        check_group(g);
+        int32_t a, b;
+        float x, y;
+        HIP_CHECK(hipMemcpy(&a, i0.p + g, 4, hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(&b, i1.p + g, 4, hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(&x, f0.p + g, 4, hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(&y, f1.p + g, 4, hipMemcpyDeviceToHost));
+        out[0] = (uint32_t)a;
+        switch (sh.kind) {
+        case DIST_DD:
+        case DIST_DPD:
+            HIP_CHECK(hipMemcpy(out + 1, cnt.p + g * sh.dim,
+                                sizeof(int32_t) * sh.dim,
+                                hipMemcpyDeviceToHost));
+            break;
+        case DIST_BB:
+            out[1] = (uint32_t)b;
+            break;
+        case DIST_GP:
+            out[1] = (uint32_t)b;
+            memcpy(&out[2], &x, 4);
+            break;
+        default:
+            memcpy(&out[1], &x, 4);
+            memcpy(&out[2], &y, 4);
+            break;
+        }
+    }
+
+    void update(int k0, int k1) {
+        if (k1 <= k0) return;
+        const size_t width = is_cat(sh.kind) ? sh.dim : 1;
+        SlaveView v = view();
+        LAUNCH(k_slave_update, (size_t)(k1 - k0) * width, v, k0, k1);
+    }
+    void init() { update(0, K); }            // mixture.hpp:354-359
+
+    void add_group() {                        // mixture.hpp:361-368
+        append_zero(1);
+        update(K - 1, K);
+    }
+    void remove_group(size_t g) {             // mixture.hpp:370-375
+        check_group(g);
+        const int last = K - 1;
+        if ((int)g != last) {
+            SlaveView v = view();
+            LAUNCH(k_slave_move_group, (size_t)std::max(1, dim()), v, (int)g,
+                   last);
+        }
+        K = last;
+    }
+    void value_op(size_t g, uint32_t value, int add) {
+        check_group(g);
+        check_value(value);
+        DIST_REQUIRE(!(sh.kind == DIST_DPD && value == DIST_DPD_OTHER),
+                     "cannot add or remove OTHER");
+        SlaveView v = view();
+        LAUNCH1(k_slave_value_op, v, (int)g, value, add);
+    }
+    float score_value_group(size_t g, uint32_t value) const {
+        check_group(g);
+        check_value(value);
+        Scratch & sc = scratch();
+        sc.f.reserve(1, 0);
+        SlaveView v = view();
+        LAUNCH1(k_slave_score_group, v, (int)g, value, sc.f.p);
+        float out;
+        sc.f.download(&out, 1);
+        return out;
+    }
+    void score_value(uint32_t value, float * acc, size_t size) const {
+        DIST_REQUIRE(size == (size_t)K, "scores_accum != len(mixture)");
+        check_value(value);
+        if (!K) return;
+        Scratch & sc = scratch();
+        sc.f.upload(acc, K);
+        SlaveView v = view();
+        LAUNCH(k_slave_score_value, (size_t)K, v, value, sc.f.p, K);
+        sc.f.download(acc, K);
+    }
+};
+
+// ---------------------------------------------------------------------------
+// PyDriver: PitmanYor::CachedMixture over MixtureDriver
+
+struct PyDriver {
+    std::vector<int> counts;   // host mirror of the device counts
+    int n_empty = 0;
+    long long sample_size = 0;
+    DeviceBuf<int32_t> d_counts;
+    DeviceBuf<float> d_shifted;
+
+    int K() const { return (int)counts.size(); }
+
+    void reserve(int need) {
+        if ((size_t)need <= d_counts.cap) return;
+        const size_t ncap = grow_capacity((size_t)need);
+        d_counts.reserve(ncap, counts.size());
+        d_shifted.reserve(ncap, counts.size());
+    }
+    void rebuild(float alpha, float d) {      // clustering.hpp:151-161
+        n_empty = 0;
+        sample_size = 0;
+        for (int c : counts) {
+            sample_size += c;
+            n_empty += (c == 0);
+        }
+        if (!counts.empty())
+            LAUNCH(k_py_rebuild, counts.size(), d_counts.p, d_shifted.p, K(),
+                   alpha, d, K() - n_empty, n_empty);
+    }
+    void init(float alpha, float d, const int * c, size_t n) {
+        ensure_device_ready();
+        for (size_t i = 0; i < n; ++i)
+            DIST_REQUIRE(c[i] >= 0, "negative group size");
+        counts.assign(c, c + n);
+        reserve((int)n);
+        d_counts.upload(counts.data(), n);
+        rebuild(alpha, d);
+        DIST_REQUIRE(n_empty > 0, "missing empty groups");  // mixture.hpp:153
+    }
+    void update_empties(float alpha, float d) {   // clustering.hpp:221-230
+        LAUNCH(k_py_rebuild, counts.size(), d_counts.p, d_shifted.p, K(),
+               alpha, d, K() - n_empty, n_empty);
+    }
+    bool add_value(float alpha, float d, size_t g) {   // clustering.hpp:163-176
+        DIST_REQUIRE(g < counts.size(), "bad groupid: " + std::to_string(g));
+        const bool add_group = (counts[g] == 0);
+        counts[g] += 1;
+        sample_size += 1;
+        if (add_group) {
+            // mixture.hpp:84-89: the filled group leaves the empty set and a
+            // fresh empty group is appended, so the set's size is unchanged
+            counts.push_back(0);
+            reserve(K());
+            LAUNCH1(k_py_set_count, d_counts.p, d_shifted.p, K() - 1, 0, d);
+            LAUNCH1(k_py_set_count, d_counts.p, d_shifted.p, (int)g, counts[g], d);
+            update_empties(alpha, d);
+        } else {
+            LAUNCH1(k_py_set_count, d_counts.p, d_shifted.p, (int)g, counts[g], d);
+        }
+        return add_group;
+    }
+    bool remove_value(float alpha, float d, size_t g) {  // clustering.hpp:178-193
+        DIST_REQUIRE(g < counts.size(), "bad groupid: " + std::to_string(g));
+        DIST_REQUIRE(counts[g] > 0, "cannot remove value from empty group");
+        counts[g] -= 1;
+        sample_size -= 1;
+        const bool remove_group = (counts[g] == 0);
+        if (remove_group) {
+            const int last = K() - 1;                   // mixture.hpp:108-119
+            if ((int)g != last) {
+                counts[g] = counts[last];
+                LAUNCH1(k_py_move, d_counts.p, d_shifted.p, (int)g, last);
+            }
+            counts.pop_back();
+            update_empties(alpha, d);
+        } else {
+            LAUNCH1(k_py_set_count, d_counts.p, d_shifted.p, (int)g, counts[g], d);
+        }
+        return remove_group;
+    }
+    void score_value(float alpha, float * scores, size_t size) const {
+        DIST_REQUIRE(size == counts.size(), "scores.size() != counts().size()");
+        Scratch & sc = scratch();
+        sc.f.reserve(size, 0);
+        LAUNCH(k_py_score, size, d_shifted.p, sc.f.p, K(), sample_size, alpha);
+        sc.f.download(scores, size);
+    }
+};
+
+// ---------------------------------------------------------------------------
+// Tracker: MixtureIdTracker (host; mirrors the swap-remove of the groups)
+
+struct Tracker {
+    std::vector<uint32_t> p2g;
+    std::vector<int32_t> g2p;   // -1 = retired
+
+    void init(size_t n) {
+        p2g.clear();
+        g2p.clear();
+        for (size_t i = 0; i < n; ++i) add_group();
+    }
+    void add_group() {
+        const uint32_t packed = (uint32_t)p2g.size();
+        const uint32_t global = (uint32_t)g2p.size();
+        p2g.push_back(global);
+        g2p.push_back((int32_t)packed);
+    }
+    void remove_group(uint32_t packed) {
+        DIST_REQUIRE(packed < p2g.size(),
+                     "bad packed id: " + std::to_string(packed));
+        g2p[p2g[packed]] = -1;
+        p2g[packed] = p2g.back();
+        p2g.pop_back();
+        if (packed != p2g.size()) g2p[p2g[packed]] = (int32_t)packed;
+    }
+    uint32_t packed_to_global(uint32_t packed) const {
+        DIST_REQUIRE(packed < p2g.size(),
+                     "bad packed id: " + std::to_string(packed));
+        return p2g[packed];
+    }
+    uint32_t global_to_packed(uint32_t global) const {
+        DIST_REQUIRE(global < g2p.size(),
+                     "bad global id: " + std::to_string(global));
+        DIST_REQUIRE(g2p[global] >= 0,
+                     "stale global id: " + std::to_string(global));
+        return (uint32_t)g2p[global];
+    }
+};
+
+// ---------------------------------------------------------------------------
+// Gibbs: the batched row engine
+
+struct Gibbs {
+    float alpha, d;
+    PyDriver py;
+    std::vector<std::unique_ptr<Slave>> feats;
+    Tracker tracker;
+
+    size_t n_rows = 0;
+    uint64_t row_offset = 0;
+    std::vector<DeviceBuf<uint32_t>> own_values;
+    std::vector<const uint32_t *> values;   // device pointers
+    DeviceBuf<uint32_t> own_assign;
+    uint32_t * assign = nullptr;             // device, global ids
+    DeviceBuf<int32_t> d_g2p;
+    DeviceBuf<uint32_t> d_p2g;
+    bool maps_dirty = true;
+
+    DeviceBuf<uint32_t> old_packed, new_packed;
+    DeviceBuf<float> base, table0;
+    DeviceBuf<SweepScalars> scalars;
+    DeviceBuf<float> row_scores;
+    DeviceBuf<int> row_size;
+
+    size_t batch_begin = 0, batch_end = 0;   // rows of the open batch
+    bool batch_open = false;
+
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double kernel_ms = 0.0;
+    uint64_t kernel_launches = 0, kernel_rows = 0;
+
+    Gibbs(float alpha_, float d_, int F, const dist_shared_t * shareds)
+        : alpha(alpha_), d(d_) {
+        ensure_device_ready();
+        DIST_REQUIRE(F >= 0 && F <= kMaxF, "too many features");
+        DIST_REQUIRE(alpha > 0.f && d >= 0.f && d < 1.f,
+                     "expected alpha > 0, 0 <= d < 1");
+        for (int f = 0; f < F; ++f)
+            feats.emplace_back(new Slave(shareds[f]));
+        HIP_CHECK(hipEventCreate(&ev0));
+        HIP_CHECK(hipEventCreate(&ev1));
+    }
+    ~Gibbs() {
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+    }
+
+    int F() const { return (int)feats.size(); }
+    int K() const { return py.K(); }
+
+    void upload_maps() {
+        if (!maps_dirty) return;
+        d_g2p.upload(tracker.g2p.data(), tracker.g2p.size());
+        d_p2g.upload(tracker.p2g.data(), tracker.p2g.size());
+        maps_dirty = false;
+    }
+
+    SweepParams params(size_t r0, size_t r1, uint32_t seed, uint64_t draw_base) {
+        SweepParams P;
+        memset(&P, 0, sizeof(P));
+        P.F = F();
+        for (int f = 0; f < F(); ++f) {
+            P.feat[f] = feats[f]->view();
+            P.values[f] = values[f];
+        }
+        P.counts = py.d_counts.p;
+        P.shifted = py.d_shifted.p;
+        P.base = base.p;
+        P.table0 = nullptr;
+        P.scalars = scalars.p;
+        P.K = K();
+        P.n_empty = py.n_empty;
+        P.alpha = alpha;
+        P.d = d;
+        P.sample_size = py.sample_size;
+        P.assign = assign;
+        P.g2p = d_g2p.p;
+        P.old_packed = old_packed.p;
+        P.new_packed = new_packed.p;
+        P.row_begin = r0;
+        P.row_end = r1;
+        P.row_offset = row_offset;
+        P.draw_base = draw_base;
+        P.seed_state = seed;
+        return P;
+    }
+
+    StatImage live_image() {
+        StatImage img;
+        memset(&img, 0, sizeof(img));
+        img.counts = py.d_counts.p;
+        for (int f = 0; f < F(); ++f) {
+            img.i0[f] = feats[f]->i0.p;
+            img.i1[f] = feats[f]->i1.p;
+            img.cnt[f] = feats[f]->cnt.p;
+        }
+        return img;
+    }
+    size_t stat_words() const {
+        size_t n = (size_t)K();
+        for (auto & s : feats)
+            n += 2 * (size_t)K() + (size_t)K() * s->dim();
+        return n;
+    }
+    StatImage word_image(int32_t * w) {
+        StatImage img;
+        memset(&img, 0, sizeof(img));
+        const size_t k = (size_t)K();
+        img.counts = w;
+        w += k;
+        for (int f = 0; f < F(); ++f) {
+            img.i0[f] = w; w += k;
+            img.i1[f] = w; w += k;
+            img.cnt[f] = w; w += k * feats[f]->dim();
+        }
+        return img;
+    }
+    // copy the integer statistics between the live arrays and a word image
+    void copy_stats(int32_t * words, bool to_words) {
+        StatImage a = live_image(), b = word_image(words);
+        const size_t k = (size_t)K();
+        auto cp = [&](int32_t * live, int32_t * w, size_t n) {
+            if (!n) return;
+            HIP_CHECK(hipMemcpyAsync(to_words ? w : live, to_words ? live : w,
+                                     n * 4, hipMemcpyDeviceToDevice, stream()));
+        };
+        cp(a.counts, b.counts, k);
+        for (int f = 0; f < F(); ++f) {
+            cp(a.i0[f], b.i0[f], k);
+            cp(a.i1[f], b.i1[f], k);
+            cp(a.cnt[f], b.cnt[f], k * feats[f]->dim());
+        }
+    }
+
+    void rebuild_caches() {
+        py.rebuild(alpha, d);
+        for (auto & s : feats) s->init();
+    }
+    void refresh_host_counts() {
+        py.counts.resize((size_t)K());
+        py.d_counts.download(py.counts.data(), py.counts.size());
+    }
+
+    void load(size_t n, const uint32_t * const * vals, bool vals_on_device,
+              const uint32_t * assign_packed, uint32_t * assign_dev,
+              int nonempty, int empty, uint64_t offset) {
+        DIST_REQUIRE(nonempty >= 0 && empty >= 1,
+                     "missing empty groups");   // mixture.hpp:153
+        n_rows = n;
+        row_offset = offset;
+        const int Kt = nonempty + empty;
+        values.assign(F(), nullptr);
+        own_values.clear();
+        own_values.resize(F());
+        DeviceBuf<uint32_t> packed_tmp;
+        const uint32_t * packed_dev = nullptr;
+        if (vals_on_device) {
+            for (int f = 0; f < F(); ++f) values[f] = vals[f];
+            packed_dev = assign_dev;
+            assign = assign_dev;       // rewritten to global ids below
+        } else {
+            std::vector<uint32_t> chk(assign_packed, assign_packed + n);
+            for (size_t i = 0; i < n; ++i)
+                DIST_REQUIRE(chk[i] < (uint32_t)nonempty, "bad groupid in assignments");
+            for (int f = 0; f < F(); ++f) {
+                own_values[f].upload(vals[f], n);
+                values[f] = own_values[f].p;
+            }
+            own_assign.upload(assign_packed, n);
+            packed_dev = own_assign.p;
+            assign = own_assign.p;
+        }
+        // empty statistics for all groups
+        py.counts.assign((size_t)Kt, 0);
+        py.reserve(Kt);
+        HIP_CHECK(hipMemsetAsync(py.d_counts.p, 0, sizeof(int32_t) * Kt, stream()));
+        for (auto & s : feats) {
+            s->clear();
+            s->append_zero(Kt);
+        }
+        tracker.init((size_t)Kt);
+        maps_dirty = true;
+        upload_maps();
+        old_packed.reserve(std::max<size_t>(n, 1), 0);
+        new_packed.reserve(std::max<size_t>(n, 1), 0);
+        base.reserve((size_t)grow_capacity(Kt), 0);
+        scalars.reserve(1, 0);
+        // integer statistics by atomics, float statistics replayed in row
+        // order (Group::add_value per row, like GroupIoMixin.from_values,
+        // distributions/mixins.py:83-90)
+        SweepParams P = params(0, n, 0, 0);
+        if (n) {
+            LAUNCH(k_load_counts, n, P, live_image(), packed_dev);
+            for (int f = 0; f < F(); ++f) {
+                if (!has_float_stats(feats[f]->sh.kind)) continue;
+                hipLaunchKernelGGL(k_replay_floats, dim3(Kt), dim3(64), 0,
+                                   stream(), feats[f]->view(), values[f],
+                                   (const uint32_t *)nullptr, packed_dev,
+                                   (size_t)0, n);
+                HIP_CHECK(hipGetLastError());
+            }
+            // assignments become global ids (identity map right after init)
+            LAUNCH(k_packed_to_global, n, packed_dev, d_p2g.p, assign, n);
+        }
+        refresh_host_counts();
+        rebuild_caches();
+        sync();
+    }
+
+    // which template instance scores this feature list
+    template <class Fn>
+    void dispatch(Fn && fn) {
+        const int k0 = F() > 0 ? feats[0]->sh.kind : -1;
+        const int k1 = F() > 1 ? feats[1]->sh.kind : -1;
+        if (F() == 1 && k0 == DIST_DD) return fn.template run<DIST_DD, -1, 1>();
+        if (F() == 1 && k0 == DIST_DPD) return fn.template run<DIST_DPD, -1, 1>();
+        if (F() == 1 && k0 == DIST_BB) return fn.template run<DIST_BB, -1, 1>();
+        if (F() == 1 && k0 == DIST_GP) return fn.template run<DIST_GP, -1, 1>();
+        if (F() == 1 && k0 == DIST_NICH) return fn.template run<DIST_NICH, -1, 1>();
+        if (F() == 2 && k0 == DIST_GP && k1 == DIST_NICH)
+            return fn.template run<DIST_GP, DIST_NICH, 2>();
+        return fn.template run<-1, -1, 0>();
+    }
+
+    void prepare(SweepParams & P) {
+        base.reserve(grow_capacity((size_t)K()), 0);
+        float * t0 = nullptr;
+        size_t n = (size_t)K();
+        if (F() > 0 && is_cat(feats[0]->sh.kind)) {
+            n = (size_t)K() * feats[0]->sh.dim;
+            table0.reserve(n, 0);
+            t0 = table0.p;
+        }
+        P.base = base.p;
+        LAUNCH(k_sweep_prepare, n, P, base.p, t0, scalars.p);
+        P.table0 = t0;
+    }
+
+    struct SampleLaunch {
+        Gibbs * self;
+        SweepParams * P;
+        template <int A, int B, int NF>
+        void run() {
+            const size_t n = P->row_end - P->row_begin;
+            // >> 256 workgroups to fill 256 CUs; grid-stride beyond that
+            const unsigned blocks = (unsigned)std::min<size_t>(
+                (n + kBlock - 1) / kBlock, 256 * 16);
+            HIP_CHECK(hipEventRecord(self->ev0, stream()));
+            hipLaunchKernelGGL((k_sweep_sample<A, B, NF>), dim3(blocks),
+                               dim3(kBlock), 0, stream(), *P);
+            HIP_CHECK(hipGetLastError());
+            HIP_CHECK(hipEventRecord(self->ev1, stream()));
+        }
+    };
+    struct RowScoreLaunch {
+        Gibbs * self;
+        SweepParams * P;
+        size_t row;
+        template <int A, int B, int NF>
+        void run() {
+            hipLaunchKernelGGL((k_row_scores<A, B, NF>), dim3(1), dim3(1), 0,
+                               stream(), *P, row, self->row_scores.p,
+                               self->row_size.p);
+            HIP_CHECK(hipGetLastError());
+        }
+    };
+
+    void batch_sample(size_t r0, size_t r1, uint32_t seed, uint64_t draw_base) {
+        DIST_REQUIRE(!batch_open, "previous batch not finished");
+        DIST_REQUIRE(r0 <= r1 && r1 <= n_rows, "bad row range");
+        batch_begin = r0;
+        batch_end = r1;
+        batch_open = true;
+        if (r0 == r1) return;
+        upload_maps();
+        SweepParams P = params(r0, r1, seed, draw_base);
+        prepare(P);
+        SampleLaunch L{this, &P};
+        dispatch(L);
+        HIP_CHECK(hipEventSynchronize(ev1));
+        float ms = 0.f;
+        HIP_CHECK(hipEventElapsedTime(&ms, ev0, ev1));
+        kernel_ms += ms;
+        kernel_launches += 1;
+        kernel_rows += r1 - r0;
+    }
+
+    void replay_floats() {
+        const size_t n = batch_end - batch_begin;
+        for (int f = 0; f < F(); ++f) {
+            if (!has_float_stats(feats[f]->sh.kind)) continue;
+            hipLaunchKernelGGL(k_replay_floats, dim3(K()), dim3(64), 0,
+                               stream(), feats[f]->view(), values[f],
+                               (const uint32_t *)old_packed.p,
+                               (const uint32_t *)new_packed.p, batch_begin, n);
+            HIP_CHECK(hipGetLastError());
+        }
+    }
+
+    void batch_apply_local() {
+        DIST_REQUIRE(batch_open, "no open batch");
+        const size_t n = batch_end - batch_begin;
+        if (!n) return;
+        SweepParams P = params(batch_begin, batch_end, 0, 0);
+        LAUNCH(k_apply_moves, n, P, live_image(), d_p2g.p, assign);
+        replay_floats();
+    }
+    void batch_delta(int32_t * delta_dev) {
+        DIST_REQUIRE(batch_open, "no open batch");
+        for (auto & s : feats)
+            DIST_REQUIRE(s->sh.kind != DIST_NICH,
+                         "NormalInverseChiSq statistics are order-dependent: "
+                         "no integer delta (single-GPU only in this round)");
+        HIP_CHECK(hipMemsetAsync(delta_dev, 0, stat_words() * 4, stream()));
+        const size_t n = batch_end - batch_begin;
+        if (!n) return;
+        SweepParams P = params(batch_begin, batch_end, 0, 0);
+        LAUNCH(k_apply_moves, n, P, word_image(delta_dev), d_p2g.p, assign);
+    }
+    void batch_apply_delta(const int32_t * delta_dev) {
+        DIST_REQUIRE(batch_open, "no open batch");
+        StatImage a = live_image();
+        StatImage b = word_image(const_cast<int32_t *>(delta_dev));
+        const size_t k = (size_t)K();
+        LAUNCH(k_add_words, k, a.counts, b.counts, k);
+        for (int f = 0; f < F(); ++f) {
+            LAUNCH(k_add_words, k, a.i0[f], b.i0[f], k);
+            LAUNCH(k_add_words, k, a.i1[f], b.i1[f], k);
+            const size_t nc = k * feats[f]->dim();
+            if (nc) LAUNCH(k_add_words, nc, a.cnt[f], b.cnt[f], nc);
+        }
+        // GP log_prod never enters score_value (gp.hpp:198-217); it is
+        // replayed from the local rows only
+        replay_floats();
+    }
+
+    // Normalise the group set after a batch (DESIGN.md "Batch semantics"):
+    // groups that lost their last member are swap-removed in descending slot
+    // order; one empty group is appended per previously empty group that
+    // gained members; caches are rebuilt from the statistics.
+    void batch_finish() {
+        DIST_REQUIRE(batch_open, "no open batch");
+        batch_open = false;
+        const std::vector<int> snap = py.counts;
+        const int K0 = K();
+        refresh_host_counts();
+        int created = 0;
+        for (int k = 0; k < K0; ++k)
+            if (snap[k] == 0 && py.counts[k] > 0) created += 1;
+        bool structural = created > 0;
+        for (int k = K0 - 1; k >= 0; --k) {
+            if (snap[k] > 0 && py.counts[k] == 0) {
+                structural = true;
+                const int last = K() - 1;
+                if (k != last) {
+                    py.counts[k] = py.counts[last];
+                    LAUNCH1(k_py_move, py.d_counts.p, py.d_shifted.p, k, last);
+                }
+                py.counts.pop_back();
+                for (auto & s : feats) s->remove_group((size_t)k);
+                tracker.remove_group((uint32_t)k);
+            }
+        }
+        for (int c = 0; c < created; ++c) {
+            py.counts.push_back(0);
+            py.reserve(K());
+            LAUNCH1(k_py_set_count, py.d_counts.p, py.d_shifted.p, K() - 1, 0, d);
+            for (auto & s : feats) s->append_zero(1);
+            tracker.add_group();
+        }
+        if (structural) maps_dirty = true;
+        rebuild_caches();
+    }
+
+    void sweep(size_t r0, size_t r1, size_t batch, uint32_t seed,
+               uint64_t draw_base) {
+        DIST_REQUIRE(batch > 0, "batch_rows must be positive");
+        for (size_t b = r0; b < r1; b += batch) {
+            const size_t e = std::min(r1, b + batch);
+            batch_sample(b, e, seed, draw_base);
+            batch_apply_local();
+            batch_finish();
+        }
+        sync();
+    }
+    void sweep_sequential(size_t r0, size_t r1, uint32_t * rng_state) {
+        for (size_t r = r0; r < r1; ++r) {
+            // draw index (draw_base + row_offset + r) must be 0 for this row
+            const uint64_t draw_base = (uint64_t)0 - (row_offset + r);
+            batch_sample(r, r + 1, *rng_state, draw_base);
+            batch_apply_local();
+            batch_finish();
+            *rng_state = lcg_mulmod(*rng_state, 16807u);
+        }
+        sync();
+    }
+
+    void get_row_scores(size_t row, float * out, size_t * size_out) {
+        DIST_REQUIRE(row < n_rows, "bad row");
+        DIST_REQUIRE(!batch_open, "batch open");
+        upload_maps();
+        row_scores.reserve(grow_capacity((size_t)K()), 0);
+        row_size.reserve(1, 0);
+        SweepParams P = params(row, row + 1, 0, 0);
+        prepare(P);
+        RowScoreLaunch L{this, &P, row};
+        dispatch(L);
+        int n = 0;
+        row_size.download(&n, 1);
+        row_scores.download(out, (size_t)n);
+        *size_out = (size_t)n;
+    }
+    void score_rows(size_t r0, size_t r1, float * out_dev, size_t ld) {
+        DIST_REQUIRE(r0 <= r1 && r1 <= n_rows && ld >= (size_t)K(),
+                     "bad row range or leading dimension");
+        if (r0 == r1) return;
+        SweepParams P = params(r0, r1, 0, 0);
+        prepare(P);
+        LAUNCH(k_score_rows, (r1 - r0) * (size_t)K(), P, out_dev, ld);
+    }
+};
+
+}  // namespace dist
+
+// ===========================================================================
+// C ABI
+
+using namespace dist;
+
+struct dist_py_mixture { PyDriver impl; };
+struct dist_mixture { std::unique_ptr<Slave> impl; };
+struct dist_id_tracker { Tracker impl; };
+struct dist_gibbs { std::unique_ptr<Gibbs> impl; };
+
+extern "C" {
+
+int dist_abi_version(void) { return DIST_ABI_VERSION; }
+const char * dist_last_error(void) { return t_last_error.c_str(); }
+int dist_device_count(int * count) {
+    return guarded([&] { HIP_CHECK(hipGetDeviceCount(count)); });
+}
+int dist_set_device(int device) {
+    return guarded([&] { HIP_CHECK(hipSetDevice(device)); });
+}
+int dist_synchronize(void) {
+    return guarded([&] { HIP_CHECK(hipDeviceSynchronize()); });
+}
+size_t dist_group_words(const dist_shared_t * shared) {
+    return group_words(*shared);
+}
+
+// ---- entropy ----------------------------------------------------------------
+uint32_t dist_rng_seed(uint64_t seed) {
+    const uint64_t s = seed % 2147483647ull;
+    return (uint32_t)(s == 0 ? 1 : s);
+}
+uint32_t dist_rng_next(uint32_t * state) {
+    *state = lcg_mulmod(*state, 16807u);
+    return *state;
+}
+float dist_rng_unif01(uint32_t * state) {
+    ensure_host_tables();
+    return lcg_unif01(dist_rng_next(state));
+}
+uint32_t dist_rng_jump(uint32_t state, uint64_t steps) {
+    return lcg_jump(state, steps);
+}
+
+// ---- vector_math ------------------------------------------------------------
+static int vector_op(int op, size_t n, const void * in, float * out) {
+    return guarded([&] {
+        ensure_device_ready();
+        if (!n) return;
+        DeviceBuf<float> a, b;
+        a.upload(static_cast<const float *>(in), n);
+        b.reserve(n, 0);
+        LAUNCH(k_vector_op, n, op, n, a.p, b.p);
+        b.download(out, n);
+    });
+}
+int dist_vector_log(size_t n, const float * in, float * out) {
+    return vector_op(VEC_LOG, n, in, out);
+}
+int dist_vector_exp(size_t n, const float * in, float * out) {
+    return vector_op(VEC_EXP, n, in, out);
+}
+int dist_vector_lgamma(size_t n, const float * in, float * out) {
+    return vector_op(VEC_LGAMMA, n, in, out);
+}
+int dist_vector_lgamma_nu(size_t n, const float * in, float * out) {
+    return vector_op(VEC_LGAMMA_NU, n, in, out);
+}
+int dist_vector_log_factorial(size_t n, const uint32_t * in, float * out) {
+    return vector_op(VEC_LOG_FACTORIAL, n, in, out);
+}
+
+// ---- sampling ---------------------------------------------------------------
+static void sample_kernel(int mode, size_t n, float * scores, bool copy_back,
+                          float total, float u, SampleOut * out) {
+    ensure_device_ready();
+    DIST_REQUIRE(n > 0 || mode == 2, "expected 0 < size");
+    Scratch & sc = scratch();
+    sc.f.upload(scores, std::max<size_t>(n, 1));
+    sc.s.reserve(1, 0);
+    LAUNCH1(k_sample_scalar, mode, (int)n, sc.f.p, total, u, sc.s.p);
+    sc.s.download(out, 1);
+    if (copy_back) sc.f.download(scores, n);
+}
+int dist_sample_from_scores_overwrite(uint32_t * rng_state, size_t n,
+                                      float * scores, size_t * sample_out) {
+    return guarded([&] {
+        ensure_host_tables();
+        const float u = lcg_unif01(dist_rng_next(rng_state));
+        SampleOut out;
+        sample_kernel(1, n, scores, true, 0.f, u, &out);
+        *sample_out = (size_t)out.sample;
+    });
+}
+int dist_scores_to_likelihoods(size_t n, float * scores, float * total_out) {
+    return guarded([&] {
+        SampleOut out;
+        sample_kernel(0, n, scores, true, 0.f, 0.f, &out);
+        *total_out = out.total;
+    });
+}
+int dist_sample_from_likelihoods(uint32_t * rng_state, size_t n,
+                                 const float * likelihoods, float total,
+                                 size_t * sample_out) {
+    return guarded([&] {
+        ensure_host_tables();
+        const float u = lcg_unif01(dist_rng_next(rng_state));
+        SampleOut out;
+        sample_kernel(3, n, const_cast<float *>(likelihoods), false, total, u,
+                      &out);
+        *sample_out = (size_t)out.sample;
+    });
+}
+int dist_log_sum_exp(size_t n, const float * scores, float * out_value) {
+    return guarded([&] {
+        if (n == 0) { *out_value = 0.f; return; }   // random.cc:80-82
+        SampleOut out;
+        sample_kernel(2, n, const_cast<float *>(scores), false, 0.f, 0.f, &out);
+        *out_value = out.log_sum_exp;
+    });
+}
+
+// ---- PitmanYor --------------------------------------------------------------
+int dist_py_score_add_value(float alpha, float d, int group_size,
+                            int nonempty, int sample_size, int empty,
+                            float * out) {
+    return guarded([&] {
+        ensure_device_ready();
+        Scratch & sc = scratch();
+        sc.f.reserve(1, 0);
+        LAUNCH1(k_py_score_add_value, alpha, d, group_size, nonempty,
+                sample_size, empty, sc.f.p);
+        sc.f.download(out, 1);
+    });
+}
+int dist_py_score_remove_value(float alpha, float d, int group_size,
+                               int nonempty, int sample_size, int empty,
+                               float * out) {
+    // clustering.hpp:106-123
+    group_size -= 1;
+    if (group_size == 0) nonempty -= 1;
+    sample_size -= 1;
+    int rc = dist_py_score_add_value(alpha, d, group_size, nonempty,
+                                     sample_size, empty, out);
+    if (rc == 0) *out = -*out;
+    return rc;
+}
+
+dist_py_mixture_t * dist_py_mixture_create(void) {
+    dist_py_mixture_t * m = nullptr;
+    guarded([&] { m = new dist_py_mixture(); });
+    return m;
+}
+void dist_py_mixture_destroy(dist_py_mixture_t * m) { delete m; }
+int dist_py_mixture_init(dist_py_mixture_t * m, float alpha, float d,
+                         const int * counts, size_t n) {
+    return guarded([&] { m->impl.init(alpha, d, counts, n); sync(); });
+}
+int dist_py_mixture_add_value(dist_py_mixture_t * m, float alpha, float d,
+                              size_t groupid, int * added_out) {
+    return guarded([&] { *added_out = m->impl.add_value(alpha, d, groupid); });
+}
+int dist_py_mixture_remove_value(dist_py_mixture_t * m, float alpha, float d,
+                                 size_t groupid, int * removed_out) {
+    return guarded(
+        [&] { *removed_out = m->impl.remove_value(alpha, d, groupid); });
+}
+int dist_py_mixture_score_value(const dist_py_mixture_t * m, float alpha,
+                                float d, float * scores, size_t size) {
+    (void)d;
+    return guarded([&] { m->impl.score_value(alpha, scores, size); });
+}
+size_t dist_py_mixture_size(const dist_py_mixture_t * m) {
+    return m->impl.counts.size();
+}
+size_t dist_py_mixture_sample_size(const dist_py_mixture_t * m) {
+    return (size_t)m->impl.sample_size;
+}
+int dist_py_mixture_counts(const dist_py_mixture_t * m, int * out) {
+    return guarded([&] {
+        // the device copy is the authority; the mirror must agree
+        std::vector<int> dev(m->impl.counts.size());
+        m->impl.d_counts.download(dev.data(), dev.size());
+        DIST_REQUIRE(dev == m->impl.counts, "count mirror out of sync");
+        std::copy(dev.begin(), dev.end(), out);
+    });
+}
+size_t dist_py_mixture_empty_groupids(const dist_py_mixture_t * m,
+                                      size_t * out, size_t cap) {
+    size_t n = 0;
+    for (size_t i = 0; i < m->impl.counts.size(); ++i) {
+        if (m->impl.counts[i] == 0) {
+            if (n < cap) out[n] = i;
+            n += 1;
+        }
+    }
+    return n;
+}
+
+// ---- Model::Mixture ---------------------------------------------------------
+dist_mixture_t * dist_mixture_create(const dist_shared_t * shared) {
+    dist_mixture_t * m = nullptr;
+    guarded([&] {
+        std::unique_ptr<dist_mixture> p(new dist_mixture());
+        p->impl.reset(new Slave(*shared));
+        m = p.release();
+    });
+    return m;
+}
+void dist_mixture_destroy(dist_mixture_t * m) { delete m; }
+int dist_mixture_clear(dist_mixture_t * m) {
+    return guarded([&] { m->impl->clear(); });
+}
+int dist_mixture_append(dist_mixture_t * m, const uint32_t * group) {
+    return guarded([&] { m->impl->append(group); });
+}
+int dist_mixture_get_group(const dist_mixture_t * m, size_t groupid,
+                           uint32_t * out) {
+    return guarded([&] { sync(); m->impl->get_group(groupid, out); });
+}
+size_t dist_mixture_size(const dist_mixture_t * m) { return (size_t)m->impl->K; }
+int dist_mixture_init(dist_mixture_t * m) {
+    return guarded([&] { m->impl->init(); sync(); });
+}
+int dist_mixture_add_group(dist_mixture_t * m) {
+    return guarded([&] { m->impl->add_group(); });
+}
+int dist_mixture_remove_group(dist_mixture_t * m, size_t groupid) {
+    return guarded([&] { m->impl->remove_group(groupid); });
+}
+int dist_mixture_add_value(dist_mixture_t * m, size_t groupid, uint32_t value) {
+    return guarded([&] { m->impl->value_op(groupid, value, 1); });
+}
+int dist_mixture_remove_value(dist_mixture_t * m, size_t groupid,
+                              uint32_t value) {
+    return guarded([&] { m->impl->value_op(groupid, value, 0); });
+}
+int dist_mixture_score_value_group(const dist_mixture_t * m, size_t groupid,
+                                   uint32_t value, float * out) {
+    return guarded([&] { *out = m->impl->score_value_group(groupid, value); });
+}
+int dist_mixture_score_value(const dist_mixture_t * m, uint32_t value,
+                             float * scores_accum, size_t size) {
+    return guarded([&] { m->impl->score_value(value, scores_accum, size); });
+}
+
+// ---- Model::Group (host scalars over the same inline model code) -----------
+int dist_group_init(const dist_shared_t * shared, uint32_t * group) {
+    return guarded([&] {
+        check_shared(*shared);
+        memset(group, 0, 4 * group_words(*shared));
+    });
+}
+static Stats group_to_stats(const dist_shared_t & sh, const uint32_t * g) {
+    Stats st = {0, 0, 0.f, 0.f};
+    st.i0 = (int32_t)g[0];
+    if (sh.kind == DIST_BB) st.i1 = (int32_t)g[1];
+    if (sh.kind == DIST_GP) { st.i1 = (int32_t)g[1]; st.f0 = u2f(g[2]); }
+    if (sh.kind == DIST_NICH) { st.f0 = u2f(g[1]); st.f1 = u2f(g[2]); }
+    return st;
+}
+static void stats_to_group(const dist_shared_t & sh, const Stats & st,
+                           uint32_t * g) {
+    g[0] = (uint32_t)st.i0;
+    if (sh.kind == DIST_BB) g[1] = (uint32_t)st.i1;
+    if (sh.kind == DIST_GP) { g[1] = (uint32_t)st.i1; g[2] = f2u(st.f0); }
+    if (sh.kind == DIST_NICH) { g[1] = f2u(st.f0); g[2] = f2u(st.f1); }
+}
+static void group_value_op(const dist_shared_t * shared, uint32_t * group,
+                           uint32_t value, bool add) {
+    ensure_host_tables();
+    check_shared(*shared);
+    if (is_cat(shared->kind))
+        DIST_REQUIRE(value < (uint32_t)shared->dim, "value out of bounds");
+    Stats st = group_to_stats(*shared, group);
+    if (add) stats_add(shared->kind, st, value);
+    else stats_remove(shared->kind, st, value);
+    stats_to_group(*shared, st, group);
+    if (is_cat(shared->kind)) group[1 + value] += add ? 1u : 0xFFFFFFFFu;
+}
+int dist_group_add_value(const dist_shared_t * shared, uint32_t * group,
+                         uint32_t value) {
+    return guarded([&] { group_value_op(shared, group, value, true); });
+}
+int dist_group_remove_value(const dist_shared_t * shared, uint32_t * group,
+                            uint32_t value) {
+    return guarded([&] { group_value_op(shared, group, value, false); });
+}
+int dist_group_score_value(const dist_shared_t * sh, const uint32_t * group,
+                           uint32_t value, float * out) {
+    return guarded([&] {
+        ensure_host_tables();
+        check_shared(*sh);
+        if (sh->kind == DIST_DD) {   // dd.hpp:222-245
+            DIST_REQUIRE(value < (uint32_t)sh->dim, "value out of bounds");
+            float alpha_sum = 0.f, mine = 0.f;
+            for (int v = 0; v < sh->dim; ++v) {
+                const float a = sh->alphas[v] + (float)(int32_t)group[1 + v];
+                if ((uint32_t)v == value) mine = a;
+                alpha_sum += a;
+            }
+            *out = fast_log(mine / alpha_sum);
+            return;
+        }
+        if (sh->kind == DIST_DPD) {  // dpd.hpp:223-232
+            const float alpha = sh->p[0];
+            const float numer = value == DIST_DPD_OTHER
+                ? alpha * sh->p[1]
+                : alpha * sh->betas[value] + (float)(int32_t)group[1 + value];
+            const float denom = alpha + (float)(int32_t)group[0];
+            *out = fast_log(numer / denom);
+            return;
+        }
+        const Stats st = group_to_stats(*sh, group);
+        const Entry e = scorer_init(sh->kind, sh->p, st);
+        const float lf = sh->kind == DIST_GP ? fast_log_factorial(value) : 0.f;
+        *out = score_group(sh->kind, e, value, lf);
+    });
+}
+
+// ---- MixtureIdTracker -------------------------------------------------------
+dist_id_tracker_t * dist_id_tracker_create(void) { return new dist_id_tracker(); }
+void dist_id_tracker_destroy(dist_id_tracker_t * t) { delete t; }
+int dist_id_tracker_init(dist_id_tracker_t * t, size_t n) {
+    return guarded([&] { t->impl.init(n); });
+}
+int dist_id_tracker_add_group(dist_id_tracker_t * t) {
+    return guarded([&] { t->impl.add_group(); });
+}
+int dist_id_tracker_remove_group(dist_id_tracker_t * t, uint32_t packed) {
+    return guarded([&] { t->impl.remove_group(packed); });
+}
+int dist_id_tracker_packed_to_global(const dist_id_tracker_t * t,
+                                     uint32_t packed, uint32_t * out) {
+    return guarded([&] { *out = t->impl.packed_to_global(packed); });
+}
+int dist_id_tracker_global_to_packed(const dist_id_tracker_t * t,
+                                     uint32_t global, uint32_t * out) {
+    return guarded([&] { *out = t->impl.global_to_packed(global); });
+}
+size_t dist_id_tracker_packed_size(const dist_id_tracker_t * t) {
+    return t->impl.p2g.size();
+}
+size_t dist_id_tracker_global_size(const dist_id_tracker_t * t) {
+    return t->impl.g2p.size();
+}
+
+// ---- batched engine ---------------------------------------------------------
+dist_gibbs_t * dist_gibbs_create(float alpha, float d, int n_features,
+                                 const dist_shared_t * shareds) {
+    dist_gibbs_t * g = nullptr;
+    guarded([&] {
+        std::unique_ptr<dist_gibbs> p(new dist_gibbs());
+        p->impl.reset(new Gibbs(alpha, d, n_features, shareds));
+        g = p.release();
+    });
+    return g;
+}
+void dist_gibbs_destroy(dist_gibbs_t * g) { delete g; }
+int dist_gibbs_load_rows(dist_gibbs_t * g, size_t n_rows,
+                         const uint32_t * const * values,
+                         const uint32_t * assign_packed, int nonempty,
+                         int empty, uint64_t row_offset) {
+    return guarded([&] {
+        g->impl->load(n_rows, values, false, assign_packed, nullptr, nonempty,
+                      empty, row_offset);
+    });
+}
+int dist_gibbs_load_rows_dev(dist_gibbs_t * g, size_t n_rows,
+                             const uint32_t * const * values_dev,
+                             uint32_t * assign_packed_dev, int nonempty,
+                             int empty, uint64_t row_offset) {
+    return guarded([&] {
+        g->impl->load(n_rows, values_dev, true, nullptr, assign_packed_dev,
+                      nonempty, empty, row_offset);
+    });
+}
+size_t dist_gibbs_stat_words(const dist_gibbs_t * g) {
+    return g->impl->stat_words();
+}
+int dist_gibbs_export_stats_dev(const dist_gibbs_t * g, int32_t * stats_dev) {
+    return guarded([&] { g->impl->copy_stats(stats_dev, true); sync(); });
+}
+int dist_gibbs_import_stats_dev(dist_gibbs_t * g, const int32_t * stats_dev) {
+    return guarded([&] {
+        g->impl->copy_stats(const_cast<int32_t *>(stats_dev), false);
+        g->impl->refresh_host_counts();
+        g->impl->rebuild_caches();
+        sync();
+    });
+}
+int dist_gibbs_sweep(dist_gibbs_t * g, size_t row_begin, size_t row_end,
+                     size_t batch_rows, uint32_t seed_state,
+                     uint64_t draw_base) {
+    return guarded([&] {
+        g->impl->sweep(row_begin, row_end, batch_rows, seed_state, draw_base);
+    });
+}
+int dist_gibbs_sweep_sequential(dist_gibbs_t * g, size_t row_begin,
+                                size_t row_end, uint32_t * rng_state) {
+    return guarded(
+        [&] { g->impl->sweep_sequential(row_begin, row_end, rng_state); });
+}
+int dist_gibbs_batch_sample(dist_gibbs_t * g, size_t row_begin, size_t row_end,
+                            uint32_t seed_state, uint64_t draw_base) {
+    return guarded([&] {
+        g->impl->batch_sample(row_begin, row_end, seed_state, draw_base);
+    });
+}
+int dist_gibbs_batch_delta_dev(dist_gibbs_t * g, int32_t * delta_dev) {
+    return guarded([&] { g->impl->batch_delta(delta_dev); sync(); });
+}
+int dist_gibbs_batch_apply_delta_dev(dist_gibbs_t * g,
+                                     const int32_t * delta_dev) {
+    return guarded([&] { g->impl->batch_apply_delta(delta_dev); });
+}
+int dist_gibbs_batch_apply_local(dist_gibbs_t * g) {
+    return guarded([&] { g->impl->batch_apply_local(); });
+}
+int dist_gibbs_batch_finish(dist_gibbs_t * g) {
+    return guarded([&] { g->impl->batch_finish(); });
+}
+int dist_gibbs_row_scores(dist_gibbs_t * g, size_t row, float * scores_out,
+                          size_t * size_out) {
+    return guarded([&] { g->impl->get_row_scores(row, scores_out, size_out); });
+}
+int dist_gibbs_score_rows_dev(dist_gibbs_t * g, size_t row_begin,
+                              size_t row_end, float * scores_dev, size_t ld) {
+    return guarded([&] {
+        g->impl->score_rows(row_begin, row_end, scores_dev, ld);
+        sync();
+    });
+}
+size_t dist_gibbs_group_count(const dist_gibbs_t * g) {
+    return (size_t)g->impl->K();
+}
+size_t dist_gibbs_row_count(const dist_gibbs_t * g) { return g->impl->n_rows; }
+int dist_gibbs_counts(const dist_gibbs_t * g, int * out) {
+    return guarded([&] {
+        std::vector<int> dev((size_t)g->impl->K());
+        g->impl->py.d_counts.download(dev.data(), dev.size());
+        std::copy(dev.begin(), dev.end(), out);
+    });
+}
+int dist_gibbs_assignments(const dist_gibbs_t * g, uint32_t * global_out) {
+    return guarded([&] {
+        sync();
+        if (g->impl->n_rows)
+            HIP_CHECK(hipMemcpy(global_out, g->impl->assign,
+                                g->impl->n_rows * 4, hipMemcpyDeviceToHost));
+    });
+}
+int dist_gibbs_get_group(const dist_gibbs_t * g, int feature, size_t groupid,
+                         uint32_t * group_out) {
+    return guarded([&] {
+        DIST_REQUIRE(feature >= 0 && feature < g->impl->F(), "bad feature");
+        sync();
+        g->impl->feats[feature]->get_group(groupid, group_out);
+    });
+}
+int dist_gibbs_packed_to_global(const dist_gibbs_t * g, uint32_t packed,
+                                uint32_t * out) {
+    return guarded([&] { *out = g->impl->tracker.packed_to_global(packed); });
+}
+int dist_gibbs_global_to_packed(const dist_gibbs_t * g, uint32_t global,
+                                uint32_t * out) {
+    return guarded([&] { *out = g->impl->tracker.global_to_packed(global); });
+}
+int dist_gibbs_kernel_stats(dist_gibbs_t * g, double * ms_out,
+                            uint64_t * launches_out, uint64_t * rows_out,
+                            int reset) {
+    return guarded([&] {
+        if (ms_out) *ms_out = g->impl->kernel_ms;
+        if (launches_out) *launches_out = g->impl->kernel_launches;
+        if (rows_out) *rows_out = g->impl->kernel_rows;
+        if (reset) {
+            g->impl->kernel_ms = 0.0;
+            g->impl->kernel_launches = 0;
+            g->impl->kernel_rows = 0;
+        }
+    });
+}
+
+}  // extern "C"

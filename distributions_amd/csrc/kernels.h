@@ -1,0 +1,585 @@
+// HIP kernels of libdistributions_hip (gfx950).  Included once, by
+// dist_hip.hip.  Layout and roofline notes per kernel are in DESIGN.md.
+#pragma once
+
+#include "models.h"
+
+namespace dist {
+
+constexpr int kBlock = 256;
+constexpr int kMaxF = DIST_MAX_FEATURES;
+
+// ---------------------------------------------------------------------------
+// elementwise special functions (vector_math.cc:190-291)
+
+enum VecOp { VEC_LOG, VEC_EXP, VEC_LGAMMA, VEC_LGAMMA_NU, VEC_LOG_FACTORIAL };
+
+__global__ void k_vector_op(int op, size_t n, const float * __restrict__ in,
+                            float * __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = in[i];
+    float y;
+    switch (op) {
+    case VEC_LOG: y = fast_log(x); break;
+    case VEC_EXP: y = fast_exp(x); break;
+    case VEC_LGAMMA: y = fast_lgamma(x); break;
+    case VEC_LGAMMA_NU: y = fast_lgamma_nu(x); break;
+    default: y = fast_log_factorial(f2u(x)); break;
+    }
+    out[i] = y;
+}
+
+// ---------------------------------------------------------------------------
+// sampling from a score vector, the scalar algorithm of random.cc:94-106 and
+// random.hpp:316-333 run by one lane (API path; the sweep kernel below runs
+// the same recurrence once per lane)
+
+struct SampleOut {
+    float total;
+    float log_sum_exp;
+    int sample;
+};
+
+// mode 0: scores_to_likelihoods; 1: + sample (u given); 2: log_sum_exp only;
+// 3: sample from given likelihoods/total
+__global__ void k_sample_scalar(int mode, int n, float * __restrict__ scores,
+                                float total_in, float u, SampleOut * out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float total = total_in;
+    if (mode != 3) {
+        float m = scores[0];
+        for (int i = 0; i < n; ++i) {
+            const float x = scores[i];
+            m = x > m ? x : m;
+        }
+        total = 0.f;
+        for (int i = 0; i < n; ++i) {
+            const float l = fast_exp(scores[i] - m);
+            if (mode != 2) scores[i] = l;
+            total += l;
+        }
+        out->log_sum_exp = n ? fast_log(total) + m : 0.f;
+    }
+    out->total = total;
+    int sample = n - 1;
+    if (mode == 1 || mode == 3) {
+        float t = total * u;
+        for (int i = 0; i < n; ++i) {
+            t -= scores[i];
+            if (t <= 0.f) { sample = i; break; }
+        }
+    }
+    out->sample = sample;
+}
+
+// ---------------------------------------------------------------------------
+// PitmanYor cached mixture (clustering.hpp:151-230)
+
+__global__ void k_py_rebuild(const int32_t * __restrict__ counts,
+                             float * __restrict__ shifted, int K, float alpha,
+                             float d, int nonempty, int empty) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    const int n = counts[k];
+    shifted[k] = n ? py_nonempty_score(n, d)
+                   : py_empty_score(alpha, d, nonempty, empty);
+}
+
+__global__ void k_py_set_count(int32_t * counts, float * shifted, int k,
+                               int n, float d) {
+    counts[k] = n;
+    if (n) shifted[k] = py_nonempty_score(n, d);
+}
+
+__global__ void k_py_move(int32_t * counts, float * shifted, int dst, int src) {
+    counts[dst] = counts[src];
+    shifted[dst] = shifted[src];
+}
+
+__global__ void k_py_score(const float * __restrict__ shifted,
+                           float * __restrict__ out, int K,
+                           long long sample_size, float alpha) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    out[k] = shifted[k] + py_shift(sample_size, alpha);
+}
+
+__global__ void k_py_score_add_value(float alpha, float d, int group_size,
+                                     int nonempty, int sample_size, int empty,
+                                     float * out) {
+    *out = py_score_add_value(alpha, d, group_size, nonempty, sample_size,
+                              empty);
+}
+
+// ---------------------------------------------------------------------------
+// feature slaves (mixture.hpp:340-450 + the per-model value scorers)
+
+// DPD prior mass alpha * beta_v (dpd.hpp:424) and the OTHER score
+__global__ void k_dpd_prior(float alpha, const float * __restrict__ betas,
+                            float * __restrict__ prior, int dim) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v < dim) prior[v] = alpha * betas[v];
+}
+__global__ void k_dpd_other(float alpha, float beta0, float * out) {
+    *out = fast_log(alpha * beta0);
+}
+
+// Group::init for groups [k0, k1)
+__global__ void k_slave_zero_groups(SlaveView s, int k0, int k1) {
+    const size_t width = is_cat(s.kind) ? (size_t)s.dim : 1;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)(k1 - k0) * width) return;
+    const int k = k0 + (int)(i / width);
+    const int v = (int)(i % width);
+    if (is_cat(s.kind)) s.cnt[(size_t)k * s.dim + v] = 0;
+    if (v == 0) {
+        s.i0[k] = 0; s.i1[k] = 0; s.f0[k] = 0.f; s.f1[k] = 0.f;
+    }
+}
+
+// MixtureValueScorer::update_group for groups [k0, k1) (update_all when the
+// range is everything): dd.hpp:369-379,399-421 etc.  One thread per
+// (value, group) cell, group fastest so that S[v][k] stores coalesce.
+__global__ void k_slave_update(SlaveView s, int k0, int k1) {
+    const size_t nk = (size_t)(k1 - k0);
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (is_cat(s.kind)) {
+        if (i >= nk * (size_t)s.dim) return;
+        const int v = (int)(i / nk);
+        const int k = k0 + (int)(i % nk);
+        refresh_cat_cell(s, k, v);
+        if (v == 0) refresh_shift(s, k);
+    } else {
+        if (i >= nk) return;
+        refresh_scalar_entry(s, k0 + (int)i);
+    }
+}
+
+// MixtureSlave::add_value / remove_value for one row (API path)
+__global__ void k_slave_value_op(SlaveView s, int k, uint32_t value, int add) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    Stats st = load_stats(s, k);
+    if (add) stats_add(s.kind, st, value); else stats_remove(s.kind, st, value);
+    store_stats(s, k, st);
+    if (is_cat(s.kind)) {
+        s.cnt[(size_t)k * s.dim + value] += add ? 1 : -1;
+        refresh_cat_cell(s, k, (int)value);   // dd.hpp:458-467
+        refresh_shift(s, k);
+    } else {
+        refresh_scalar_entry(s, k);
+    }
+}
+
+// Packed_::packed_remove (vector.hpp:47-51): group `src` moves into `dst`
+__global__ void k_slave_move_group(SlaveView s, int dst, int src) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (is_cat(s.kind)) {
+        if (v < s.dim) {
+            s.cnt[(size_t)dst * s.dim + v] = s.cnt[(size_t)src * s.dim + v];
+            s.S[(size_t)v * s.cap + dst] = s.S[(size_t)v * s.cap + src];
+        }
+    }
+    if (v == 0) {
+        s.i0[dst] = s.i0[src]; s.i1[dst] = s.i1[src];
+        s.f0[dst] = s.f0[src]; s.f1[dst] = s.f1[src];
+        s.c0[dst] = s.c0[src]; s.c1[dst] = s.c1[src];
+        s.c2[dst] = s.c2[src]; s.c3[dst] = s.c3[src];
+    }
+}
+
+// MixtureSlave::score_value (accumulates) and score_value_group
+__global__ void k_slave_score_value(SlaveView s, uint32_t value,
+                                    float * __restrict__ acc, int K) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    const float lf = s.kind == DIST_GP ? fast_log_factorial(value) : 0.f;
+    acc[k] = accumulate(s.kind, acc[k], load_entry(s, k, value), value, lf);
+}
+__global__ void k_slave_score_group(SlaveView s, int k, uint32_t value,
+                                    float * out) {
+    const float lf = s.kind == DIST_GP ? fast_log_factorial(value) : 0.f;
+    *out = score_group(s.kind, load_entry(s, k, value), value, lf);
+}
+
+// ---------------------------------------------------------------------------
+// the batched row update
+
+struct SweepScalars {
+    float shift;         // -fast_log(float(N - 1) + alpha)   (row removed)
+    float empty_single;  // empty-group score with one non-empty group fewer
+    float shift_full;    // -fast_log(float(N) + alpha)       (no removal)
+};
+
+struct SweepParams {
+    int F;
+    SlaveView feat[kMaxF];
+    const uint32_t * values[kMaxF];
+    const int32_t * counts;    // driver counts[K] at batch entry
+    const float * shifted;     // clustering.hpp shifted_scores_[K]
+    const float * base;        // shifted[k] + shift
+    const float * table0;      // feature 0 folded, k-major: [K][dim0] or null
+    const SweepScalars * scalars;
+    int K;
+    int n_empty;
+    float alpha, d;
+    long long sample_size;
+    const uint32_t * assign;   // global group id per local row
+    const int32_t * g2p;       // global -> packed at batch entry
+    uint32_t * old_packed;     // per batch row
+    uint32_t * new_packed;
+    size_t row_begin, row_end;
+    unsigned long long row_offset;   // global index of local row 0
+    unsigned long long draw_base;
+    uint32_t seed_state;
+};
+
+// base[k], the scalars and (categorical feature 0) the folded k-major table
+//   table0[k][v] = (base[k] + S[v][k]) - shift0[k]
+// which is the row score for value v at group k when no self-removal applies;
+// the two float operations are the reference's, in its order.
+__global__ void k_sweep_prepare(SweepParams P, float * __restrict__ base,
+                                float * __restrict__ table0,
+                                SweepScalars * scalars) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const float shift = py_shift(P.sample_size - 1, P.alpha);
+    if (i == 0) {
+        scalars->shift = shift;
+        scalars->shift_full = py_shift(P.sample_size, P.alpha);
+        scalars->empty_single = py_empty_score(
+            P.alpha, P.d, P.K - P.n_empty - 1, P.n_empty);
+    }
+    if (table0) {
+        const SlaveView & s = P.feat[0];
+        if (i >= (size_t)P.K * s.dim) return;
+        const int k = (int)(i / s.dim);
+        const int v = (int)(i % s.dim);
+        const float b = P.shifted[k] + shift;
+        if (v == 0) base[k] = b;
+        table0[i] = (b + s.S[(size_t)v * s.cap + k]) - s.c0[k];
+    } else {
+        if (i >= (size_t)P.K) return;
+        base[i] = P.shifted[i] + shift;
+    }
+}
+
+// Scores of one row in batch semantics: state at batch entry minus the row.
+//   count(g) >= 2: group order unchanged; slot g scored from (stats - row).
+//   count(g) == 1: the group vanishes as MixtureDriver::remove_value does it
+//     (mixture.hpp:108-119): the last group moves into slot g, one slot fewer,
+//     and the empty groups' prior loses one non-empty group
+//     (clustering.hpp:221-230).
+// KIND0/KIND1 >= 0 pin the kind of features 0/1 at compile time and NF > 0
+// the feature count; NF == 0 is the run-time generic form (any feature list).
+template <int KIND0, int KIND1, int NF>
+struct RowScorer {
+    static constexpr int kUnroll = NF > 0 ? NF : 1;
+    const SweepParams & P;
+    uint32_t x[kMaxF];
+    float lf[kMaxF];
+    int g;
+    int singleton;
+    int Kl;
+    float s_own;
+    float shift, empty_single;
+
+    __device__ __forceinline__ int nf() const { return NF > 0 ? NF : P.F; }
+    __device__ __forceinline__ int kind_of(int f) const {
+        if (f == 0 && KIND0 >= 0) return KIND0;
+        if (f == 1 && KIND1 >= 0) return KIND1;
+        return P.feat[f].kind;
+    }
+
+    __device__ __forceinline__ RowScorer(const SweepParams & P_, size_t row)
+        : P(P_) {
+        shift = P.scalars->shift;
+        empty_single = P.scalars->empty_single;
+        g = P.g2p[P.assign[row]];
+        const int n_g = P.counts[g];
+        singleton = (n_g == 1);
+        Kl = P.K - singleton;
+#pragma unroll kUnroll
+        for (int f = 0; f < nf(); ++f) {
+            x[f] = P.values[f][row];
+            lf[f] = kind_of(f) == DIST_GP ? fast_log_factorial(x[f]) : 0.f;
+        }
+        if (!singleton) {
+            float s = py_nonempty_score(n_g - 1, P.d) + shift;
+#pragma unroll kUnroll
+            for (int f = 0; f < nf(); ++f) {
+                SlaveView v = P.feat[f];
+                v.kind = kind_of(f);
+                s = accumulate(v.kind, s, entry_after_remove(v, g, x[f]),
+                               x[f], lf[f]);
+            }
+            s_own = s;
+        } else {
+            s_own = unfolded(P.K - 1, true);
+        }
+    }
+
+    // score of slot `src` from the caches, nothing folded
+    __device__ __forceinline__ float unfolded(int src, bool single) const {
+        const float c = (single && P.counts[src] == 0) ? empty_single
+                                                        : P.shifted[src];
+        float s = c + shift;
+#pragma unroll kUnroll
+        for (int f = 0; f < nf(); ++f) {
+            SlaveView v = P.feat[f];
+            v.kind = kind_of(f);
+            s = accumulate(v.kind, s, load_entry(v, src, x[f]), x[f], lf[f]);
+        }
+        return s;
+    }
+
+    // score of local slot k (k < K; slots >= Kl are not part of the row's
+    // view and are masked by the caller)
+    __device__ __forceinline__ float at(int k) const {
+        float s;
+        int f0 = 0;
+        if (P.table0 != nullptr
+            && !(KIND0 == DIST_DPD && x[0] == DIST_DPD_OTHER)) {
+            s = P.table0[(size_t)k * P.feat[0].dim + x[0]];
+            f0 = 1;
+        } else {
+            s = P.base[k];
+        }
+#pragma unroll kUnroll
+        for (int f = f0; f < nf(); ++f) {
+            SlaveView v = P.feat[f];
+            v.kind = kind_of(f);
+            s = accumulate(v.kind, s, load_entry(v, k, x[f]), x[f], lf[f]);
+        }
+        if (P.counts[k] == 0) {   // uniform across the wave, rare
+            const float s2 = unfolded(k, true);
+            s = singleton ? s2 : s;
+        }
+        return k == g ? s_own : s;
+    }
+};
+
+// One lane = one row: three passes over the groups in index order, exactly
+// the scalar recurrences of scores_to_likelihoods (random.cc:94-106) and
+// sample_from_likelihoods (random.hpp:316-333).  Rows are independent, so the
+// float sums keep the reference's association while 64 rows run per wave.
+template <int KIND0, int KIND1, int NF>
+__global__ __launch_bounds__(kBlock) void k_sweep_sample(SweepParams P) {
+    __shared__ uint32_t s_exp[1024];
+    for (int i = threadIdx.x; i < 1024; i += kBlock)
+        s_exp[i] = g_tables_dev.exp_table[i];
+    __syncthreads();
+    const float ea = u2f(g_tables_dev.exp_ab[0]);
+    const float eb = u2f(g_tables_dev.exp_ab[1]);
+    const int K = P.K;
+
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t row = P.row_begin + (size_t)blockIdx.x * kBlock + threadIdx.x;
+         row < P.row_end; row += stride) {
+        const RowScorer<KIND0, KIND1, NF> rs(P, row);
+        const int Kl = rs.Kl;
+
+        // vector_max (vector_math.cc:74-83)
+        float m = rs.at(0);
+        for (int k = 1; k < K; ++k) {
+            const float s = rs.at(k);
+            m = (k < Kl && s > m) ? s : m;
+        }
+        // scores_to_likelihoods: total in index order
+        float total = 0.f;
+        for (int k = 0; k < K; ++k) {
+            const float l = fast_exp_nonpos(rs.at(k) - m, s_exp, ea, eb);
+            total += (k < Kl) ? l : 0.f;
+        }
+        // sample_unif01: engine step (draw_base + global row + 1)
+        const unsigned long long draw =
+            P.draw_base + P.row_offset + (unsigned long long)row;
+        const uint32_t xs = lcg_jump(P.seed_state, draw + 1ull);
+        const float u = lcg_unif01(xs);
+        // sample_from_likelihoods
+        float t = total * u;
+        int found = -1;
+        for (int k = 0; k < K; ++k) {
+            const float l = fast_exp_nonpos(rs.at(k) - m, s_exp, ea, eb);
+            t -= (k < Kl) ? l : 0.f;
+            if (found < 0 && k < Kl && t <= 0.f) found = k;
+            if (__all(found >= 0)) break;
+        }
+        int g2 = found < 0 ? Kl - 1 : found;
+        if (rs.singleton && g2 == rs.g) g2 = K - 1;   // slot g held group K-1
+        const size_t b = row - P.row_begin;
+        P.old_packed[b] = (uint32_t)rs.g;
+        P.new_packed[b] = (uint32_t)g2;
+    }
+}
+
+// batch-semantics scores of one row, for tolerance tests of the scores
+template <int KIND0, int KIND1, int NF>
+__global__ void k_row_scores(SweepParams P, size_t row, float * out,
+                             int * size_out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const RowScorer<KIND0, KIND1, NF> rs(P, row);
+    for (int k = 0; k < rs.Kl; ++k) out[k] = rs.at(k);
+    *size_out = rs.Kl;
+}
+
+// score_values extension: out[r][k] against the current state, no removal
+__global__ void k_score_rows(SweepParams P, float * __restrict__ out,
+                             size_t ld) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t n = (P.row_end - P.row_begin) * (size_t)P.K;
+    if (i >= n) return;
+    const size_t r = i / P.K;
+    const int k = (int)(i % P.K);
+    const size_t row = P.row_begin + r;
+    float s = P.shifted[k] + P.scalars->shift_full;
+    for (int f = 0; f < P.F; ++f) {
+        const SlaveView & v = P.feat[f];
+        const uint32_t x = P.values[f][row];
+        const float lf = v.kind == DIST_GP ? fast_log_factorial(x) : 0.f;
+        s = accumulate(v.kind, s, load_entry(v, k, x), x, lf);
+    }
+    out[r * ld + k] = s;
+}
+
+// ---------------------------------------------------------------------------
+// applying a batch of moves
+
+// Integer statistics are exact under atomics.  `stats` is either the live
+// state or a zeroed delta image in the stat-word layout:
+//   counts[K] | per feature: i0[K] i1[K] (categorical: cnt[K][dim])
+// NormalInverseChiSq's count moves with its float statistics in k_replay.
+struct StatImage {
+    int32_t * counts;
+    int32_t * i0[kMaxF];
+    int32_t * i1[kMaxF];
+    int32_t * cnt[kMaxF];
+};
+
+__global__ void k_apply_moves(SweepParams P, StatImage img,
+                              const uint32_t * __restrict__ p2g,
+                              uint32_t * __restrict__ assign) {
+    const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t n = P.row_end - P.row_begin;
+    if (b >= n) return;
+    const size_t row = P.row_begin + b;
+    const uint32_t go = P.old_packed[b], gn = P.new_packed[b];
+    if (assign) assign[row] = p2g[gn];
+    if (go == gn) return;
+    atomicAdd(&img.counts[go], -1);
+    atomicAdd(&img.counts[gn], 1);
+    for (int f = 0; f < P.F; ++f) {
+        const SlaveView & s = P.feat[f];
+        const uint32_t x = P.values[f][row];
+        switch (s.kind) {
+        case DIST_DD:
+        case DIST_DPD:
+            atomicAdd(&img.i0[f][go], -1);
+            atomicAdd(&img.i0[f][gn], 1);
+            if (x != DIST_DPD_OTHER) {
+                atomicAdd(&img.cnt[f][(size_t)go * s.dim + x], -1);
+                atomicAdd(&img.cnt[f][(size_t)gn * s.dim + x], 1);
+            }
+            break;
+        case DIST_BB:
+            atomicAdd(x ? &img.i0[f][go] : &img.i1[f][go], -1);
+            atomicAdd(x ? &img.i0[f][gn] : &img.i1[f][gn], 1);
+            break;
+        case DIST_GP:
+            atomicAdd(&img.i0[f][go], -1);
+            atomicAdd(&img.i0[f][gn], 1);
+            atomicAdd(&img.i1[f][go], -(int32_t)x);
+            atomicAdd(&img.i1[f][gn], (int32_t)x);
+            break;
+        default:
+            break;
+        }
+    }
+}
+
+// stats += delta (after the all-reduce), elementwise over the stat words
+__global__ void k_add_words(int32_t * __restrict__ dst,
+                            const int32_t * __restrict__ src, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] += src[i];
+}
+
+// Float statistics (NICH count/mean/ctv, GP log_prod) depend on update order
+// (nich.hpp:125-165 is a running Welford update), so they are replayed per
+// group in row order: one wave per group walks the batch 64 rows at a time
+// and applies "remove from old, then add to new" for the rows that touch its
+// group -- the order the sequential chain would apply them in.
+// old_packed == nullptr means rows are only added (initial load).
+__global__ __launch_bounds__(64) void k_replay_floats(
+        SlaveView s, const uint32_t * __restrict__ values,
+        const uint32_t * __restrict__ old_packed,
+        const uint32_t * __restrict__ new_packed, size_t row_begin,
+        size_t n_rows) {
+    const int k = blockIdx.x;
+    const int lane = threadIdx.x;
+    Stats st = load_stats(s, k);
+    const bool ints_too = (s.kind == DIST_NICH);
+    Stats fl = st;   // running copy whose float members are authoritative
+    for (size_t base = 0; base < n_rows; base += 64) {
+        const size_t b = base + lane;
+        uint32_t go = 0xFFFFFFFFu, gn = 0xFFFFFFFFu, x = 0;
+        if (b < n_rows) {
+            gn = new_packed[b];
+            go = old_packed ? old_packed[b] : 0xFFFFFFFFu;
+            x = values[row_begin + b];
+        }
+        unsigned long long touched =
+            __ballot(go == (uint32_t)k || gn == (uint32_t)k);
+        while (touched) {
+            const int j = __ffsll((long long)touched) - 1;
+            touched &= touched - 1;
+            const uint32_t xj = __shfl(x, j);
+            const uint32_t goj = __shfl(go, j);
+            const uint32_t gnj = __shfl(gn, j);
+            if (goj == (uint32_t)k) stats_remove(s.kind, fl, xj);
+            if (gnj == (uint32_t)k) stats_add(s.kind, fl, xj);
+        }
+    }
+    if (lane == 0) {
+        s.f0[k] = fl.f0;
+        s.f1[k] = fl.f1;
+        if (ints_too) s.i0[k] = fl.i0;
+    }
+}
+
+// initial load: integer statistics of all rows by atomics
+__global__ void k_load_counts(SweepParams P, StatImage img,
+                              const uint32_t * __restrict__ assign_packed) {
+    const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= P.row_end) return;
+    const uint32_t g = assign_packed[row];
+    atomicAdd(&img.counts[g], 1);
+    for (int f = 0; f < P.F; ++f) {
+        const SlaveView & s = P.feat[f];
+        const uint32_t x = P.values[f][row];
+        switch (s.kind) {
+        case DIST_DD:
+        case DIST_DPD:
+            atomicAdd(&img.i0[f][g], 1);
+            atomicAdd(&img.cnt[f][(size_t)g * s.dim + x], 1);
+            break;
+        case DIST_BB:
+            atomicAdd(x ? &img.i0[f][g] : &img.i1[f][g], 1);
+            break;
+        case DIST_GP:
+            atomicAdd(&img.i0[f][g], 1);
+            atomicAdd(&img.i1[f][g], (int32_t)x);
+            break;
+        default:
+            break;
+        }
+    }
+}
+
+__global__ void k_packed_to_global(const uint32_t * __restrict__ packed,
+                                   const uint32_t * __restrict__ p2g,
+                                   uint32_t * __restrict__ global, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) global[i] = p2g[packed[i]];
+}
+
+}  // namespace dist

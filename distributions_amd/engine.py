@@ -1,0 +1,166 @@
+"""The batched row engine: many Gibbs row updates per launch.
+
+`Gibbs` is the reference's pattern -- one PitmanYor driver, one slave mixture
+per feature column, one MixtureIdTracker (examples/mixture/main.py:59-123,
+213-248) -- over a table of rows resident in HBM.  `ShardedGibbs` runs it with
+one process per GPU: rows are block-partitioned, every rank keeps a replica of
+the sufficient statistics, and each sub-sweep ends with one all-reduce of the
+integer statistic deltas (RCCL over xGMI through torch.distributed).
+"""
+import numpy as np
+
+from . import _core
+
+KIND = {"dd": _core.KIND_DD, "bb": _core.KIND_BB, "gp": _core.KIND_GP,
+        "nich": _core.KIND_NICH, "dpd": _core.KIND_DPD}
+
+
+def dd_shared(alphas):
+    """DirichletDiscrete::Shared (models/dd.hpp:57-86)"""
+    return _core.SharedParams.make(_core.KIND_DD, alphas=list(alphas))
+
+
+def bb_shared(alpha, beta):
+    """BetaBernoulli::Shared (models/bb.hpp:54-76)"""
+    return _core.SharedParams.make(_core.KIND_BB, p=(alpha, beta))
+
+
+def gp_shared(alpha, inv_beta):
+    """GammaPoisson::Shared (models/gp.hpp:52-81)"""
+    return _core.SharedParams.make(_core.KIND_GP, p=(alpha, inv_beta))
+
+
+def nich_shared(mu, kappa, sigmasq, nu):
+    """NormalInverseChiSq::Shared (models/nich.hpp:52-95)"""
+    return _core.SharedParams.make(_core.KIND_NICH,
+                                   p=(mu, kappa, sigmasq, nu))
+
+
+def dpd_shared(alpha, betas, beta0=0.0):
+    """DirichletProcessDiscrete::Shared with values remapped to 0..len(betas)-1
+    (models/dpd.hpp:59-153)"""
+    return _core.SharedParams.make(_core.KIND_DPD, p=(alpha, beta0),
+                                   betas=np.asarray(betas, np.float32))
+
+
+class Gibbs(object):
+    """PitmanYor(alpha, d) driver + feature slaves over resident rows."""
+
+    def __init__(self, alpha, d, shareds):
+        self.alpha = float(alpha)
+        self.d = float(d)
+        self.shareds = list(shareds)
+        self.core = _core.GibbsEngine(self.alpha, self.d, self.shareds)
+
+    # -- data ---------------------------------------------------------------
+    def load_rows(self, values, assign_packed, nonempty_groups,
+                  empty_groups=1, row_offset=0):
+        self.core.load_rows(values, assign_packed, nonempty_groups,
+                            empty_groups, row_offset)
+
+    def load_rows_torch(self, values, assign_packed, nonempty_groups,
+                        empty_groups=1, row_offset=0):
+        """values: int32/float32 CUDA tensors (one per feature);
+        assign_packed: int32 CUDA tensor, rewritten in place to global ids."""
+        ptrs = [int(v.data_ptr()) for v in values]
+        self.core.load_rows_dev(ptrs, int(assign_packed.data_ptr()),
+                                int(assign_packed.numel()), nonempty_groups,
+                                empty_groups, row_offset,
+                                keep=(list(values), assign_packed))
+
+    # -- sweeps -------------------------------------------------------------
+    def sweep(self, row_begin, row_end, batch_rows, seed, draw_base=0):
+        """One pass over rows [row_begin,row_end) in frozen batches."""
+        self.core.sweep(row_begin, row_end, batch_rows, _core.rng_seed(seed),
+                        draw_base)
+
+    def sweep_sequential(self, row_begin, row_end, rng_state):
+        """The reference's sequential chain; returns the new rng state."""
+        return self.core.sweep_sequential(row_begin, row_end, rng_state)
+
+    # -- state --------------------------------------------------------------
+    def __len__(self):
+        return self.core.group_count()
+
+    def counts(self):
+        return self.core.counts()
+
+    def assignments(self):
+        return self.core.assignments()
+
+    def get_group(self, feature, groupid):
+        return self.core.get_group(feature, groupid)
+
+    def row_scores(self, row):
+        return self.core.row_scores(row)
+
+    def kernel_stats(self, reset=False):
+        return self.core.kernel_stats(reset)
+
+
+class ShardedGibbs(object):
+    """Row-sharded Gibbs over the ranks of a torch.distributed process group.
+
+    Every rank holds rows [row_offset, row_offset + n_local) and a full
+    replica of the statistics.  A sub-sweep scores `batch_rows` local rows per
+    rank against the common snapshot, turns the local moves into integer
+    deltas, sums the deltas over ranks with ONE all-reduce, applies the sum
+    and normalises the group set identically on every rank.  Row i always
+    uses engine draw (draw_base + global index of i), so the result does not
+    depend on the number of ranks for a given batch composition.
+
+    `backend` is the per-rank compute object (a GibbsEngine-like); the
+    distributed tests substitute a CPU stand-in to exercise this driver with
+    gloo.
+    """
+
+    def __init__(self, backend, n_local, row_offset, group=None, device=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.backend = backend
+        self.n_local = int(n_local)
+        self.row_offset = int(row_offset)
+        self.group = group
+        self.device = device
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+
+    def _all_reduce(self, tensor):
+        if self.world > 1:
+            self.dist.all_reduce(tensor, op=self.dist.ReduceOp.SUM,
+                                 group=self.group)
+
+    def sync_initial_stats(self):
+        """After every rank loaded ITS rows: make the statistics global."""
+        import torch
+        if self.world == 1:
+            return
+        n = self.backend.stat_words()
+        t = torch.zeros(n, dtype=torch.int32, device=self.device)
+        self.backend.export_stats_dev(int(t.data_ptr()))
+        self._all_reduce(t)
+        self.backend.import_stats_dev(int(t.data_ptr()))
+
+    def sweep(self, batch_rows, seed_state, draw_base=0):
+        """One pass over the local shard; all ranks take the same number of
+        sub-sweeps (shards are equal up to one batch of padding)."""
+        import torch
+        n_batches = (self.n_local + batch_rows - 1) // batch_rows
+        if self.world > 1:
+            nb = torch.tensor([n_batches], dtype=torch.int64,
+                              device=self.device)
+            self.dist.all_reduce(nb, op=self.dist.ReduceOp.MAX,
+                                 group=self.group)
+            n_batches = int(nb.item())
+        for b in range(n_batches):
+            r0 = min(self.n_local, b * batch_rows)
+            r1 = min(self.n_local, r0 + batch_rows)
+            self.backend.batch_sample(r0, r1, seed_state, draw_base)
+            if self.world == 1:
+                self.backend.batch_apply_local()
+            else:
+                n = self.backend.stat_words()
+                delta = torch.empty(n, dtype=torch.int32, device=self.device)
+                self.backend.batch_delta_dev(int(delta.data_ptr()))
+                self._all_reduce(delta)
+                self.backend.batch_apply_delta_dev(int(delta.data_ptr()))
+            self.backend.batch_finish()

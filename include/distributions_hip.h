@@ -1,0 +1,257 @@
+/* distributions_hip.h -- C ABI of libdistributions_hip.so
+ *
+ * MI355X (gfx950) implementation of the collapsed-Gibbs mixture hot path of
+ * forcedotcom/distributions v2.0.28.  The reference has no C ABI: its boundary
+ * is C++ templates (include/distributions/{mixture,clustering}.hpp,
+ * the models headers) wrapped by Cython (distributions/lp/).  Each entry point below
+ * names the reference member it stands in for (paths relative to the
+ * reference root).  include/distributions_hip.hpp re-presents these as the
+ * reference's C++ classes; distributions_amd/lp re-presents them as the
+ * reference's Python classes.
+ *
+ * Conventions
+ *   - every call returns 0 on success, non-zero on error; dist_last_error()
+ *     then holds the message (the reference throws std::runtime_error under
+ *     DIST_THROW_ON_ERROR, common.hpp:49-57).  Bounds are always checked.
+ *   - numeric state (sufficient statistics, score caches) lives in HBM; host
+ *     pointers are caller-owned and copied in/out, like the numpy<->VectorFloat
+ *     copies of lp/vector.pyx:33-47.  Pointers named *_dev are device memory.
+ *   - values cross the ABI as 32-bit words: int for DirichletDiscrete /
+ *     BetaBernoulli / GammaPoisson / DirichletProcessDiscrete, IEEE float bits
+ *     for NormalInverseChiSq.
+ *   - group ids are "packed" ids (mixture.hpp:41-46) unless named global.
+ */
+#ifndef DISTRIBUTIONS_HIP_H
+#define DISTRIBUTIONS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DIST_ABI_VERSION 1
+
+enum dist_kind {
+    DIST_DD = 0,   /* models/dd.hpp   DirichletDiscrete<256>          */
+    DIST_BB = 1,   /* models/bb.hpp   BetaBernoulli                   */
+    DIST_GP = 2,   /* models/gp.hpp   GammaPoisson                    */
+    DIST_NICH = 3, /* models/nich.hpp NormalInverseChiSq              */
+    DIST_DPD = 4   /* models/dpd.hpp  DirichletProcessDiscrete (dense
+                      value remap: value v in [0,dim), OTHER = 2^32-1) */
+};
+
+#define DIST_DD_MAX_DIM 256
+#define DIST_DPD_OTHER 0xFFFFFFFFu
+#define DIST_MAX_FEATURES 8
+
+/* Model::Shared (dd.hpp:57-86, bb.hpp:54-76, gp.hpp:52-81, nich.hpp:52-95,
+ * dpd.hpp:59-153) */
+typedef struct dist_shared {
+    int kind;
+    int dim;             /* DD: dim; DPD: number of known values            */
+    float p[4];          /* BB: alpha,beta | GP: alpha,inv_beta |
+                            NICH: mu,kappa,sigmasq,nu | DPD: alpha,beta0    */
+    float alphas[DIST_DD_MAX_DIM]; /* DD                                    */
+    const float * betas; /* DPD: betas[dim], host pointer, copied           */
+} dist_shared_t;
+
+/* Model::Group as 32-bit words (dd.hpp:89-93, bb.hpp:79-82, gp.hpp:84-88,
+ * nich.hpp:98-102, dpd.hpp:157-158):
+ *   DD / DPD: { count_sum, counts[dim] }     BB:   { heads, tails }
+ *   GP:       { count, sum, log_prod(f32) }  NICH: { count, mean(f32),
+ *                                                    count_times_variance(f32) } */
+size_t dist_group_words(const dist_shared_t * shared);
+
+int dist_abi_version(void);
+const char * dist_last_error(void);
+int dist_device_count(int * count);
+int dist_set_device(int device);
+int dist_synchronize(void);
+
+/* ---- entropy: rng_t = std::default_random_engine (random_fwd.hpp:34) ----
+ * The engine state is one word; sample_unif01 (random.hpp:47-50) consumes
+ * exactly one step. */
+uint32_t dist_rng_seed(uint64_t seed);            /* engine.seed(seed)      */
+uint32_t dist_rng_next(uint32_t * state);         /* engine()               */
+float dist_rng_unif01(uint32_t * state);          /* sample_unif01          */
+uint32_t dist_rng_jump(uint32_t state, uint64_t steps);
+
+/* ---- special.hpp / vector_math.hpp on device (host arrays in/out) -------- */
+int dist_vector_log(size_t n, const float * in, float * out);      /* vector_math.cc:224-255 */
+int dist_vector_exp(size_t n, const float * in, float * out);      /* :190-221 */
+int dist_vector_lgamma(size_t n, const float * in, float * out);   /* :257-272 */
+int dist_vector_lgamma_nu(size_t n, const float * in, float * out);/* :275-291 */
+int dist_vector_log_factorial(size_t n, const uint32_t * in, float * out); /* special.hpp:208-214 */
+
+/* ---- discrete sampling (random.hpp:316-392, random.cc:77-128) ------------ */
+/* sample_from_scores_overwrite: scores[n] (host) become likelihoods */
+int dist_sample_from_scores_overwrite(uint32_t * rng_state, size_t n,
+                                      float * scores, size_t * sample_out);
+int dist_scores_to_likelihoods(size_t n, float * scores, float * total_out);
+int dist_sample_from_likelihoods(uint32_t * rng_state, size_t n,
+                                 const float * likelihoods, float total,
+                                 size_t * sample_out);
+int dist_log_sum_exp(size_t n, const float * scores, float * out);
+
+/* ---- Clustering<int>::PitmanYor (clustering.hpp:58-123) ------------------ */
+int dist_py_score_add_value(float alpha, float d, int group_size,
+                            int nonempty_group_count, int sample_size,
+                            int empty_group_count, float * out);
+int dist_py_score_remove_value(float alpha, float d, int group_size,
+                               int nonempty_group_count, int sample_size,
+                               int empty_group_count, float * out);
+
+/* ---- PitmanYor::Mixture = CachedMixture (clustering.hpp:126-234) --------- */
+typedef struct dist_py_mixture dist_py_mixture_t;
+dist_py_mixture_t * dist_py_mixture_create(void);
+void dist_py_mixture_destroy(dist_py_mixture_t * m);
+/* counts() = counts; init(model)                       clustering.hpp:151-161 */
+int dist_py_mixture_init(dist_py_mixture_t * m, float alpha, float d,
+                         const int * counts, size_t group_count);
+/* add_value(model, groupid) -> group was empty         clustering.hpp:163-176 */
+int dist_py_mixture_add_value(dist_py_mixture_t * m, float alpha, float d,
+                              size_t groupid, int * added_out);
+/* remove_value(model, groupid) -> group became empty   clustering.hpp:178-193 */
+int dist_py_mixture_remove_value(dist_py_mixture_t * m, float alpha, float d,
+                                 size_t groupid, int * removed_out);
+/* score_value(model, scores): OVERWRITES scores[size]  clustering.hpp:195-208 */
+int dist_py_mixture_score_value(const dist_py_mixture_t * m, float alpha,
+                                float d, float * scores, size_t size);
+size_t dist_py_mixture_size(const dist_py_mixture_t * m);           /* counts().size() */
+size_t dist_py_mixture_sample_size(const dist_py_mixture_t * m);    /* sample_size()   */
+int dist_py_mixture_counts(const dist_py_mixture_t * m, int * out); /* counts()        */
+/* empty_groupids(): writes at most cap ids, returns how many exist */
+size_t dist_py_mixture_empty_groupids(const dist_py_mixture_t * m,
+                                      size_t * out, size_t cap);
+
+/* ---- Model::Mixture = MixtureSlave<Model, ...> (mixture.hpp:340-450) ----- */
+typedef struct dist_mixture dist_mixture_t;
+dist_mixture_t * dist_mixture_create(const dist_shared_t * shared);
+void dist_mixture_destroy(dist_mixture_t * m);
+int dist_mixture_clear(dist_mixture_t * m);                        /* groups().clear()      */
+int dist_mixture_append(dist_mixture_t * m, const uint32_t * group);/* groups().push_back(g) */
+int dist_mixture_get_group(const dist_mixture_t * m, size_t groupid,
+                           uint32_t * group_out);                  /* groups(i) (copy)      */
+size_t dist_mixture_size(const dist_mixture_t * m);                /* groups().size()       */
+int dist_mixture_init(dist_mixture_t * m);                         /* init        :354-359  */
+int dist_mixture_add_group(dist_mixture_t * m);                    /* add_group   :361-368  */
+int dist_mixture_remove_group(dist_mixture_t * m, size_t groupid); /* remove_group:370-375  */
+int dist_mixture_add_value(dist_mixture_t * m, size_t groupid,
+                           uint32_t value);                        /* add_value   :377-384  */
+int dist_mixture_remove_value(dist_mixture_t * m, size_t groupid,
+                              uint32_t value);                     /* remove_value:386-398  */
+int dist_mixture_score_value_group(const dist_mixture_t * m, size_t groupid,
+                                   uint32_t value, float * out);   /* :400-414 */
+/* score_value: ACCUMULATES into scores_accum[size]                   :416-425 */
+int dist_mixture_score_value(const dist_mixture_t * m, uint32_t value,
+                             float * scores_accum, size_t size);
+
+/* ---- Model::Group scalar API (host side, O(1); dd.hpp:113-199 etc.) ------ */
+int dist_group_init(const dist_shared_t * shared, uint32_t * group);
+int dist_group_add_value(const dist_shared_t * shared, uint32_t * group,
+                         uint32_t value);
+int dist_group_remove_value(const dist_shared_t * shared, uint32_t * group,
+                            uint32_t value);
+int dist_group_score_value(const dist_shared_t * shared,
+                           const uint32_t * group, uint32_t value,
+                           float * out);
+
+/* ---- MixtureIdTracker (mixture.hpp:460-521) ------------------------------ */
+typedef struct dist_id_tracker dist_id_tracker_t;
+dist_id_tracker_t * dist_id_tracker_create(void);
+void dist_id_tracker_destroy(dist_id_tracker_t * t);
+int dist_id_tracker_init(dist_id_tracker_t * t, size_t group_count);
+int dist_id_tracker_add_group(dist_id_tracker_t * t);
+int dist_id_tracker_remove_group(dist_id_tracker_t * t, uint32_t packed);
+int dist_id_tracker_packed_to_global(const dist_id_tracker_t * t,
+                                     uint32_t packed, uint32_t * global_out);
+int dist_id_tracker_global_to_packed(const dist_id_tracker_t * t,
+                                     uint32_t global, uint32_t * packed_out);
+size_t dist_id_tracker_packed_size(const dist_id_tracker_t * t);
+size_t dist_id_tracker_global_size(const dist_id_tracker_t * t);
+
+/* ==== batched row engine (extension; SURVEY 8b "new batched entry points") ==
+ * One PitmanYor driver + n_features slaves + an id tracker over a resident
+ * table of rows -- the loop of examples/mixture/main.py:236-244 /
+ * benchmarks/mixture.cc:104-115 with sampling, run for many rows per launch.
+ *
+ * Batch semantics: every row of a batch is scored against the
+ * state at batch entry minus itself (exactly what remove_value leaves behind,
+ * including group removal when the row was alone), draws with engine step
+ * (draw_base + global row index + 1) of `seed_state`, and all moves are then
+ * applied in row order.  A batch of one row is the reference's sequential
+ * update. */
+typedef struct dist_gibbs dist_gibbs_t;
+dist_gibbs_t * dist_gibbs_create(float alpha, float d, int n_features,
+                                 const dist_shared_t * shareds);
+void dist_gibbs_destroy(dist_gibbs_t * g);
+
+/* Make n_rows rows resident.  values[f] -> n_rows words; assign_packed[i] in
+ * [0, nonempty_groups); empty_groups >= 1 empty groups are appended
+ * (mixture.hpp:152-162).  row_offset = global index of local row 0 (multi-GPU
+ * shards).  The *_dev form takes device pointers and keeps using them. */
+int dist_gibbs_load_rows(dist_gibbs_t * g, size_t n_rows,
+                         const uint32_t * const * values,
+                         const uint32_t * assign_packed, int nonempty_groups,
+                         int empty_groups, uint64_t row_offset);
+int dist_gibbs_load_rows_dev(dist_gibbs_t * g, size_t n_rows,
+                             const uint32_t * const * values_dev,
+                             uint32_t * assign_packed_dev, int nonempty_groups,
+                             int empty_groups, uint64_t row_offset);
+/* multi-GPU: the statistics were built from local rows only; add the other
+ * shards' (dist_gibbs_stat_words() int32 words, all-reduced by the caller) */
+size_t dist_gibbs_stat_words(const dist_gibbs_t * g);
+int dist_gibbs_export_stats_dev(const dist_gibbs_t * g, int32_t * stats_dev);
+int dist_gibbs_import_stats_dev(dist_gibbs_t * g, const int32_t * stats_dev);
+
+/* one Gibbs pass over local rows [row_begin,row_end) in batches of
+ * batch_rows, single GPU */
+int dist_gibbs_sweep(dist_gibbs_t * g, size_t row_begin, size_t row_end,
+                     size_t batch_rows, uint32_t seed_state,
+                     uint64_t draw_base);
+/* the reference's sequential chain (batch of one row), advancing *rng_state
+ * one step per row */
+int dist_gibbs_sweep_sequential(dist_gibbs_t * g, size_t row_begin,
+                                size_t row_end, uint32_t * rng_state);
+/* the same pass in phases, for callers that exchange statistics between
+ * GPUs: sample -> moves_to_delta -> [all-reduce delta] -> apply_delta ->
+ * finish.  delta is dist_gibbs_stat_words() int32 words of device memory. */
+int dist_gibbs_batch_sample(dist_gibbs_t * g, size_t row_begin, size_t row_end,
+                            uint32_t seed_state, uint64_t draw_base);
+int dist_gibbs_batch_delta_dev(dist_gibbs_t * g, int32_t * delta_dev);
+int dist_gibbs_batch_apply_delta_dev(dist_gibbs_t * g,
+                                     const int32_t * delta_dev);
+int dist_gibbs_batch_apply_local(dist_gibbs_t * g);
+int dist_gibbs_batch_finish(dist_gibbs_t * g);
+
+/* batch-semantics scores of one resident row (length written to *size_out;
+ * scores_out needs dist_gibbs_group_count() floats) */
+int dist_gibbs_row_scores(dist_gibbs_t * g, size_t row, float * scores_out,
+                          size_t * size_out);
+/* score_values extension: scores[r * ld + k] for rows [row_begin,row_end)
+ * against the current state (no self-removal), device output */
+int dist_gibbs_score_rows_dev(dist_gibbs_t * g, size_t row_begin,
+                              size_t row_end, float * scores_dev, size_t ld);
+
+size_t dist_gibbs_group_count(const dist_gibbs_t * g);     /* counts().size() */
+size_t dist_gibbs_row_count(const dist_gibbs_t * g);
+int dist_gibbs_counts(const dist_gibbs_t * g, int * out);  /* driver counts() */
+int dist_gibbs_assignments(const dist_gibbs_t * g, uint32_t * global_out);
+int dist_gibbs_get_group(const dist_gibbs_t * g, int feature, size_t groupid,
+                         uint32_t * group_out);
+int dist_gibbs_packed_to_global(const dist_gibbs_t * g, uint32_t packed,
+                                uint32_t * global_out);
+int dist_gibbs_global_to_packed(const dist_gibbs_t * g, uint32_t global,
+                                uint32_t * packed_out);
+/* HIP-event time (ms) and launch count of the score+sample kernel since the
+ * last reset, measured on the engine's stream */
+int dist_gibbs_kernel_stats(dist_gibbs_t * g, double * ms_out,
+                            uint64_t * launches_out, uint64_t * rows_out,
+                            int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DISTRIBUTIONS_HIP_H */

@@ -1,0 +1,105 @@
+"""GPU parity of the batched row update against the oracle (bit-exact
+assignment indices, integer statistics and float statistics; scores to the
+tolerance stated in each test)."""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+import workloads
+
+pytestmark = pytest.mark.gpu
+
+
+def both(config, n, k, alpha, d, empty=1, dim=None, seed=workloads.SEED):
+    from distributions_amd import engine
+    osh, gsh, vals, assign = workloads.make(config, n, k, seed=seed, dim=dim)
+    orc = ol.OracleMixture(alpha, d, osh)
+    orc.init_from_assignments(vals, assign, k, empty)
+    gpu = engine.Gibbs(alpha, d, gsh)
+    gpu.load_rows(vals, assign, k, empty)
+    return orc, gpu
+
+
+def assert_same_state(orc, gpu, what=""):
+    assert len(gpu) == len(orc), what
+    np.testing.assert_array_equal(gpu.counts(), orc.counts(), err_msg=what)
+    got, want = gpu.assignments(), orc.assign
+    bad = np.nonzero(got != want)[0]
+    assert bad.size == 0, "%s first divergent row %d: gpu %d oracle %d" % (
+        what, bad[0], got[bad[0]], want[bad[0]])
+    for f in range(orc.F):
+        for g in range(len(orc)):
+            np.testing.assert_array_equal(
+                gpu.get_group(f, g), orc.get_group(f, g),
+                err_msg="%s feature %d group %d" % (what, f, g))
+
+
+CONFIGS = ["dd", "dd_skew", "bb", "gp", "nich", "gp_nich", "dpd", "dd_bb_gp"]
+
+
+@pytest.mark.parametrize("config", CONFIGS)
+def test_load_matches_oracle(config):
+    orc, gpu = both(config, 3000, 24, 1.0, 0.2)
+    assert_same_state(orc, gpu, "after load")
+
+
+@pytest.mark.parametrize("config", CONFIGS)
+def test_row_scores_match_oracle(config):
+    """scores[k] of a row in batch semantics; tolerance 0 ulp expected (same
+    float operations), asserted as bit equality with a 1e-6 relative fallback
+    report."""
+    orc, gpu = both(config, 2000, 16, 1.0, 0.1)
+    for row in [0, 1, 17, 999, 1999]:
+        g = int(ol.oracle().orc_mix_global_to_packed(orc.h, int(orc.assign[row])))
+        want = orc.row_scores(row, g)
+        got = gpu.row_scores(row)
+        assert got.shape == want.shape
+        np.testing.assert_allclose(got, want, rtol=1e-6, atol=0)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (
+            config, row, np.abs(got - want).max())
+
+
+@pytest.mark.parametrize("config", CONFIGS)
+@pytest.mark.parametrize("batch", [256, 1000, 4096])
+def test_batch_sweeps_bit_exact(config, batch):
+    n, k = 4096, 32
+    orc, gpu = both(config, n, k, 1.0, 0.2)
+    seed = 12345
+    st = ol.oracle().orc_rng_seed(seed)
+    for sweep in range(2):
+        base = sweep * n
+        for b in range(0, n, batch):
+            orc.gibbs_batch(b, min(n, b + batch), st, base)
+        gpu.sweep(0, n, batch, seed, draw_base=base)
+        assert_same_state(orc, gpu, "%s sweep %d batch %d" % (config, sweep, batch))
+
+
+@pytest.mark.parametrize("config", ["dd", "gp_nich", "bb"])
+def test_sequential_chain_bit_exact(config):
+    """batch of one row == the reference's sequential update."""
+    n, k = 300, 8
+    orc, gpu = both(config, n, k, 1.0, 0.2)
+    st = ol.oracle().orc_rng_seed(7)
+    st_o = orc.gibbs_sequential(0, n, st)
+    st_g = gpu.sweep_sequential(0, n, st)
+    assert st_o == st_g
+    assert_same_state(orc, gpu, config + " sequential")
+
+
+@pytest.mark.parametrize("config", ["dd", "gp_nich"])
+@pytest.mark.parametrize("empty", [1, 3])
+def test_group_creation_and_removal(config, empty):
+    """Many groups, few rows, large alpha: rows are alone in their group,
+    groups die and empty groups get filled (mixture.hpp:84-89,108-119)."""
+    n, k = 96, 48
+    orc, gpu = both(config, n, k, 20.0, 0.5, empty=empty)
+    seed = 99
+    st = ol.oracle().orc_rng_seed(seed)
+    for sweep in range(4):
+        for b in range(0, n, 16):
+            orc.gibbs_batch(b, b + 16, st, sweep * n)
+        gpu.sweep(0, n, 16, seed, draw_base=sweep * n)
+        assert_same_state(orc, gpu, "dynamic sweep %d" % sweep)
+    st2 = orc.gibbs_sequential(0, n, st)
+    assert gpu.sweep_sequential(0, n, st) == st2
+    assert_same_state(orc, gpu, "dynamic sequential")

@@ -1,0 +1,64 @@
+"""Seeded synthetic workloads shared by the parity tests and bench.py
+(SURVEY 8d): identical bytes for the oracle and the GPU."""
+import numpy as np
+
+import oracle_lib as ol
+from distributions_amd import engine
+
+SEED = 20240601
+
+
+def make(config, n, k, seed=SEED, dim=None):
+    """-> (oracle shareds, engine shareds, values per feature, assign_packed)"""
+    rng = np.random.default_rng(seed)
+    assign = (np.arange(n) % k).astype(np.uint32)
+    if config == "dd":
+        dim = dim or 16
+        vals = [rng.integers(0, dim, n).astype(np.uint32)]
+        osh = [ol.make_shared(ol.DD, alphas=[0.5] * dim)]
+        gsh = [engine.dd_shared([0.5] * dim)]
+    elif config == "dd_skew":
+        dim = dim or 16
+        p = 1.0 / np.arange(1, dim + 1) ** 1.1
+        vals = [rng.choice(dim, n, p=p / p.sum()).astype(np.uint32)]
+        alphas = [2.0 / (i + 1) for i in range(dim)]
+        osh = [ol.make_shared(ol.DD, alphas=alphas)]
+        gsh = [engine.dd_shared(alphas)]
+    elif config == "bb":
+        vals = [(rng.random(n) < 0.3).astype(np.uint32)]
+        osh = [ol.make_shared(ol.BB, alpha=0.5, beta=2.0)]
+        gsh = [engine.bb_shared(0.5, 2.0)]
+    elif config == "gp":
+        vals = [rng.poisson(5.0, n).astype(np.uint32)]
+        osh = [ol.make_shared(ol.GP, alpha=1.0, inv_beta=1.0)]
+        gsh = [engine.gp_shared(1.0, 1.0)]
+    elif config == "nich":
+        vals = [rng.normal(0, 1, n).astype(np.float32)]
+        osh = [ol.make_shared(ol.NICH, mu=0.0, kappa=1.0, sigmasq=1.0, nu=1.0)]
+        gsh = [engine.nich_shared(0.0, 1.0, 1.0, 1.0)]
+    elif config == "gp_nich":
+        vals = [rng.poisson(5.0, n).astype(np.uint32),
+                rng.normal(0, 1, n).astype(np.float32)]
+        osh = [ol.make_shared(ol.GP, alpha=1.0, inv_beta=1.0),
+               ol.make_shared(ol.NICH, mu=0.0, kappa=1.0, sigmasq=1.0, nu=1.0)]
+        gsh = [engine.gp_shared(1.0, 1.0),
+               engine.nich_shared(0.0, 1.0, 1.0, 1.0)]
+    elif config == "dpd":
+        dim = dim or 100
+        betas = np.full(dim, 1.0 / dim, np.float32)
+        vals = [rng.integers(0, dim, n).astype(np.uint32)]
+        osh = [ol.make_shared(ol.DPD, alpha=0.5, betas=betas, beta0=0.0)]
+        gsh = [engine.dpd_shared(0.5, betas, 0.0)]
+    elif config == "dd_bb_gp":
+        dim = dim or 8
+        vals = [rng.integers(0, dim, n).astype(np.uint32),
+                (rng.random(n) < 0.5).astype(np.uint32),
+                rng.poisson(3.0, n).astype(np.uint32)]
+        osh = [ol.make_shared(ol.DD, alphas=[0.5] * dim),
+               ol.make_shared(ol.BB, alpha=0.5, beta=2.0),
+               ol.make_shared(ol.GP, alpha=1.0, inv_beta=1.0)]
+        gsh = [engine.dd_shared([0.5] * dim), engine.bb_shared(0.5, 2.0),
+               engine.gp_shared(1.0, 1.0)]
+    else:
+        raise ValueError(config)
+    return osh, gsh, vals, assign
