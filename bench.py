@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""bench.py -- row-Gibbs-updates/s of the batched mixture row update.
+
+Workload (BASELINE.json configs[1], SURVEY 8d "C2"): DirichletDiscrete
+dim=256, alphas=0.5, K=1024 non-empty groups + 1 empty, N=10M rows per GPU,
+values iid uniform{0..255}, initial assignment i mod K, PitmanYor(alpha=1,
+d=0.2).  A step = one full Gibbs pass over the resident rows (self-remove,
+score all K groups, sample, add), in frozen sub-sweeps of --batch rows, with
+the statistics update, group-set normalisation and cache rebuild included.
+Rows are generated on the device (seeded) before the timed region.
+
+N > 1: one process per GPU (torch.distributed, backend nccl == RCCL); rows
+are sharded, weak scaling (N rows per GPU), one all-reduce of the integer
+statistic deltas per sub-sweep.
+
+Prints ONE JSON line (rank 0).  `roofline` prices the score+sample kernel
+(k_sweep_sample) by ALGORITHMIC bytes: (12*K + 12) B per row over
+its HIP-event duration on the launch stream.  `cpu_baseline` times the
+oracle's sequential chain (the reference loop restated, oracle/oracle.c) on a
+bounded row sample of the same workload, one host thread.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--rows", type=int, default=10_000_000,
+                    help="rows per GPU")
+    ap.add_argument("--groups", type=int, default=1024)
+    ap.add_argument("--dim", type=int, default=256)
+    ap.add_argument("--batch", type=int, default=1 << 20,
+                    help="rows per frozen sub-sweep (per GPU)")
+    ap.add_argument("--alpha", type=float, default=1.0)
+    ap.add_argument("--d", type=float, default=0.2)
+    ap.add_argument("--seed", type=int, default=20240601)
+    ap.add_argument("--cpu-rows", type=int, default=1_000_000,
+                    help="rows of the CPU-baseline sample (0 = skip)")
+    return ap.parse_args()
+
+
+def cpu_baseline(args):
+    """Oracle (port of the reference loop) on a bounded sample, 1 thread."""
+    import numpy as np
+    import oracle_lib as ol
+    n = min(args.cpu_rows, args.rows)
+    rng = np.random.default_rng(args.seed)
+    values = rng.integers(0, args.dim, n).astype(np.uint32)
+    assign = (np.arange(n) % args.groups).astype(np.uint32)
+    orc = ol.OracleMixture(args.alpha, args.d,
+                           [ol.make_shared(ol.DD, alphas=[0.5] * args.dim)])
+    orc.init_from_assignments([values], assign, args.groups, 1)
+    st = ol.oracle().orc_rng_seed(args.seed)
+    t0 = time.perf_counter()
+    orc.gibbs_sequential(0, n, st)
+    dt = time.perf_counter() - t0
+    return {
+        "value": n / dt,
+        "unit": "row-updates/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": "one sequential sweep over the first %d rows of the "
+                  "workload (K=%d, dim=%d), oracle/oracle.c -O3, %.1f s"
+                  % (n, args.groups, args.dim, dt),
+    }
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from distributions_amd import _core, engine
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    torch.cuda.set_device(local_rank)
+    _core.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    n = args.rows
+    k = args.groups
+    row_offset = rank * n
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(args.seed + rank)
+    values = torch.randint(0, args.dim, (n,), generator=gen, device=dev,
+                           dtype=torch.int32)
+    assign = (torch.arange(n, device=dev, dtype=torch.int64)
+              + row_offset).remainder(k).to(torch.int32)
+    g = engine.Gibbs(args.alpha, args.d, [engine.dd_shared([0.5] * args.dim)])
+    g.load_rows_torch([values], assign, k, 1, row_offset=row_offset)
+    sharded = engine.ShardedGibbs(g.core, n, row_offset, device=dev)
+    sharded.sync_initial_stats()
+    seed_state = _core.rng_seed(args.seed)
+
+    def step(i):
+        # every sweep draws a fresh stretch of the engine's stream
+        sharded.sweep(args.batch, seed_state, draw_base=i * n * world)
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    g.kernel_stats(reset=True)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    ms, launches, rows = g.kernel_stats()
+    total_rows = float(n) * world * args.steps
+    bytes_per_row = 12 * k + 12            # 4K (PY) + 2*4K (DD) + 12
+    if rank == 0:
+        out = {
+            "metric": "row-Gibbs-updates/sec (score+sample+suffstat) at "
+                      "N=10M, K=1024; 1/2/4/8 GPU",
+            "value": total_rows / dt,
+            "unit": "row-updates/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "DirichletDiscrete(dim=%d) N=%d rows/GPU K=%d+1 "
+                            "PitmanYor(alpha=%g,d=%g), frozen sub-sweeps of "
+                            "%d rows" % (args.dim, n, k, args.alpha, args.d,
+                                         args.batch),
+                "rows_per_gpu": n, "groups": k, "dim": args.dim,
+                "batch_rows": args.batch,
+                "parallelism": "rows sharded over %d GPU(s), all-reduce of "
+                               "statistic deltas per sub-sweep" % world,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "k_sweep_sample<DD>",
+                "achieved": (bytes_per_row * rows / max(launches, 1))
+                            / (1e-3 * ms / max(launches, 1)) / 1e9,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": (bytes_per_row * rows) / (1e-3 * ms) / 1e9
+                        / HBM_PEAK_GBS,
+                "traffic": None,
+                "algorithmic_bytes_per_row": bytes_per_row,
+                "rows_per_launch": rows / max(launches, 1),
+                "avg_launch_ms": ms / max(launches, 1),
+                "launches": launches,
+            },
+        }
+        if world == 1 and args.cpu_rows > 0:
+            out["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

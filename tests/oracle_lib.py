@@ -273,7 +273,7 @@ class OracleMixture(object):
 
     def get_group(self, f, g):
         s = self.shareds[f]
-        n = 1 + s.dim if s.kind in (DD, DPD) else 3
+        n = 1 + s.dim if s.kind in (DD, DPD) else (2 if s.kind == BB else 3)
         out = np.zeros(n, np.uint32)
         self.L.orc_mix_slave_get_group(self.h, f, g, out)
         return out
