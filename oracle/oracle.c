@@ -996,31 +996,40 @@ int orc_mix_batch_row_scores(const orc_mix * m, const uint32_t * x, uint32_t g,
     return Kl;
 }
 
-void orc_mix_gibbs_batch(orc_mix * m, size_t row_begin, size_t row_end,
-                         const uint32_t * const * values, uint32_t * assign,
-                         uint32_t seed_state, uint64_t draw_base) {
+/* ---- the batch in phases (what a multi-GPU driver interleaves with its
+ * all-reduce); orc_mix_gibbs_batch below is their composition -------------- */
+
+/* phase 1: score + sample every row against the frozen state.  Row i uses
+ * engine draw (draw_base + row_offset + i). */
+void orc_mix_batch_sample(const orc_mix * m, size_t row_begin, size_t row_end,
+                          const uint32_t * const * values,
+                          const uint32_t * assign, uint32_t seed_state,
+                          uint64_t draw_base, uint64_t row_offset,
+                          uint32_t * old_p, uint32_t * new_p) {
     unsigned saved = orc_ftz_enable();
     const int K = m->K;
-    const size_t B = row_end - row_begin;
     float * scores = malloc(sizeof(float) * (K + 1));
-    uint32_t * old_p = malloc(sizeof(uint32_t) * (B + 1));
-    uint32_t * new_p = malloc(sizeof(uint32_t) * (B + 1));
     uint32_t x[64];
-    /* phase 1: score + sample every row against the frozen state */
     for (size_t i = row_begin; i < row_end; ++i) {
         uint32_t g = orc_mix_global_to_packed(m, assign[i]);
         for (int fi = 0; fi < m->F; ++fi) x[fi] = values[fi][i];
         int Kl = orc_mix_batch_row_scores(m, x, g, scores);
-        uint32_t st = orc_rng_jump(seed_state, draw_base + i);
+        uint32_t st = orc_rng_jump(seed_state, draw_base + row_offset + i);
         float u = orc_sample_unif01(&st);
         uint32_t g2 = (uint32_t)orc_sample_from_scores_u(Kl, scores, u);
         if (Kl != K && g2 == g) g2 = (uint32_t)(K - 1); /* slot g held K-1 */
         old_p[i - row_begin] = g;
         new_p[i - row_begin] = g2;
     }
-    /* phase 2: apply all moves in row order (remove, then add, per row) */
-    int32_t * snap_counts = malloc(sizeof(int32_t) * K);
-    memcpy(snap_counts, m->counts, sizeof(int32_t) * K);
+    free(scores);
+    orc_ftz_restore(saved);
+}
+
+/* phase 2: apply the moves in row order (remove, then add, per row) */
+void orc_mix_apply_moves(orc_mix * m, size_t row_begin, size_t row_end,
+                         const uint32_t * const * values, uint32_t * assign,
+                         const uint32_t * old_p, const uint32_t * new_p) {
+    unsigned saved = orc_ftz_enable();
     for (size_t i = row_begin; i < row_end; ++i) {
         uint32_t g = old_p[i - row_begin], g2 = new_p[i - row_begin];
         m->counts[g] -= 1;
@@ -1031,9 +1040,48 @@ void orc_mix_gibbs_batch(orc_mix * m, size_t row_begin, size_t row_end,
         }
         assign[i] = m->p2g[g2];
     }
-    /* phase 3: normalise the group set.  Groups that lost their last member
-     * are swap-removed in descending slot order; one new empty group is
-     * appended for every previously empty group that gained members. */
+    orc_ftz_restore(saved);
+}
+
+/* integer statistics as words: counts[K] | per feature i0[K] i1[K]
+ * (categorical: cnt[K][dim]) -- the layout of dist_gibbs_stat_words() */
+size_t orc_mix_stat_words(const orc_mix * m) {
+    size_t n = (size_t)m->K;
+    for (int fi = 0; fi < m->F; ++fi)
+        n += 2 * (size_t)m->K
+           + (is_cat(m->f[fi].sh.kind) ? (size_t)m->K * m->f[fi].sh.dim : 0);
+    return n;
+}
+static void stat_copy(orc_mix * m, int32_t * w, int to_words) {
+    size_t K = (size_t)m->K;
+#define ORC_CP(live, n) do {                          \
+        if (to_words) { memcpy(w, live, 4 * (n)); }       \
+        else { memcpy(live, w, 4 * (n)); }                \
+        w += (n);                                         \
+    } while (0)
+    ORC_CP(m->counts, K);
+    for (int fi = 0; fi < m->F; ++fi) {
+        feat * f = &m->f[fi];
+        ORC_CP(f->i0, K);
+        ORC_CP(f->i1, K);
+        if (is_cat(f->sh.kind)) ORC_CP(f->cnt, K * (size_t)f->sh.dim);
+    }
+#undef ORC_CP
+}
+void orc_mix_export_stats(const orc_mix * m, int32_t * words) {
+    stat_copy((orc_mix *)m, words, 1);
+}
+void orc_mix_import_stats(orc_mix * m, const int32_t * words) {
+    stat_copy(m, (int32_t *)words, 0);
+}
+
+/* phases 3 + 4: normalise the group set against the counts at batch entry
+ * and rebuild the caches.  Groups that lost their last member are
+ * swap-removed in descending slot order; one new empty group is appended for
+ * every previously empty group that gained members. */
+void orc_mix_batch_finish(orc_mix * m, const int32_t * snap_counts) {
+    unsigned saved = orc_ftz_enable();
+    const int K = m->K;
     int created = 0;
     for (int k = 0; k < K; ++k)
         if (snap_counts[k] == 0 && m->counts[k] > 0) created += 1;
@@ -1058,14 +1106,26 @@ void orc_mix_gibbs_batch(orc_mix * m, size_t row_begin, size_t row_end,
         }
         orc_mix_tracker_add_group(m);
     }
-    /* phase 4: caches are pure functions of the statistics */
-    {
-        int * counts = malloc(sizeof(int) * m->K);
-        memcpy(counts, m->counts, sizeof(int) * m->K);
-        orc_mix_driver_init(m, counts, m->K);
-        free(counts);
-    }
+    /* caches are pure functions of the statistics */
+    int * counts = malloc(sizeof(int) * (m->K + 1));
+    memcpy(counts, m->counts, sizeof(int) * m->K);
+    orc_mix_driver_init(m, counts, m->K);
+    free(counts);
     for (int fi = 0; fi < m->F; ++fi) cache_update_all(&m->f[fi]);
-    free(snap_counts); free(scores); free(old_p); free(new_p);
     orc_ftz_restore(saved);
+}
+
+void orc_mix_gibbs_batch(orc_mix * m, size_t row_begin, size_t row_end,
+                         const uint32_t * const * values, uint32_t * assign,
+                         uint32_t seed_state, uint64_t draw_base) {
+    const size_t B = row_end - row_begin;
+    uint32_t * old_p = malloc(sizeof(uint32_t) * (B + 1));
+    uint32_t * new_p = malloc(sizeof(uint32_t) * (B + 1));
+    int32_t * snap_counts = malloc(sizeof(int32_t) * (m->K + 1));
+    memcpy(snap_counts, m->counts, sizeof(int32_t) * m->K);
+    orc_mix_batch_sample(m, row_begin, row_end, values, assign, seed_state,
+                         draw_base, 0, old_p, new_p);
+    orc_mix_apply_moves(m, row_begin, row_end, values, assign, old_p, new_p);
+    orc_mix_batch_finish(m, snap_counts);
+    free(snap_counts); free(old_p); free(new_p);
 }

@@ -166,6 +166,21 @@ void orc_mix_gibbs_batch(orc_mix * m, size_t row_begin, size_t row_end,
                          const uint32_t * const * values,
                          uint32_t * assign_global, uint32_t seed_state,
                          uint64_t draw_base);
+/* the same batch in phases (multi-GPU drivers put an all-reduce of the
+ * statistic deltas between apply and finish) */
+void orc_mix_batch_sample(const orc_mix * m, size_t row_begin, size_t row_end,
+                          const uint32_t * const * values,
+                          const uint32_t * assign_global, uint32_t seed_state,
+                          uint64_t draw_base, uint64_t row_offset,
+                          uint32_t * old_packed_out, uint32_t * new_packed_out);
+void orc_mix_apply_moves(orc_mix * m, size_t row_begin, size_t row_end,
+                         const uint32_t * const * values,
+                         uint32_t * assign_global, const uint32_t * old_packed,
+                         const uint32_t * new_packed);
+size_t orc_mix_stat_words(const orc_mix * m);
+void orc_mix_export_stats(const orc_mix * m, int32_t * words);
+void orc_mix_import_stats(orc_mix * m, const int32_t * words);
+void orc_mix_batch_finish(orc_mix * m, const int32_t * counts_at_entry);
 /* scores of one row in batch semantics (for score-tolerance tests);
  * returns the local group count K' (K or K-1) */
 int orc_mix_batch_row_scores(const orc_mix * m, const uint32_t * row_values,

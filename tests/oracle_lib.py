@@ -277,3 +277,91 @@ class OracleMixture(object):
         out = np.zeros(n, np.uint32)
         self.L.orc_mix_slave_get_group(self.h, f, g, out)
         return out
+
+
+def _phase_sigs(L):
+    sz = ctypes.c_size_t
+    vp = ctypes.c_void_p
+    pp = ctypes.POINTER(ctypes.c_void_p)
+    L.orc_mix_batch_sample.restype = None
+    L.orc_mix_batch_sample.argtypes = [vp, sz, sz, pp, c_u32p, ctypes.c_uint32,
+                                       ctypes.c_uint64, ctypes.c_uint64,
+                                       c_u32p, c_u32p]
+    L.orc_mix_apply_moves.restype = None
+    L.orc_mix_apply_moves.argtypes = [vp, sz, sz, pp, c_u32p, c_u32p, c_u32p]
+    L.orc_mix_stat_words.restype = sz
+    L.orc_mix_stat_words.argtypes = [vp]
+    L.orc_mix_export_stats.restype = None
+    L.orc_mix_export_stats.argtypes = [vp, c_i32p]
+    L.orc_mix_import_stats.restype = None
+    L.orc_mix_import_stats.argtypes = [vp, c_i32p]
+    L.orc_mix_batch_finish.restype = None
+    L.orc_mix_batch_finish.argtypes = [vp, c_i32p]
+
+
+class OracleBackend(object):
+    """CPU stand-in with the interface distributions_amd.engine.ShardedGibbs
+    drives (GibbsEngine's batch_* / *_stats_dev methods), built on the
+    oracle.  TESTS ONLY: lets the multi-rank driver run under gloo without a
+    GPU.  "device pointers" are addresses of CPU torch tensors here."""
+
+    def __init__(self, mix, row_offset):
+        self.m = mix
+        self.L = mix.L
+        _phase_sigs(self.L)
+        self.row_offset = row_offset
+        self._open = None
+
+    @staticmethod
+    def _view(ptr, n):
+        buf = (ctypes.c_int32 * n).from_address(ptr)
+        return np.frombuffer(buf, dtype=np.int32)
+
+    def stat_words(self):
+        return self.L.orc_mix_stat_words(self.m.h)
+
+    def export_stats_dev(self, ptr):
+        w = np.zeros(self.stat_words(), np.int32)
+        self.L.orc_mix_export_stats(self.m.h, w)
+        self._view(ptr, w.size)[:] = w
+
+    def import_stats_dev(self, ptr):
+        w = np.ascontiguousarray(self._view(ptr, self.stat_words()).copy())
+        self.L.orc_mix_import_stats(self.m.h, w)
+        self.L.orc_mix_batch_finish(self.m.h, self.m.counts())
+
+    def batch_sample(self, r0, r1, seed_state, draw_base=0):
+        n = r1 - r0
+        old = np.zeros(n + 1, np.uint32)
+        new = np.zeros(n + 1, np.uint32)
+        self.L.orc_mix_batch_sample(self.m.h, r0, r1, self.m._vals,
+                                    self.m.assign, seed_state, draw_base,
+                                    self.row_offset, old, new)
+        self._open = (r0, r1, old, new, self.m.counts().copy())
+
+    def _snapshot(self):
+        w = np.zeros(self.stat_words(), np.int32)
+        self.L.orc_mix_export_stats(self.m.h, w)
+        return w
+
+    def batch_apply_local(self):
+        r0, r1, old, new, _ = self._open
+        self.L.orc_mix_apply_moves(self.m.h, r0, r1, self.m._vals,
+                                   self.m.assign, old, new)
+
+    def batch_delta_dev(self, ptr):
+        before = self._snapshot()
+        self.batch_apply_local()
+        after = self._snapshot()
+        self.L.orc_mix_import_stats(self.m.h, before)   # undo: delta only
+        self._view(ptr, before.size)[:] = after - before
+
+    def batch_apply_delta_dev(self, ptr):
+        cur = self._snapshot()
+        cur += self._view(ptr, cur.size)
+        self.L.orc_mix_import_stats(self.m.h, np.ascontiguousarray(cur))
+
+    def batch_finish(self):
+        snap = np.ascontiguousarray(self._open[4], np.int32)
+        self.L.orc_mix_batch_finish(self.m.h, snap)
+        self._open = None

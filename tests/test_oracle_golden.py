@@ -1,0 +1,180 @@
+"""The oracle against the REAL reference: golden vectors produced by
+oracle/_ref (tests/golden/make_goldens.py) and, when oracle/_ref is present,
+live comparison on larger random inputs.  Everything here is bit-exact."""
+import ctypes
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(GOLD, name))
+
+
+def bits(x):
+    return np.ascontiguousarray(x, np.float32).view(np.uint32)
+
+
+@pytest.mark.parametrize("name", ["fast_log", "fast_exp", "fast_lgamma",
+                                  "fast_lgamma_nu", "fast_log_factorial"])
+def test_special_functions_match_reference_goldens(name):
+    g = load("special_functions.npz")
+    x = np.ascontiguousarray(g[name + "_in"])
+    want = g[name + "_out"]
+    got = np.zeros(x.size, np.float32)
+    getattr(ol.oracle(), "orc_vec_" + name)(x.size, x, got)
+    bad = np.nonzero(bits(got) != want)[0]
+    assert bad.size == 0, (name, x[bad[:5]], got[bad[:5]])
+
+
+@pytest.mark.parametrize("name,lo,hi", [("fast_log", 1e-30, 1e30),
+                                        ("fast_exp", None, None),
+                                        ("fast_lgamma", 2.5, 4e9),
+                                        ("fast_lgamma_nu", 0.0625, 4e9)])
+def test_special_functions_match_live_reference(name, lo, hi):
+    R = ol.ref()
+    if R is None:
+        pytest.skip("oracle/_ref not built (no /root/reference)")
+    rng = np.random.default_rng(11)
+    if name == "fast_exp":
+        x = rng.uniform(-100, 10, 400000).astype(np.float32)
+    else:
+        x = np.exp(rng.uniform(np.log(lo), np.log(hi), 400000)).astype(
+            np.float32)
+    a = np.zeros_like(x)
+    b = np.zeros_like(x)
+    getattr(ol.oracle(), "orc_vec_" + name)(x.size, x, a)
+    getattr(R, "ref_" + name)(x.size, x, b)
+    assert np.array_equal(bits(a), bits(b))
+
+
+def test_tables_are_the_reference_build_tables():
+    """ref_tables.h == what libref.so holds; and the libmvec effect: the
+    source formulas with scalar libm differ from the built tables in the last
+    bit for a minority of entries (why the tables are pinned as data)."""
+    L = ol.oracle()
+    x = (1.0 + np.arange(16384) / 16384.0).astype(np.float32)
+    got = np.zeros_like(x)
+    L.orc_vec_fast_log(x.size, x, got)
+    formula = np.zeros(16384, np.float32)
+    L.orc_formula_log_table(formula)
+    scalar = (formula * np.float32(0.69314718055994529)).astype(np.float32)
+    diff = np.abs(bits(scalar).astype(np.int64) - bits(got).astype(np.int64))
+    assert diff.max() <= 4
+    assert 0 < (diff != 0).mean() < 0.5
+    R = ol.ref()
+    if R is not None:
+        t = np.zeros(16384, np.float32)
+        R.ref_log_table(t)
+        want = (t * np.float32(0.69314718055994529)).astype(np.float32)
+        assert np.array_equal(bits(want), bits(got))
+    etab = np.zeros(1024, np.uint32)
+    L.orc_formula_exp_table(etab)
+    one = np.zeros(1, np.float32)
+    L.orc_vec_fast_exp(1, np.zeros(1, np.float32), one)
+    assert one[0] == 1.0
+
+
+def test_ref_tables_header_hashes():
+    """the product's copy of the tables is byte-identical to the oracle's"""
+    root = os.path.dirname(GOLD[:-len("/golden")])
+    a = open(os.path.join(root, "oracle", "ref_tables.h")).read()
+    b = open(os.path.join(root, "distributions_amd", "csrc",
+                          "ref_tables.h")).read()
+    pa = [l for l in a.splitlines() if l.startswith(("  0x", "// sha256"))]
+    pb = [l for l in b.splitlines() if l.startswith(("  0x", "// sha256"))]
+    assert pa == pb and len(pa) > 2000
+
+
+def test_vector_math_matches_reference_goldens():
+    g = load("vector_math.npz")
+    L = ol.oracle()
+    for n in [1, 3, 4, 7, 64, 1000]:
+        io, a, b = (np.ascontiguousarray(g["n%d_%s" % (n, k)])
+                    for k in ("io", "a", "b"))
+        r = io.copy()
+        L.orc_vector_add_subtract(n, r, a, b)
+        assert np.array_equal(bits(r), g["n%d_add_subtract" % n])
+        r = io.copy()
+        L.orc_vector_add_subtract_scalar(n, r, 1.2345, b)
+        assert np.array_equal(bits(r), g["n%d_add_subtract_scalar" % n])
+        r = io.copy()
+        L.orc_vector_add(n, r, a)
+        assert np.array_equal(bits(r), g["n%d_add" % n])
+        assert L.orc_vector_max(n, io) == g["n%d_max" % n][0]
+
+
+def test_driver_and_tracker_match_reference_goldens():
+    """MixtureDriver (mixture.hpp:48-163) and MixtureIdTracker (:460-521):
+    same return flags and same state after every step of the recorded
+    script."""
+    g = load("driver_tracker.npz")
+    L = ol.oracle()
+    for case in range(2):
+        counts = np.ascontiguousarray(g["case%d_counts" % case], np.int32)
+        m = ol.OracleMixture(1.0, 0.1, [])
+        L.orc_mix_driver_init(m.h, counts, counts.size)
+        L.orc_mix_tracker_init(m.h, counts.size)
+        for (op, grp), want in zip(g["case%d_script" % case],
+                                   g["case%d_trace" % case]):
+            if op == 1:
+                flag = L.orc_mix_driver_add_value(m.h, int(grp))
+                if flag:
+                    L.orc_mix_tracker_add_group(m.h)
+            else:
+                flag = L.orc_mix_driver_remove_value(m.h, int(grp))
+                if flag:
+                    L.orc_mix_tracker_remove_group(m.h, int(grp))
+            size = len(m)
+            cur = m.counts()
+            p2g = [L.orc_mix_packed_to_global(m.h, i) for i in range(size)]
+            got = (flag, size, L.orc_mix_sample_size(m.h),
+                   L.orc_mix_empty_count(m.h),
+                   int(np.dot(cur, np.arange(1, size + 1)) % 1000003),
+                   int(np.dot(p2g, np.arange(1, size + 1)) % 1000003))
+            assert got == tuple(int(v) for v in want)
+            for i, gl in enumerate(p2g):
+                assert L.orc_mix_global_to_packed(m.h, gl) == i
+
+
+def test_rng_matches_libstdcxx_goldens():
+    """rng_t = std::default_random_engine, sample_unif01 =
+    uniform_real_distribution<float>(0,1): raw outputs and u bit patterns."""
+    g = load("rng_libstdcxx.npz")
+    L = ol.oracle()
+    for seed in g["seeds"]:
+        st = ctypes.c_uint32(L.orc_rng_seed(int(seed)))
+        st2 = ctypes.c_uint32(st.value)
+        raw = [L.orc_rng_next(ctypes.byref(st)) for _ in range(64)]
+        u = [L.orc_sample_unif01(ctypes.byref(st2)) for _ in range(64)]
+        assert np.array_equal(np.array(raw, np.uint32), g["raw_%d" % seed])
+        assert np.array_equal(bits(np.array(u, np.float32)), g["u_%d" % seed])
+    # the values recorded from the compiled reference in SURVEY.md 8c
+    st = ctypes.c_uint32(L.orc_rng_seed(1))
+    assert [L.orc_rng_next(ctypes.byref(st)) for _ in range(4)] == [
+        16807, 282475249, 1622650073, 984943658]
+    st = ctypes.c_uint32(L.orc_rng_seed(1))
+    u = np.array([L.orc_sample_unif01(ctypes.byref(st)) for _ in range(4)],
+                 np.float32)
+    assert [hex(v) for v in bits(u)] == ["0x37034c00", "0x3e06b1d8",
+                                         "0x3f416f5a", "0x3eead431"]
+
+
+def test_rng_jump_ahead():
+    L = ol.oracle()
+    for seed in [1, 12345, 2147483646]:
+        s0 = L.orc_rng_seed(seed)
+        st = ctypes.c_uint32(s0)
+        for j in range(1, 200):
+            x = L.orc_rng_next(ctypes.byref(st))
+            assert L.orc_rng_jump(s0, j) == x
+    s0 = L.orc_rng_seed(99)
+    a = L.orc_rng_jump(s0, 10 ** 12 + 7)
+    b = L.orc_rng_jump(L.orc_rng_jump(s0, 10 ** 12), 7)
+    assert a == b

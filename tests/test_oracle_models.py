@@ -1,0 +1,293 @@
+"""The parts of the oracle that cannot be compared with a compiled reference
+here (random.hpp needs Eigen): pinned by the reference's OWN tests for this
+path, restated, and by an independent float64 evaluation.
+
+  test_mixture_score            distributions/tests/test_models.py:537-594
+  test_mixture_runs             distributions/tests/test_models.py:498-534
+  test_py_mixture_matches_...   distributions/tests/test_clustering.py:242-327
+  test_sample_discrete_known    distributions/tests/test_random.py:224-247
+  test_log_sum_exp              distributions/tests/test_random.py:213-221
+  test_scores_sampler_gof       distributions/tests/test_random.py:201-210
+EXAMPLES are the lp modules' (lp/models/dd.pyx:35-48, bb.pyx:35-44,
+gp.pyx:35-40, nich.pyx:35-40, dpd.pyx:37-66; lp/clustering.pyx:211-217).
+"""
+import ctypes
+
+import numpy as np
+import pytest
+from scipy import special, stats
+
+import oracle_lib as ol
+
+TOL = 1e-3   # distributions/tests/util.py:42
+
+
+def assert_close(a, b, tol=TOL, msg=""):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    assert np.all(np.abs(a - b) <= tol * (1.0 + np.abs(a) + np.abs(b))), (
+        msg, a, b)
+
+
+EXAMPLES = [
+    ("dd4", ol.DD, dict(alphas=[0.5, 0.5, 0.5, 0.5]), [0, 1, 0, 2, 0, 1, 0]),
+    ("dd2", ol.DD, dict(alphas=[1.0, 4.0]), [0, 1, 1, 1, 1, 0, 1]),
+    ("dd20", ol.DD, dict(alphas=[2.0 / n for n in range(1, 21)]),
+     list(range(20))),
+    ("bb", ol.BB, dict(alpha=0.5, beta=2.0), [False, False, True, False, True,
+                                              True, False, False]),
+    ("bb2", ol.BB, dict(alpha=10.5, beta=0.5), [False] * 9),
+    ("gp", ol.GP, dict(alpha=1.0, inv_beta=1.0), [0, 1, 2, 3, 4, 5, 6, 7, 8]),
+    ("gp2", ol.GP, dict(alpha=3.0, inv_beta=0.25), [2, 1, 0, 9, 70, 3]),
+    ("nich", ol.NICH, dict(mu=0.0, kappa=1.0, sigmasq=1.0, nu=1.0),
+     [-4.0, -2.0, 0.0, 1.0, 2.0, 3.0, 5.0]),
+    ("nich2", ol.NICH, dict(mu=1.5, kappa=0.3, sigmasq=2.5, nu=4.0),
+     [0.25, -1.5, 3.0, 3.25, 100.0]),
+    ("dpd", ol.DPD, dict(alpha=0.5, betas=[0.25] * 4, beta0=0.0),
+     [0, 1, 0, 2, 0, 1, 0, 3]),
+]
+
+
+def words(kind, value):
+    return int(ol.value_words(kind, [value])[0])
+
+
+def float64_score(kind, kw, group_values, value):
+    """log predictive density of `value` given the group's values, in float64
+    (what the dbg flavour computes with scipy)."""
+    v = np.asarray(group_values, np.float64)
+    n = len(v)
+    if kind == ol.DD:
+        a = np.asarray(kw["alphas"], np.float64)
+        c = np.bincount(np.asarray(group_values, int), minlength=len(a))
+        return np.log((a[value] + c[value]) / (a.sum() + n))
+    if kind == ol.DPD:
+        b = np.asarray(kw["betas"], np.float64) * kw["alpha"]
+        c = np.bincount(np.asarray(group_values, int), minlength=len(b))
+        return np.log((b[value] + c[value]) / (kw["alpha"] + n))
+    if kind == ol.BB:
+        h = v.sum()
+        a, b = kw["alpha"] + h, kw["beta"] + n - h
+        return np.log((a if value else b) / (a + b))
+    if kind == ol.GP:
+        a = kw["alpha"] + v.sum()
+        ib = kw["inv_beta"] + n
+        # negative binomial predictive
+        return (special.gammaln(a + value) - special.gammaln(a)
+                - special.gammaln(value + 1) + a * np.log(ib / (ib + 1.0))
+                - value * np.log(ib + 1.0))
+    if kind == ol.NICH:
+        mu, kappa, sigmasq, nu = (kw["mu"], kw["kappa"], kw["sigmasq"],
+                                  kw["nu"])
+        mean = v.mean() if n else 0.0
+        ctv = ((v - mean) ** 2).sum() if n else 0.0
+        kn = kappa + n
+        mun = (kappa * mu + mean * n) / kn
+        nun = nu + n
+        sn = (nu * sigmasq + ctv + n * kappa * (mu - mean) ** 2 / kn) / nun
+        scale = np.sqrt(sn * (kn + 1.0) / kn)
+        return stats.t.logpdf(value, nun, loc=mun, scale=scale)
+    raise ValueError(kind)
+
+
+@pytest.mark.parametrize("name,kind,kw,values", EXAMPLES)
+def test_mixture_score(name, kind, kw, values):
+    """Mixture.score_value (accumulating, vectorised caches) ==
+    Group.score_value per group (Scorer) == float64, after init, after every
+    add and every remove."""
+    L = ol.oracle()
+    sh = ol.make_shared(kind, **kw)
+    m = ol.OracleMixture(1.0, 0.0, [sh])
+    members = [[v] for v in values]
+    for v in values:
+        L.orc_mix_slave_append_empty(m.h, 0)
+        L.orc_mix_slave_group_add_value(m.h, 0, len(m_groups(m)) - 1,
+                                        words(kind, v))
+    L.orc_mix_slave_init(m.h, 0)
+    rng = np.random.default_rng(0)
+
+    def check(value):
+        k = L.orc_mix_slave_size(m.h, 0)
+        expected = [L.orc_group_score_value(ctypes.byref(sh),
+                                            m.get_group(0, g),
+                                            words(kind, value))
+                    for g in range(k)]
+        noise = rng.normal(size=k).astype(np.float32)
+        actual = noise.copy()
+        L.orc_mix_slave_score_value(m.h, 0, words(kind, value), actual)
+        actual = actual - noise
+        assert_close(actual, expected, msg="score_value")
+        another = [L.orc_mix_slave_score_value_group(m.h, 0, g,
+                                                     words(kind, value))
+                   for g in range(k)]
+        assert_close(another, expected, msg="score_value_group")
+        f64 = [float64_score(kind, kw, members[g], value) for g in range(k)]
+        assert_close(expected, f64, tol=2e-3, msg="float64 " + name)
+        return actual
+
+    for v in values:
+        check(v)
+    placed = []
+    for v in values:
+        scores = check(v)
+        p = np.exp(scores - scores.max())
+        g = int(rng.choice(len(p), p=p / p.sum()))
+        L.orc_mix_slave_add_value(m.h, 0, g, words(kind, v))
+        members[g].append(v)
+        placed.append(g)
+    for v, g in zip(values, placed):
+        L.orc_mix_slave_remove_value(m.h, 0, g, words(kind, v))
+        members[g].remove(v)
+        check(v)
+
+
+def m_groups(m):
+    return range(ol.oracle().orc_mix_slave_size(m.h, 0))
+
+
+@pytest.mark.parametrize("name,kind,kw,values", EXAMPLES)
+def test_mixture_runs(name, kind, kw, values):
+    L = ol.oracle()
+    sh = ol.make_shared(kind, **kw)
+    m = ol.OracleMixture(1.0, 0.0, [sh])
+    for v in values:
+        L.orc_mix_slave_append_empty(m.h, 0)
+        L.orc_mix_slave_group_add_value(m.h, 0, len(m_groups(m)) - 1,
+                                        words(kind, v))
+    L.orc_mix_slave_init(m.h, 0)
+    st = ctypes.c_uint32(L.orc_rng_seed(0))
+    placed = []
+    for v in values:
+        scores = np.zeros(len(m_groups(m)), np.float32)
+        L.orc_mix_slave_score_value(m.h, 0, words(kind, v), scores)
+        g = L.orc_sample_from_scores_overwrite(ctypes.byref(st), scores.size,
+                                               scores)
+        L.orc_mix_slave_add_value(m.h, 0, g, words(kind, v))
+        placed.append(g)
+    L.orc_mix_slave_add_group(m.h, 0)
+    assert len(m_groups(m)) == len(values) + 1
+    for v, g in zip(values, placed):
+        L.orc_mix_slave_remove_value(m.h, 0, g, words(kind, v))
+    L.orc_mix_slave_remove_group(m.h, 0, 0)
+    L.orc_mix_slave_remove_group(m.h, 0, len(m_groups(m)) - 1)
+    assert len(m_groups(m)) == len(values) - 1
+
+
+PY_EXAMPLES = [(1.0, 0.0), (1.0, 0.1), (1.0, 0.9), (10.0, 0.1), (0.1, 0.1)]
+
+
+@pytest.mark.parametrize("alpha,d", PY_EXAMPLES)
+@pytest.mark.parametrize("empty_group_count", [1, 10])
+def test_py_mixture_matches_score_add_value(alpha, d, empty_group_count):
+    L = ol.oracle()
+    rng = np.random.default_rng(5)
+    nonempty = list(rng.integers(1, 30, 12))
+    counts = nonempty + [0] * empty_group_count
+    rng.shuffle(counts)
+    counts = [int(c) for c in counts]
+    m = ol.OracleMixture(alpha, d, [])
+    L.orc_mix_driver_init(m.h, np.array(counts, np.int32), len(counts))
+    L.orc_mix_tracker_init(m.h, len(counts))
+
+    def check():
+        assert L.orc_mix_empty_count(m.h) == empty_group_count
+        assert list(m.counts()) == counts
+        n = sum(counts)
+        ne = len(counts) - empty_group_count
+        expected = [L.orc_py_score_add_value(alpha, d, c, ne, n,
+                                             empty_group_count)
+                    for c in counts]
+        actual = rng.normal(size=len(counts)).astype(np.float32)
+        L.orc_mix_driver_score_value(m.h, actual)   # overwrites
+        assert_close(actual, expected)
+        # float64 Pitman-Yor predictive
+        f64 = [np.log((c - d) / (n + alpha)) if c else
+               np.log((alpha + d * ne) / ((n + alpha) * empty_group_count))
+               for c in counts]
+        assert_close(actual, f64, tol=2e-3)
+        return actual
+
+    check()
+    placed = []
+    for _ in range(200):
+        scores = check()
+        p = np.exp(scores - scores.max())
+        g = int(rng.choice(len(p), p=p / p.sum()))
+        expected_added = counts[g] == 0
+        counts[g] += 1
+        assert bool(L.orc_mix_driver_add_value(m.h, g)) == expected_added
+        placed.append(L.orc_mix_packed_to_global(m.h, g))
+        if expected_added:
+            L.orc_mix_tracker_add_group(m.h)
+            counts.append(0)
+    for gl in placed:
+        g = L.orc_mix_global_to_packed(m.h, gl)
+        counts[g] -= 1
+        expected_removed = counts[g] == 0
+        assert bool(L.orc_mix_driver_remove_value(m.h, g)) == expected_removed
+        if expected_removed:
+            L.orc_mix_tracker_remove_group(m.h, g)
+            back = counts.pop()
+            if g < len(counts):
+                counts[g] = back
+        check()
+
+
+def test_sample_discrete_known_answers():
+    L = ol.oracle()
+    st = ctypes.c_uint32(L.orc_rng_seed(0))
+    for probs, want in [([.5], 0), ([1.], 0), ([1e-3], 0),
+                        ([1 - 1e-3, 1e-3], 0), ([1e-3, 1 - 1e-3], 1)]:
+        p = np.array(probs, np.float32)
+        assert L.orc_sample_discrete(ctypes.byref(st), p.size, p) == want
+
+
+def test_sample_from_scores_recorded_probe():
+    """scores {-1,-2.5,.25,-.75,-3}, seed 1 -> 0 0 2 2 2 2 0 2
+    (recorded from the compiled reference)"""
+    L = ol.oracle()
+    st = ctypes.c_uint32(L.orc_rng_seed(1))
+    got = []
+    for _ in range(8):
+        s = np.array([-1, -2.5, .25, -.75, -3], np.float32)
+        got.append(L.orc_sample_from_scores_overwrite(ctypes.byref(st), 5, s))
+    assert got == [0, 0, 2, 2, 2, 2, 0, 2]
+
+
+def test_log_sum_exp():
+    L = ol.oracle()
+    rng = np.random.default_rng(1)
+    for size in range(20):
+        s = rng.normal(size=size).astype(np.float32)
+        want = np.logaddexp.reduce(s.astype(np.float64)) if size else 0.0
+        assert_close(L.orc_log_sum_exp(size, np.ascontiguousarray(s)), want)
+
+
+def test_scores_sampler_goodness_of_fit():
+    L = ol.oracle()
+    rng = np.random.default_rng(2)
+    st = ctypes.c_uint32(L.orc_rng_seed(2))
+    for size in [1, 2, 5, 30]:
+        scores = rng.normal(size=size).astype(np.float32) * 2
+        p = np.exp(scores.astype(np.float64) - scores.max())
+        p /= p.sum()
+        n = 20000
+        hist = np.zeros(size)
+        for _ in range(n):
+            s = scores.copy()
+            hist[L.orc_sample_from_scores_overwrite(ctypes.byref(st), size,
+                                                    s)] += 1
+        if size > 1:
+            chi2 = ((hist - n * p) ** 2 / (n * p)).sum()
+            assert stats.chi2.sf(chi2, size - 1) > 1e-4
+
+
+def test_fast_exp_flushes_like_the_reference_build():
+    """FTZ/DAZ: exp(-88) has a zero exponent field in fmath's scale factor,
+    which the -ffast-math build treats as zero."""
+    L = ol.oracle()
+    assert L.orc_fast_exp(-88.0) == 0.0
+    assert L.orc_fast_exp(-87.0) > 0.0
+    s = np.array([0.0, -100.0, -88.0, -50.0], np.float32)
+    total = L.orc_scores_to_likelihoods(4, s)
+    assert s[0] == 1.0 and s[1] == 0.0 and s[2] == 0.0 and total >= 1.0

@@ -1,0 +1,100 @@
+"""The multi-rank driver (distributions_amd.engine.ShardedGibbs) under gloo,
+world_size 2, on CPU.  The per-rank compute object is the oracle stand-in
+(oracle_lib.OracleBackend): this exercises row sharding, the statistic-delta
+all-reduce, lock-step normalisation and the global draw indexing -- not the
+HIP kernels (those are covered by the -m gpu tests)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+N, K, BATCH, SWEEPS, SEED = 2400, 12, 300, 2, 4242
+
+
+def make_rows():
+    rng = np.random.default_rng(7)
+    values = rng.integers(0, 8, N).astype(np.uint32)
+    assign = (np.arange(N) % K).astype(np.uint32)
+    return values, assign
+
+
+def make_mix(values, assign, lo, hi):
+    import oracle_lib as ol
+    sh = [ol.make_shared(ol.DD, alphas=[0.5] * 8)]
+    m = ol.OracleMixture(3.0, 0.3, sh)
+    m.init_from_assignments([values[lo:hi]], assign[lo:hi], K, 2)
+    return m
+
+
+def worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle_lib as ol
+    from distributions_amd import engine
+    values, assign = make_rows()
+    lo, hi = rank * N // world, (rank + 1) * N // world
+    m = make_mix(values, assign, lo, hi)
+    backend = ol.OracleBackend(m, row_offset=lo)
+    sharded = engine.ShardedGibbs(backend, hi - lo, lo, device="cpu")
+    sharded.sync_initial_stats()
+    st = ol.oracle().orc_rng_seed(SEED)
+    for s in range(SWEEPS):
+        sharded.sweep(BATCH // world, st, draw_base=s * N)
+    np.save(os.path.join(out, "assign_%d.npy" % rank), m.assign)
+    np.save(os.path.join(out, "counts_%d.npy" % rank), m.counts())
+    dist.destroy_process_group()
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def test_two_ranks_equal_one_rank_with_the_same_batches(tmp_path):
+    import oracle_lib as ol
+    world = 2
+    mp.spawn(worker, args=(world, free_port(), str(tmp_path)), nprocs=world,
+             join=True)
+    got = np.concatenate([np.load(tmp_path / ("assign_%d.npy" % r))
+                          for r in range(world)])
+    counts = [np.load(tmp_path / ("counts_%d.npy" % r)) for r in range(world)]
+    assert np.array_equal(counts[0], counts[1])   # replicas agree
+
+    # single process, same batch composition: batch b = the union over ranks
+    # of local rows [b*B/2, (b+1)*B/2) of each shard
+    values, assign = make_rows()
+    m = make_mix(values, assign, 0, N)
+    L = ol.oracle()
+    ol._phase_sigs(L)
+    st = L.orc_rng_seed(SEED)
+    half = N // world
+    per = BATCH // world
+    for s in range(SWEEPS):
+        for b in range(0, half, per):
+            snap = m.counts().copy()
+            moves = []
+            for r in range(world):
+                r0, r1 = r * half + b, r * half + min(half, b + per)
+                old = np.zeros(r1 - r0 + 1, np.uint32)
+                new = np.zeros(r1 - r0 + 1, np.uint32)
+                L.orc_mix_batch_sample(m.h, r0, r1, m._vals, m.assign, st,
+                                       s * N, 0, old, new)
+                moves.append((r0, r1, old, new))
+            for r0, r1, old, new in moves:
+                L.orc_mix_apply_moves(m.h, r0, r1, m._vals, m.assign, old, new)
+            L.orc_mix_batch_finish(m.h, np.ascontiguousarray(snap, np.int32))
+    assert np.array_equal(m.counts(), counts[0])
+    assert np.array_equal(got, m.assign)
