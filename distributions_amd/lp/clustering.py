@@ -1,0 +1,111 @@
+"""Mirror of distributions/lp/clustering.pyx for Pitman-Yor (CRP when d = 0):
+PitmanYor(alpha, d), PitmanYor.Mixture, count_assignments.
+(LowEntropy is outside the row-update path: SURVEY 2.1.)"""
+import numpy as np
+
+from .. import _core
+
+
+def count_assignments(assignments):
+    """Clustering<int>::count_assignments (src/clustering.cc:37-63):
+    {value_id: group_id} -> group sizes, group ids being 0..G-1"""
+    counts = []
+    for group_id in assignments.values():
+        if group_id >= len(counts):
+            counts.extend([0] * (group_id + 1 - len(counts)))
+        counts[group_id] += 1
+    return counts
+
+
+class PitmanYorMixture(object):
+    """PitmanYor::Mixture = CachedMixture (clustering.hpp:126-234)"""
+
+    def __init__(self):
+        self._core = _core.PyMixture()
+
+    def __len__(self):
+        return len(self._core)
+
+    @property
+    def empty_groupids(self):
+        return iter(self._core.empty_groupids())
+
+    def init(self, model, counts):
+        self._core.init(model.alpha, model.d, list(counts))
+
+    def add_value(self, model, groupid):
+        return self._core.add_value(model.alpha, model.d, groupid)
+
+    def remove_value(self, model, groupid):
+        return self._core.remove_value(model.alpha, model.d, groupid)
+
+    def score_value(self, model, scores):
+        assert scores.dtype == np.float32
+        self._core.score_value(model.alpha, model.d, scores)
+
+    def counts(self):
+        return self._core.counts()
+
+
+class PitmanYor(object):
+    EXAMPLES = [
+        {'alpha': 1., 'd': 0.},
+        {'alpha': 1., 'd': 0.1},
+        {'alpha': 1., 'd': 0.9},
+        {'alpha': 10., 'd': 0.1},
+        {'alpha': 0.1, 'd': 0.1},
+    ]
+    Mixture = PitmanYorMixture
+
+    def __init__(self, **kwargs):                # lp/clustering.pyx:144-154
+        if kwargs:
+            self.load(kwargs)
+        else:
+            self.alpha = 1.0
+            self.d = 0.0
+
+    def load(self, raw):
+        alpha = float(np.float32(raw['alpha']))
+        d = float(np.float32(raw['d']))
+        assert 0 < alpha
+        assert 0 <= d and d < 1
+        self.alpha = alpha
+        self.d = d
+
+    def dump(self):
+        return {'alpha': self.alpha, 'd': self.d}
+
+    @classmethod
+    def from_dict(cls, raw):
+        model = cls()
+        model.load(raw)
+        return model
+
+    def protobuf_load(self, message):
+        self.load({'alpha': message.alpha, 'd': message.d})
+
+    def protobuf_dump(self, message):
+        message.Clear()
+        message.alpha = self.alpha
+        message.d = self.d
+
+    def score_add_value(self, group_size, nonempty_group_count, sample_size,
+                        empty_group_count=1):
+        return _core.py_score_add_value(self.alpha, self.d, group_size,
+                                        nonempty_group_count, sample_size,
+                                        empty_group_count)
+
+    def score_remove_value(self, group_size, nonempty_group_count,
+                           sample_size, empty_group_count=1):
+        return _core.py_score_remove_value(self.alpha, self.d, group_size,
+                                           nonempty_group_count, sample_size,
+                                           empty_group_count)
+
+    def sample_assignments(self, size):
+        raise NotImplementedError(
+            "sample_assignments is initialisation, outside the row-update "
+            "path (SURVEY 8f rank 3)")
+
+    def score_counts(self, counts):
+        raise NotImplementedError(
+            "score_counts is hyper-parameter scoring (SURVEY 8f rank 1)")

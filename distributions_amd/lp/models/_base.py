@@ -1,0 +1,208 @@
+"""Shared/Group/Mixture of one component model over the C ABI.
+
+The reference generates one Cython module per model from the same template
+(distributions/lp/models/_dd.pyx:31-151; "_X.pyx identical across models").
+Here the template is this module; the per-model modules supply the
+hyper-parameter and statistics field names.
+
+    Shared   holds hyper-parameters                 (_dd.pyx:31-36, dd.pyx:52-82)
+    Group    one group's sufficient statistics on the host, as the 32-bit
+             words of dist_group_words()            (_dd.pyx:39-69, dd.pyx:85-113)
+    Mixture  the groups' statistics and score caches in HBM
+             (dist_mixture_t)                       (_dd.pyx:84-135)
+"""
+import numpy as np
+
+from ... import _core
+from ..random import get_rng  # noqa: F401  (same import surface as the reference)
+
+
+class SharedBase(object):
+    KIND = None
+
+    def __init__(self):
+        self._params = None
+
+    # --- to be provided by the model module --------------------------------
+    def load(self, raw):
+        raise NotImplementedError
+
+    def dump(self):
+        raise NotImplementedError
+
+    # --- SharedMixin / SharedIoMixin (distributions/mixins.py:51-60,99-110) -
+    def add_value(self, value):
+        pass
+
+    def remove_value(self, value):
+        pass
+
+    def realize(self):
+        pass
+
+    @classmethod
+    def from_dict(cls, raw):
+        model = cls()
+        model.load(raw)
+        return model
+
+    def protobuf_load(self, message):
+        self.load({name: _message_get(message, name)
+                   for name in self.FIELDS})
+
+    def protobuf_dump(self, message):
+        message.Clear()
+        for name, value in self.dump().items():
+            _message_set(message, name, value)
+
+    @property
+    def params(self):
+        """the dist_shared_t behind this object"""
+        if self._params is None:
+            raise RuntimeError("Shared has not been loaded")
+        return self._params
+
+
+def _message_get(message, name):
+    value = getattr(message, name)
+    try:
+        return list(value)
+    except TypeError:
+        return value
+
+
+def _message_set(message, name, value):
+    if isinstance(value, (list, tuple)):
+        getattr(message, name).extend(value)
+    else:
+        setattr(message, name, value)
+
+
+class GroupBase(object):
+    """Model::Group; `words` is the statistics image the ABI uses."""
+    SHARED = None
+
+    def __init__(self):
+        self.words = None
+
+    def init(self, shared):
+        self.words = shared.params.group_init()
+
+    def add_value(self, shared, value):
+        shared.params.group_add_value(self.words, self._word(shared, value))
+
+    def add_repeated_value(self, shared, value, count):
+        for _ in range(int(count)):
+            self.add_value(shared, value)
+
+    def remove_value(self, shared, value):
+        shared.params.group_remove_value(self.words, self._word(shared, value))
+
+    def score_value(self, shared, value):
+        return shared.params.group_score_value(self.words,
+                                               self._word(shared, value))
+
+    def score_data(self, shared):
+        raise NotImplementedError(
+            "score_data is outside the row-update path (SURVEY 8f rank 1)")
+
+    def sample_value(self, shared):
+        raise NotImplementedError(
+            "samplers are outside the row-update path (SURVEY 2.2)")
+
+    @staticmethod
+    def _word(shared, value):
+        return int(_core.value_words(shared.params.kind, [value])[0])
+
+    # --- GroupIoMixin (distributions/mixins.py:83-96) ------------------------
+    @classmethod
+    def from_values(cls, model, values=[]):
+        group = cls()
+        group.init(model)
+        for value in values:
+            group.add_value(model, value)
+        return group
+
+    @classmethod
+    def from_dict(cls, raw):
+        group = cls()
+        group.load(raw)
+        return group
+
+
+class MixtureBase(object):
+    """Model::Mixture = MixtureSlave<Model, ...> (mixture.hpp:340-450)."""
+    GROUP = None
+
+    def __init__(self):
+        self._core = None
+        self._pending = []     # groups appended before the first init()
+        self._key = None
+
+    def _handle(self, shared):
+        key = (shared.params.kind, tuple(shared.params.p),
+               tuple(shared.params.alphas), shared.params.dim)
+        if self._core is None or key != self._key:
+            groups = self._pending if self._core is None else [
+                self._core.get_group(i) for i in range(len(self._core))]
+            self._core = _core.SlaveMixture(shared.params)
+            for words in groups:
+                self._core.append(np.ascontiguousarray(words, np.uint32))
+            self._pending = []
+            self._key = key
+        return self._core
+
+    def __len__(self):
+        return len(self._pending) if self._core is None else len(self._core)
+
+    def __getitem__(self, groupid):
+        assert groupid < len(self), "groupid out of bounds"
+        group = self.GROUP()
+        if self._core is None:
+            group.words = self._pending[groupid].copy()
+        else:
+            group.words = self._core.get_group(groupid)
+        group._after_load()
+        return group
+
+    def append(self, group):
+        if self._core is None:
+            self._pending.append(np.array(group.words, np.uint32))
+        else:
+            self._core.append(np.ascontiguousarray(group.words, np.uint32))
+
+    def clear(self):
+        self._pending = []
+        if self._core is not None:
+            self._core.clear()
+
+    def init(self, shared):
+        self._handle(shared).init()
+
+    def add_group(self, shared):
+        self._handle(shared).add_group()
+
+    def remove_group(self, shared, groupid):
+        self._handle(shared).remove_group(groupid)
+
+    def add_value(self, shared, groupid, value):
+        self._handle(shared).add_value(groupid,
+                                       GroupBase._word(shared, value))
+
+    def remove_value(self, shared, groupid, value):
+        self._handle(shared).remove_value(groupid,
+                                          GroupBase._word(shared, value))
+
+    def score_value_group(self, shared, groupid, value):
+        return self._handle(shared).score_value_group(
+            groupid, GroupBase._word(shared, value))
+
+    def score_value(self, shared, value, scores_accum):
+        assert len(scores_accum) == len(self), "scores_accum != len(mixture)"
+        assert scores_accum.dtype == np.float32
+        self._handle(shared).score_value(GroupBase._word(shared, value),
+                                         scores_accum)
+
+    def score_data(self, shared):
+        raise NotImplementedError(
+            "score_data is outside the row-update path (SURVEY 8f rank 1)")

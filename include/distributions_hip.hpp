@@ -1,0 +1,252 @@
+// distributions_hip.hpp -- header shim: the reference's C++ class surface for
+// the mixture row-update path, forwarding to the C ABI of
+// libdistributions_hip.so (distributions_hip.h).
+//
+// A downstream program that instantiates `Model::Mixture` /
+// `Clustering<int>::PitmanYor::Mixture` from the reference's headers
+// (include/distributions/mixture.hpp:340-450, clustering.hpp:126-234) can
+// switch to these classes by changing the namespace; member names, argument
+// order, the accumulate/overwrite semantics of score_value and the
+// add_value/remove_value return flags are the reference's.  Differences, all
+// forced by the state living in HBM:
+//   - `rng_t &` arguments are accepted and ignored where the reference ignores
+//     them too (every Mixture member on this path);
+//   - groups(i) returns a copy (like the lp wrapper's Mixture.__getitem__,
+//     lp/models/_dd.pyx:96-100), not a reference;
+//   - errors throw std::runtime_error (the reference does under
+//     DIST_THROW_ON_ERROR, common.hpp:49-57).
+#pragma once
+
+#include <cstdint>
+#include <cstring>
+#include <stdexcept>
+#include <vector>
+
+#include "distributions_hip.h"
+
+namespace distributions_hip {
+
+typedef uint32_t rng_t;   // minstd_rand0 state (random_fwd.hpp:34)
+
+inline void check(int rc) {
+    if (rc != 0) throw std::runtime_error(dist_last_error());
+}
+
+// AlignedFloats / VectorFloat stand-in (vector.hpp:63-90)
+typedef std::vector<float> VectorFloat;
+
+namespace detail {
+inline uint32_t word(float x) { uint32_t u; memcpy(&u, &x, 4); return u; }
+inline uint32_t word(int x) { return (uint32_t)x; }
+inline uint32_t word(uint32_t x) { return x; }
+inline uint32_t word(bool x) { return x ? 1u : 0u; }
+}  // namespace detail
+
+// Model::{Shared, Group, Mixture} over one dist_kind.
+template <int KIND, class Value_>
+struct Model {
+    typedef Value_ Value;
+
+    struct Shared : dist_shared_t {
+        Shared() { memset(static_cast<dist_shared_t *>(this), 0,
+                          sizeof(dist_shared_t)); kind = KIND; }
+    };
+
+    struct Group {
+        std::vector<uint32_t> words;
+        void init(const Shared & shared, rng_t &) {
+            words.assign(dist_group_words(&shared), 0);
+            check(dist_group_init(&shared, words.data()));
+        }
+        void add_value(const Shared & shared, const Value & value, rng_t &) {
+            check(dist_group_add_value(&shared, words.data(),
+                                       detail::word(value)));
+        }
+        void remove_value(const Shared & shared, const Value & value, rng_t &) {
+            check(dist_group_remove_value(&shared, words.data(),
+                                          detail::word(value)));
+        }
+        float score_value(const Shared & shared, const Value & value,
+                          rng_t &) const {
+            float out = 0;
+            check(dist_group_score_value(&shared, words.data(),
+                                         detail::word(value), &out));
+            return out;
+        }
+    };
+
+    // MixtureSlave<Model, ...> (mixture.hpp:340-450)
+    class Mixture {
+      public:
+        Mixture() : ptr_(nullptr) {}
+        ~Mixture() { if (ptr_) dist_mixture_destroy(ptr_); }
+        Mixture(const Mixture &) = delete;
+        Mixture & operator=(const Mixture &) = delete;
+
+        // groups().push_back(group) / groups().size() / groups(i)
+        void append(const Shared & shared, const Group & group) {
+            check(dist_mixture_append(handle(shared), group.words.data()));
+        }
+        size_t size() const { return ptr_ ? dist_mixture_size(ptr_) : 0; }
+        Group groups(const Shared & shared, size_t i) {
+            Group g;
+            g.words.assign(dist_group_words(&shared), 0);
+            check(dist_mixture_get_group(handle(shared), i, g.words.data()));
+            return g;
+        }
+        void init(const Shared & shared, rng_t &) {
+            check(dist_mixture_init(handle(shared)));
+        }
+        void add_group(const Shared & shared, rng_t &) {
+            check(dist_mixture_add_group(handle(shared)));
+        }
+        void remove_group(const Shared & shared, size_t groupid) {
+            check(dist_mixture_remove_group(handle(shared), groupid));
+        }
+        void add_value(const Shared & shared, size_t groupid,
+                       const Value & value, rng_t &) {
+            check(dist_mixture_add_value(handle(shared), groupid,
+                                         detail::word(value)));
+        }
+        void remove_value(const Shared & shared, size_t groupid,
+                          const Value & value, rng_t &) {
+            check(dist_mixture_remove_value(handle(shared), groupid,
+                                            detail::word(value)));
+        }
+        float score_value_group(const Shared & shared, size_t groupid,
+                                const Value & value, rng_t &) {
+            float out = 0;
+            check(dist_mixture_score_value_group(handle(shared), groupid,
+                                                 detail::word(value), &out));
+            return out;
+        }
+        // accumulates into scores_accum (mixture.hpp:416-425)
+        void score_value(const Shared & shared, const Value & value,
+                         VectorFloat & scores_accum, rng_t &) {
+            check(dist_mixture_score_value(handle(shared), detail::word(value),
+                                           scores_accum.data(),
+                                           scores_accum.size()));
+        }
+
+      private:
+        dist_mixture_t * handle(const Shared & shared) {
+            if (!ptr_) {
+                ptr_ = dist_mixture_create(&shared);
+                if (!ptr_) throw std::runtime_error(dist_last_error());
+            }
+            return ptr_;
+        }
+        dist_mixture_t * ptr_;
+    };
+};
+
+typedef Model<DIST_DD, int> DirichletDiscrete;          // models/dd.hpp (max_dim 256)
+typedef Model<DIST_BB, bool> BetaBernoulli;              // models/bb.hpp
+typedef Model<DIST_GP, uint32_t> GammaPoisson;           // models/gp.hpp
+typedef Model<DIST_NICH, float> NormalInverseChiSq;      // models/nich.hpp
+typedef Model<DIST_DPD, uint32_t> DirichletProcessDiscrete;  // models/dpd.hpp
+
+// Clustering<int>::PitmanYor (clustering.hpp:58-234)
+struct PitmanYor {
+    float alpha;
+    float d;
+
+    float score_add_value(int group_size, int nonempty_group_count,
+                          int sample_size, int empty_group_count = 1) const {
+        float out = 0;
+        check(dist_py_score_add_value(alpha, d, group_size,
+                                      nonempty_group_count, sample_size,
+                                      empty_group_count, &out));
+        return out;
+    }
+    float score_remove_value(int group_size, int nonempty_group_count,
+                             int sample_size, int empty_group_count = 1) const {
+        float out = 0;
+        check(dist_py_score_remove_value(alpha, d, group_size,
+                                         nonempty_group_count, sample_size,
+                                         empty_group_count, &out));
+        return out;
+    }
+
+    class Mixture {   // CachedMixture
+      public:
+        Mixture() : ptr_(dist_py_mixture_create()) {
+            if (!ptr_) throw std::runtime_error(dist_last_error());
+        }
+        ~Mixture() { dist_py_mixture_destroy(ptr_); }
+        Mixture(const Mixture &) = delete;
+        Mixture & operator=(const Mixture &) = delete;
+
+        std::vector<int> & counts() { return staged_; }   // set before init()
+        void init(const PitmanYor & model) {
+            check(dist_py_mixture_init(ptr_, model.alpha, model.d,
+                                       staged_.data(), staged_.size()));
+        }
+        bool add_value(const PitmanYor & model, size_t groupid) {
+            int flag = 0;
+            check(dist_py_mixture_add_value(ptr_, model.alpha, model.d,
+                                            groupid, &flag));
+            return flag != 0;
+        }
+        bool remove_value(const PitmanYor & model, size_t groupid) {
+            int flag = 0;
+            check(dist_py_mixture_remove_value(ptr_, model.alpha, model.d,
+                                               groupid, &flag));
+            return flag != 0;
+        }
+        // overwrites scores (clustering.hpp:195-208)
+        void score_value(const PitmanYor & model, VectorFloat & scores) const {
+            check(dist_py_mixture_score_value(ptr_, model.alpha, model.d,
+                                              scores.data(), scores.size()));
+        }
+        size_t size() const { return dist_py_mixture_size(ptr_); }
+        size_t sample_size() const { return dist_py_mixture_sample_size(ptr_); }
+        std::vector<size_t> empty_groupids() const {
+            std::vector<size_t> ids(dist_py_mixture_empty_groupids(ptr_, nullptr, 0));
+            dist_py_mixture_empty_groupids(ptr_, ids.data(), ids.size());
+            return ids;
+        }
+
+      private:
+        dist_py_mixture_t * ptr_;
+        std::vector<int> staged_;
+    };
+};
+
+// MixtureIdTracker (mixture.hpp:460-521)
+class MixtureIdTracker {
+  public:
+    typedef uint32_t Id;
+    MixtureIdTracker() : ptr_(dist_id_tracker_create()) {}
+    ~MixtureIdTracker() { dist_id_tracker_destroy(ptr_); }
+    MixtureIdTracker(const MixtureIdTracker &) = delete;
+    MixtureIdTracker & operator=(const MixtureIdTracker &) = delete;
+    void init(size_t group_count = 0) { check(dist_id_tracker_init(ptr_, group_count)); }
+    void add_group() { check(dist_id_tracker_add_group(ptr_)); }
+    void remove_group(Id packed) { check(dist_id_tracker_remove_group(ptr_, packed)); }
+    Id packed_to_global(Id packed) const {
+        Id out = 0;
+        check(dist_id_tracker_packed_to_global(ptr_, packed, &out));
+        return out;
+    }
+    Id global_to_packed(Id global) const {
+        Id out = 0;
+        check(dist_id_tracker_global_to_packed(ptr_, global, &out));
+        return out;
+    }
+    size_t packed_size() const { return dist_id_tracker_packed_size(ptr_); }
+    size_t global_size() const { return dist_id_tracker_global_size(ptr_); }
+
+  private:
+    dist_id_tracker_t * ptr_;
+};
+
+// sample_from_scores_overwrite (random.hpp:361-366)
+inline size_t sample_from_scores_overwrite(rng_t & rng, VectorFloat & scores) {
+    size_t sample = 0;
+    check(dist_sample_from_scores_overwrite(&rng, scores.size(), scores.data(),
+                                            &sample));
+    return sample;
+}
+
+}  // namespace distributions_hip

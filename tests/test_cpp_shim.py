@@ -1,0 +1,46 @@
+"""include/distributions_hip.hpp: a C++ caller written like a caller of the
+reference's headers compiles against the shim (CPU) and, on the GPU, produces
+the oracle's sequential chain."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "examples", "row_update")
+
+
+def build():
+    subprocess.check_call(
+        ["g++", "-std=c++11", "-I" + os.path.join(ROOT, "include"),
+         os.path.join(ROOT, "examples", "row_update.cc"),
+         "-L" + os.path.join(ROOT, "distributions_amd"),
+         "-ldistributions_hip",
+         "-Wl,-rpath," + os.path.join(ROOT, "distributions_amd"),
+         "-o", EXE])
+
+
+def test_shim_example_compiles_and_links():
+    build()
+    assert os.path.exists(EXE)
+
+
+@pytest.mark.gpu
+def test_shim_example_reproduces_the_sequential_chain():
+    build()
+    out = subprocess.check_output([EXE], text=True).split()
+    groups = int(out[1])
+    got = [int(v) for v in out[3:]]
+    values = np.array([0, 1, 0, 2, 0, 1, 0, 3], np.uint32)
+    assign = (np.arange(8) % 3).astype(np.uint32)
+    m = ol.OracleMixture(1.0, 0.2, [ol.make_shared(ol.DD, alphas=[0.5] * 4)])
+    m.init_from_assignments([values], assign, 3, 1)
+    st = ol.oracle().orc_rng_seed(1)
+    for _ in range(3):
+        st = m.gibbs_sequential(0, 8, st)
+    assert groups == len(m)
+    assert got == list(m.assign)

@@ -1,0 +1,296 @@
+"""The reference's own tests for this path, restated against the lp mirror on
+the GPU (distributions/tests/test_models.py:498-594,
+distributions/tests/test_clustering.py:242-327,
+distributions/tests/test_random.py:183-247), plus bit-exact checks of every
+value against the oracle and the reference goldens."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3   # distributions/tests/util.py:42
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def assert_close(a, b, tol=TOL, msg=""):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    assert np.all(np.abs(a - b) <= tol * (1.0 + np.abs(a) + np.abs(b))), (
+        msg, a, b)
+
+
+def bits(x):
+    return np.ascontiguousarray(x, np.float32).view(np.uint32)
+
+
+def modules():
+    from distributions_amd.lp.models import dd, bb, gp, nich, dpd
+    return [dd, bb, gp, nich, dpd]
+
+
+def examples():
+    out = []
+    for module in modules():
+        for i, ex in enumerate(module.EXAMPLES):
+            out.append(pytest.param(module, ex, id="%s-%d" % (module.NAME, i)))
+    return out
+
+
+def oracle_twin(module, shared):
+    """the same Shared for the oracle"""
+    p = shared.params
+    kind = p.kind
+    if kind == ol.DD:
+        return ol.make_shared(ol.DD, alphas=p.alphas)
+    if kind == ol.BB:
+        return ol.make_shared(ol.BB, alpha=p.p[0], beta=p.p[1])
+    if kind == ol.GP:
+        return ol.make_shared(ol.GP, alpha=p.p[0], inv_beta=p.p[1])
+    if kind == ol.NICH:
+        return ol.make_shared(ol.NICH, mu=p.p[0], kappa=p.p[1],
+                              sigmasq=p.p[2], nu=p.p[3])
+    return ol.make_shared(ol.DPD, alpha=p.p[0], beta0=p.p[1], betas=p.betas)
+
+
+@pytest.mark.parametrize("module,EXAMPLE", examples())
+def test_mixture_runs(module, EXAMPLE):
+    from distributions_amd.lp import random as lprandom
+    lprandom.seed(0)
+    shared = module.Shared.from_dict(EXAMPLE['shared'])
+    values = EXAMPLE['values']
+    mixture = module.Mixture()
+    for value in values:
+        shared.add_value(value)
+        mixture.append(module.Group.from_values(shared, [value]))
+    mixture.init(shared)
+    groupids = []
+    for value in values:
+        scores = np.zeros(len(mixture), dtype=np.float32)
+        mixture.score_value(shared, value, scores)
+        groupid = lprandom.sample_from_scores(scores)
+        mixture.add_value(shared, groupid, value)
+        groupids.append(groupid)
+    mixture.add_group(shared)
+    assert len(mixture) == len(values) + 1
+    for value, groupid in zip(values, groupids):
+        mixture.remove_value(shared, groupid, value)
+    mixture.remove_group(shared, 0)
+    mixture.remove_group(shared, len(mixture) - 1)
+    assert len(mixture) == len(values) - 1
+    for value in values:
+        scores = np.zeros(len(mixture), dtype=np.float32)
+        mixture.score_value(shared, value, scores)
+        groupid = lprandom.sample_from_scores(scores)
+        mixture.add_value(shared, groupid, value)
+
+
+@pytest.mark.parametrize("module,EXAMPLE", examples())
+def test_mixture_score(module, EXAMPLE):
+    """Mixture.score_value / score_value_group == per-group Group.score_value
+    (TOL, like the reference) and == the oracle's MixtureSlave bit for bit."""
+    L = ol.oracle()
+    rng = np.random.default_rng(0)
+    shared = module.Shared.from_dict(EXAMPLE['shared'])
+    values = EXAMPLE['values']
+    groups = [module.Group.from_values(shared, [value]) for value in values]
+    mixture = module.Mixture()
+    for group in groups:
+        mixture.append(group)
+    mixture.init(shared)
+
+    osh = oracle_twin(module, shared)
+    orc = ol.OracleMixture(1.0, 0.0, [osh])
+    word = lambda v: module.Group._word(shared, v)   # noqa: E731
+    for g, value in enumerate(values):
+        L.orc_mix_slave_append_empty(orc.h, 0)
+        L.orc_mix_slave_group_add_value(orc.h, 0, g, word(value))
+    L.orc_mix_slave_init(orc.h, 0)
+
+    def check_score_value(value):
+        expected = [group.score_value(shared, value) for group in groups]
+        actual = np.zeros(len(mixture), dtype=np.float32)
+        noise = rng.normal(size=len(actual)).astype(np.float32)
+        actual += noise
+        want = noise.copy()
+        mixture.score_value(shared, value, actual)
+        L.orc_mix_slave_score_value(orc.h, 0, word(value), want)
+        assert np.array_equal(bits(actual), bits(want)), "vs oracle"
+        assert_close(actual - noise, expected, msg='score_value')
+        another = [mixture.score_value_group(shared, i, value)
+                   for i in range(len(groups))]
+        want_g = [L.orc_mix_slave_score_value_group(orc.h, 0, i, word(value))
+                  for i in range(len(groups))]
+        assert np.array_equal(bits(another), bits(want_g)), "group vs oracle"
+        assert_close(another, expected, msg='score_value_group')
+        return actual - noise
+
+    for value in values:
+        check_score_value(value)
+    groupids = []
+    for value in values:
+        scores = check_score_value(value)
+        p = np.exp(scores - scores.max())
+        groupid = int(rng.choice(len(p), p=p / p.sum()))
+        groups[groupid].add_value(shared, value)
+        mixture.add_value(shared, groupid, value)
+        L.orc_mix_slave_add_value(orc.h, 0, groupid, word(value))
+        groupids.append(groupid)
+        np.testing.assert_array_equal(mixture[groupid].words,
+                                      groups[groupid].words)
+    for value, groupid in zip(values, groupids):
+        groups[groupid].remove_value(shared, value)
+        mixture.remove_value(shared, groupid, value)
+        L.orc_mix_slave_remove_value(orc.h, 0, groupid, word(value))
+        check_score_value(value)
+
+
+def test_mixture_errors_are_runtime_errors():
+    from distributions_amd.lp.models import dd
+    shared = dd.Shared.from_dict(dd.EXAMPLES[0]['shared'])
+    mixture = dd.Mixture()
+    mixture.append(dd.Group.from_values(shared, [0]))
+    mixture.init(shared)
+    with pytest.raises(RuntimeError):
+        mixture.add_value(shared, 5, 0)           # bad groupid
+    with pytest.raises(RuntimeError):
+        mixture.add_value(shared, 0, 4)           # value out of bounds
+    with pytest.raises(AssertionError):
+        mixture.score_value(shared, 0, np.zeros(3, np.float32))
+
+
+@pytest.mark.parametrize("EXAMPLE", [
+    {'alpha': 1., 'd': 0.}, {'alpha': 1., 'd': 0.1}, {'alpha': 1., 'd': 0.9},
+    {'alpha': 10., 'd': 0.1}, {'alpha': 0.1, 'd': 0.1}])
+def test_mixture_score_matches_score_add_value(EXAMPLE):
+    from distributions_amd.lp.clustering import PitmanYor
+    from distributions_amd.lp.mixture import MixtureIdTracker
+    L = ol.oracle()
+    rng = np.random.default_rng(1)
+    model = PitmanYor()
+    model.load(EXAMPLE)
+    sample_count = 120
+    nonempty_counts = [int(c) for c in rng.integers(1, 40, 9)]
+
+    def check_counts(mixture, counts, empty_group_count):
+        empty_groupids = frozenset(mixture.empty_groupids)
+        assert len(empty_groupids) == empty_group_count
+        for groupid in empty_groupids:
+            assert counts[groupid] == 0
+        np.testing.assert_array_equal(mixture.counts(), counts)
+
+    def check_scores(mixture, counts, empty_group_count):
+        sample_count = sum(counts)
+        nonempty_group_count = len(counts) - empty_group_count
+        expected = [model.score_add_value(group_size, nonempty_group_count,
+                                          sample_count, empty_group_count)
+                    for group_size in counts]
+        want = [L.orc_py_score_add_value(model.alpha, model.d, c,
+                                         nonempty_group_count, sample_count,
+                                         empty_group_count) for c in counts]
+        assert np.array_equal(bits(expected), bits(want))
+        actual = rng.normal(size=len(counts)).astype(np.float32)
+        mixture.score_value(model, actual)
+        assert_close(actual, expected)
+        return actual
+
+    for empty_group_count in [1, 10]:
+        counts = nonempty_counts + [0] * empty_group_count
+        rng.shuffle(counts)
+        counts = [int(c) for c in counts]
+        mixture = PitmanYor.Mixture()
+        id_tracker = MixtureIdTracker()
+        mixture.init(model, counts)
+        id_tracker.init(len(counts))
+        orc = ol.OracleMixture(model.alpha, model.d, [])
+        L.orc_mix_driver_init(orc.h, np.array(counts, np.int32), len(counts))
+
+        def vs_oracle(scores):
+            want = np.zeros(len(counts), np.float32)
+            L.orc_mix_driver_score_value(orc.h, want)
+            assert np.array_equal(bits(scores), bits(want))
+
+        groupids = []
+        for _ in range(sample_count):
+            check_counts(mixture, counts, empty_group_count)
+            scores = check_scores(mixture, counts, empty_group_count)
+            vs_oracle(scores)
+            p = np.exp(scores - scores.max())
+            groupid = int(rng.choice(len(p), p=p / p.sum()))
+            expected_group_added = (counts[groupid] == 0)
+            counts[groupid] += 1
+            assert mixture.add_value(model, groupid) == expected_group_added
+            L.orc_mix_driver_add_value(orc.h, groupid)
+            groupids.append(id_tracker.packed_to_global(groupid))
+            if expected_group_added:
+                id_tracker.add_group()
+                counts.append(0)
+        for global_groupid in groupids:
+            groupid = id_tracker.global_to_packed(global_groupid)
+            counts[groupid] -= 1
+            expected_group_removed = (counts[groupid] == 0)
+            assert (mixture.remove_value(model, groupid)
+                    == expected_group_removed)
+            L.orc_mix_driver_remove_value(orc.h, groupid)
+            if expected_group_removed:
+                id_tracker.remove_group(groupid)
+                back = counts.pop()
+                if groupid < len(counts):
+                    counts[groupid] = back
+            check_counts(mixture, counts, empty_group_count)
+            vs_oracle(check_scores(mixture, counts, empty_group_count))
+
+
+@pytest.mark.parametrize("name", ["fast_log", "fast_exp", "fast_lgamma",
+                                  "fast_lgamma_nu", "fast_log_factorial"])
+def test_special_functions_match_reference_goldens_on_gpu(name):
+    """the device special functions against the REAL reference's outputs"""
+    from distributions_amd.lp import special
+    g = np.load(os.path.join(GOLD, "special_functions.npz"))
+    x = g[name + "_in"]
+    got = getattr(special, name)(x)
+    bad = np.nonzero(bits(got) != g[name + "_out"])[0]
+    assert bad.size == 0, (name, x[bad[:5]], got[bad[:5]])
+
+
+def test_sampling_matches_oracle_and_reference_probe():
+    from distributions_amd.lp import random as lprandom
+    L = ol.oracle()
+    lprandom.seed(1)
+    got = [lprandom.sample_from_scores([-1, -2.5, .25, -.75, -3])
+           for _ in range(8)]
+    assert got == [0, 0, 2, 2, 2, 2, 0, 2]
+    rng = np.random.default_rng(3)
+    lprandom.seed(77)
+    st = ctypes.c_uint32(L.orc_rng_seed(77))
+    for size in [1, 2, 5, 64, 1024, 5000]:
+        for _ in range(4):
+            scores = (rng.normal(size=size) * 4).astype(np.float32)
+            s2 = scores.copy()
+            want = L.orc_sample_from_scores_overwrite(ctypes.byref(st), size,
+                                                      s2)
+            assert lprandom.sample_from_scores(scores) == want
+            assert lprandom.get_rng().state == st.value
+            assert np.float32(lprandom.log_sum_exp(scores)) == np.float32(
+                L.orc_log_sum_exp(size, np.ascontiguousarray(scores)))
+    # extreme spreads: flushed tails, ties
+    for scores in [[0, -100, -88, -87.5, -50], [5, 5, 5, 5], [-1e30, 0.0]]:
+        s = np.array(scores, np.float32)
+        s2 = s.copy()
+        want = L.orc_sample_from_scores_overwrite(ctypes.byref(st), s.size, s2)
+        assert lprandom.sample_from_scores(s) == want
+
+
+def test_prob_from_scores():
+    from distributions_amd.lp import random as lprandom
+    rng = np.random.default_rng(4)
+    lprandom.seed(5)
+    for size in range(1, 30):
+        scores = rng.normal(size=size).tolist()
+        sample, prob1 = lprandom.sample_prob_from_scores(scores)
+        assert 0 <= sample < size
+        prob2 = lprandom.prob_from_scores(sample, scores)
+        assert_close(prob1, prob2)
