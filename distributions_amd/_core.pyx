@@ -143,6 +143,8 @@ cdef extern from "distributions_hip.h" nogil:
     int dist_gibbs_global_to_packed(const dist_gibbs_t *, uint32_t, uint32_t *)
     int dist_gibbs_kernel_stats(dist_gibbs_t *, double *, uint64_t *,
                                 uint64_t *, int)
+    int dist_gibbs_set_option(dist_gibbs_t *, const char *, int)
+    int dist_gibbs_path_counts(const dist_gibbs_t *, uint64_t *, uint64_t *)
 
 
 KIND_DD = DIST_DD
@@ -712,6 +714,15 @@ cdef class GibbsEngine:
         cdef uint32_t out = 0
         check(dist_gibbs_global_to_packed(self.ptr, global_, &out))
         return out
+
+    def set_option(self, name, int value):
+        check(dist_gibbs_set_option(self.ptr, name.encode(), value))
+
+    def path_counts(self):
+        """-> (batches served by the value-sorted kernel, by the generic one)"""
+        cdef uint64_t a = 0, b = 0
+        check(dist_gibbs_path_counts(self.ptr, &a, &b))
+        return a, b
 
     def kernel_stats(self, reset=False):
         """-> (ms, launches, rows) of the score+sample kernel (HIP events)"""

@@ -482,6 +482,23 @@ struct Gibbs {
     size_t batch_begin = 0, batch_end = 0;   // rows of the open batch
     bool batch_open = false;
 
+    // value-sorted path (single small-domain feature): rows of a batch range
+    // sorted by value once, tiles of <= 64 equal-valued rows
+    struct VsCache {
+        size_t r0 = 0, r1 = 0;
+        DeviceBuf<uint32_t> sorted_rows;
+        DeviceBuf<VsTile> tiles;
+        uint32_t n_tiles = 0;
+        DeviceBuf<uint32_t> other_rows;   // rows the tiles do not cover
+        uint32_t n_other = 0;
+    };
+    std::vector<std::unique_ptr<VsCache>> vs_cache;
+    DeviceBuf<float> vsLA, vsLB, vsM, vsmB;
+    DeviceBuf<int> vsArg;
+    DeviceBuf<uint32_t> deferred, deferred_count;
+    int value_sorted_mode = 1;   // 0 off, 1 auto, 2 always (when eligible)
+    uint64_t vs_batches = 0, generic_batches = 0;
+
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double kernel_ms = 0.0;
     uint64_t kernel_launches = 0, kernel_rows = 0;
@@ -722,6 +739,131 @@ struct Gibbs {
         }
     };
 
+    int vs_nvals() const {
+        const dist_shared_t & sh = feats[0]->sh;
+        return sh.kind == DIST_BB ? 2 : sh.dim;
+    }
+    bool use_value_sorted(size_t rows) const {
+        if (value_sorted_mode == 0 || F() != 1) return false;
+        const int kind = feats[0]->sh.kind;
+        if (kind != DIST_DD && kind != DIST_DPD && kind != DIST_BB) return false;
+        if (value_sorted_mode == 2) return true;
+        return rows >= (size_t)16 * vs_nvals() && rows >= 4096;
+    }
+
+    VsCache & vs_get(size_t r0, size_t r1) {
+        for (auto & c : vs_cache)
+            if (c->r0 == r0 && c->r1 == r1) return *c;
+        std::unique_ptr<VsCache> c(new VsCache());
+        c->r0 = r0;
+        c->r1 = r1;
+        const size_t n = r1 - r0;
+        const uint32_t nv = (uint32_t)vs_nvals();
+        DeviceBuf<uint32_t> hist;
+        hist.reserve(nv + 1, 0);   // zero-filled
+        LAUNCH(k_vs_hist, n, values[0], r0, n, nv, hist.p);
+        std::vector<uint32_t> h(nv + 1), start(nv + 2, 0);
+        hist.download(h.data(), nv + 1);
+        for (uint32_t x = 0; x <= nv; ++x) start[x + 1] = start[x] + h[x];
+        DeviceBuf<uint32_t> cursor;
+        cursor.upload(start.data(), nv + 1);
+        c->sorted_rows.reserve(std::max<size_t>(n, 1), 0);
+        LAUNCH(k_vs_scatter, n, values[0], r0, n, nv, cursor.p,
+               c->sorted_rows.p);
+        std::vector<VsTile> tiles;
+        for (uint32_t x = 0; x < nv; ++x)
+            for (uint32_t off = 0; off < h[x]; off += 64)
+                tiles.push_back(VsTile{x, start[x] + off,
+                                       std::min<uint32_t>(64, h[x] - off)});
+        c->n_tiles = (uint32_t)tiles.size();
+        c->tiles.upload(tiles.data(), tiles.size());
+        // rows whose value is outside the table (DPD OTHER): generic kernel
+        c->n_other = h[nv];
+        if (c->n_other) {
+            std::vector<uint32_t> idx(c->n_other);
+            sync();
+            HIP_CHECK(hipMemcpy(idx.data(), c->sorted_rows.p + start[nv],
+                                4 * (size_t)c->n_other, hipMemcpyDeviceToHost));
+            for (auto & i : idx) i += (uint32_t)r0;
+            c->other_rows.upload(idx.data(), idx.size());
+        }
+        sync();
+        if (vs_cache.size() >= 64) vs_cache.erase(vs_cache.begin());
+        vs_cache.push_back(std::move(c));
+        return *vs_cache.back();
+    }
+
+    struct VsLaunch {
+        Gibbs * self;
+        SweepParams * P;
+        VsCache * c;
+        VsTables T;
+        template <int KIND>
+        void go() {
+            const uint32_t nv = (uint32_t)self->vs_nvals();
+            hipLaunchKernelGGL((k_vs_prepare<KIND>), dim3(nv), dim3(kBlock), 0,
+                               stream(), *P, T);
+            HIP_CHECK(hipGetLastError());
+            HIP_CHECK(hipEventRecord(self->ev0, stream()));
+            hipLaunchKernelGGL((k_vs_sample<KIND>),
+                               dim3((c->n_tiles + 3) / 4), dim3(kBlock), 0,
+                               stream(), *P, T, c->tiles.p, c->n_tiles,
+                               c->sorted_rows.p, self->deferred.p,
+                               self->deferred_count.p);
+            HIP_CHECK(hipGetLastError());
+            HIP_CHECK(hipEventRecord(self->ev1, stream()));
+        }
+    };
+
+    void sample_value_sorted(SweepParams & P) {
+        VsCache & c = vs_get(P.row_begin, P.row_end);
+        const size_t n = P.row_end - P.row_begin;
+        const uint32_t nv = (uint32_t)vs_nvals();
+        const int Kpad = (K() + kVsUnroll - 1) / kVsUnroll * kVsUnroll;
+        vsLA.reserve((size_t)nv * Kpad, 0);
+        vsLB.reserve((size_t)nv * Kpad, 0);
+        vsM.reserve(nv, 0);
+        vsmB.reserve(nv, 0);
+        vsArg.reserve(nv, 0);
+        deferred.reserve(std::max<size_t>(n, 1), 0);
+        deferred_count.reserve(1, 0);
+        // base[] and the scalars; no folded table (the deferred rows use the
+        // generic kernel unfolded, which is the same arithmetic)
+        base.reserve(grow_capacity((size_t)K()), 0);
+        P.base = base.p;
+        P.table0 = nullptr;
+        LAUNCH(k_sweep_prepare, (size_t)K(), P, base.p, (float *)nullptr,
+               scalars.p);
+        HIP_CHECK(hipMemcpyAsync(deferred_count.p, &c.n_other, 4,
+                                 hipMemcpyHostToDevice, stream()));
+        if (c.n_other)
+            HIP_CHECK(hipMemcpyAsync(deferred.p, c.other_rows.p,
+                                     4 * (size_t)c.n_other,
+                                     hipMemcpyDeviceToDevice, stream()));
+        VsLaunch L{this, &P, &c,
+                   VsTables{vsLA.p, vsLB.p, vsM.p, vsmB.p, vsArg.p, Kpad}};
+        switch (feats[0]->sh.kind) {
+        case DIST_DD: L.go<DIST_DD>(); break;
+        case DIST_DPD: L.go<DIST_DPD>(); break;
+        default: L.go<DIST_BB>(); break;
+        }
+        // the handed-over rows, by the generic kernel in list mode
+        SweepParams Q = P;
+        Q.row_list = deferred.p;
+        Q.row_list_count = deferred_count.p;
+        DeferredLaunch D{&Q};
+        dispatch(D);
+    }
+    struct DeferredLaunch {
+        SweepParams * P;
+        template <int A, int B, int NF>
+        void run() {
+            hipLaunchKernelGGL((k_sweep_sample<A, B, NF>), dim3(64),
+                               dim3(kBlock), 0, stream(), *P);
+            HIP_CHECK(hipGetLastError());
+        }
+    };
+
     void batch_sample(size_t r0, size_t r1, uint32_t seed, uint64_t draw_base) {
         DIST_REQUIRE(!batch_open, "previous batch not finished");
         DIST_REQUIRE(r0 <= r1 && r1 <= n_rows, "bad row range");
@@ -731,9 +873,15 @@ struct Gibbs {
         if (r0 == r1) return;
         upload_maps();
         SweepParams P = params(r0, r1, seed, draw_base);
-        prepare(P);
-        SampleLaunch L{this, &P};
-        dispatch(L);
+        if (use_value_sorted(r1 - r0)) {
+            sample_value_sorted(P);
+            vs_batches += 1;
+        } else {
+            prepare(P);
+            SampleLaunch L{this, &P};
+            dispatch(L);
+            generic_batches += 1;
+        }
         HIP_CHECK(hipEventSynchronize(ev1));
         float ms = 0.f;
         HIP_CHECK(hipEventElapsedTime(&ms, ev0, ev1));
@@ -1346,6 +1494,24 @@ int dist_gibbs_packed_to_global(const dist_gibbs_t * g, uint32_t packed,
 int dist_gibbs_global_to_packed(const dist_gibbs_t * g, uint32_t global,
                                 uint32_t * out) {
     return guarded([&] { *out = g->impl->tracker.global_to_packed(global); });
+}
+int dist_gibbs_set_option(dist_gibbs_t * g, const char * name, int value) {
+    return guarded([&] {
+        const std::string key(name);
+        if (key == "value_sorted") {
+            DIST_REQUIRE(value >= 0 && value <= 2, "value_sorted: 0, 1 or 2");
+            g->impl->value_sorted_mode = value;
+        } else {
+            throw Error("unknown option: " + key);
+        }
+    });
+}
+int dist_gibbs_path_counts(const dist_gibbs_t * g, uint64_t * value_sorted,
+                           uint64_t * generic) {
+    return guarded([&] {
+        *value_sorted = g->impl->vs_batches;
+        *generic = g->impl->generic_batches;
+    });
 }
 int dist_gibbs_kernel_stats(dist_gibbs_t * g, double * ms_out,
                             uint64_t * launches_out, uint64_t * rows_out,

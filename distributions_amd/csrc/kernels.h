@@ -232,6 +232,10 @@ struct SweepParams {
     unsigned long long row_offset;   // global index of local row 0
     unsigned long long draw_base;
     uint32_t seed_state;
+    // when set, the generic kernel scores rows row_list[0 .. *row_list_count)
+    // (rows the value-sorted kernel handed over) instead of the whole range
+    const uint32_t * row_list;
+    const uint32_t * row_list_count;
 };
 
 // base[k], the scalars and (categorical feature 0) the folded k-major table
@@ -373,8 +377,12 @@ __global__ __launch_bounds__(kBlock) void k_sweep_sample(SweepParams P) {
     const int K = P.K;
 
     const size_t stride = (size_t)gridDim.x * kBlock;
-    for (size_t row = P.row_begin + (size_t)blockIdx.x * kBlock + threadIdx.x;
-         row < P.row_end; row += stride) {
+    const size_t n_items = P.row_list ? (size_t)*P.row_list_count
+                                      : P.row_end - P.row_begin;
+    for (size_t item = (size_t)blockIdx.x * kBlock + threadIdx.x;
+         item < n_items; item += stride) {
+        const size_t row = P.row_list ? (size_t)P.row_list[item]
+                                      : P.row_begin + item;
         const RowScorer<KIND0, KIND1, NF> rs(P, row);
         const int Kl = rs.Kl;
 
@@ -439,6 +447,235 @@ __global__ void k_score_rows(SweepParams P, float * __restrict__ out,
         s = accumulate(v.kind, s, load_entry(v, k, x), x, lf);
     }
     out[r * ld + k] = s;
+}
+
+// ---------------------------------------------------------------------------
+// The value-sorted row update (single feature with a small value domain:
+// DD, DPD, BB).
+//
+// Rows with the same value x see the same score vector s_x[k] except in their
+// own slot, and the own-slot score after self-removal never exceeds the
+// unpatched one in exact arithmetic, so the softmax shift m of a row is
+//   class A (own group is not the arg-max of s_x):  M[x]  = max_k s_x[k]
+//   class B (own group is the arg-max of s_x):      mB[x] = max(s_own, M2[x])
+// both functions of x alone.  The likelihood vectors
+//   LA[x][k] = fast_exp(s_x[k] - M[x]),  LB[x][k] = fast_exp(s_x[k] - mB[x])
+// are therefore computed once per value and batch (k_vs_prepare), and the
+// per-row work shrinks to the two order-sensitive recurrences (running sum,
+// subtractive scan) over wave-uniform inputs, with one per-lane exp for the
+// own slot.  Rows are pre-sorted by value (static: values never change), one
+// wave = one tile of <= 64 rows of one value.  Every float operation a row
+// performs is the one the generic kernel performs, in the same order; rows the
+// shortcut does not cover exactly (group of one member; own-slot score above
+// M[x] through table rounding; DPD OTHER) are handed to the generic kernel.
+
+struct VsTables {
+    float * LA;      // [nvals][Kpad]
+    float * LB;
+    float * M;       // [nvals]
+    float * mB;
+    int * argmax;    // [nvals], first index attaining the maximum
+    int Kpad;
+};
+struct VsTile {
+    uint32_t x;      // the tile's value
+    uint32_t pos;    // first position in the sorted row list
+    uint32_t n;      // rows in the tile (<= 64)
+};
+
+// score of a row with value x at its own slot g after removing itself
+__device__ __forceinline__ float vs_own_score(const SweepParams & P,
+                                              const SlaveView & v, int g,
+                                              int n_g, uint32_t x, float lf,
+                                              float shift) {
+    const float s = py_nonempty_score(n_g - 1, P.d) + shift;
+    return accumulate(v.kind, s, entry_after_remove(v, g, x), x, lf);
+}
+
+// does group g hold at least one row with value x?
+__device__ __forceinline__ bool vs_group_has_value(const SlaveView & v, int g,
+                                                   uint32_t x) {
+    if (is_cat(v.kind)) return v.cnt[(size_t)g * v.dim + x] >= 1;
+    return (x ? v.i0[g] : v.i1[g]) >= 1;   // BB: heads / tails
+}
+
+template <int KIND>
+__global__ __launch_bounds__(kBlock) void k_vs_prepare(SweepParams P,
+                                                       VsTables T) {
+    __shared__ float r_m1[kBlock], r_m2[kBlock];
+    __shared__ int r_i1[kBlock];
+    __shared__ float sh_M, sh_mB;
+    const uint32_t x = blockIdx.x;
+    SlaveView v = P.feat[0];
+    v.kind = KIND;
+    const int K = P.K;
+    const float lf = 0.f;
+    float * la = T.LA + (size_t)x * T.Kpad;
+    float * lb = T.LB + (size_t)x * T.Kpad;
+    // pass 1: scores, local (max, first arg-max, max of the rest)
+    float m1 = -INFINITY, m2 = -INFINITY;
+    int i1 = 0x7fffffff;
+    for (int k = threadIdx.x; k < K; k += kBlock) {
+        const float s = accumulate(KIND, P.base[k], load_entry(v, k, x), x, lf);
+        la[k] = s;
+        if (s > m1) { m2 = m1; m1 = s; i1 = k; }
+        else if (s > m2) m2 = s;
+    }
+    r_m1[threadIdx.x] = m1; r_m2[threadIdx.x] = m2; r_i1[threadIdx.x] = i1;
+    __syncthreads();
+    for (int off = kBlock / 2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            const float a1 = r_m1[threadIdx.x], a2 = r_m2[threadIdx.x];
+            const float b1 = r_m1[threadIdx.x + off], b2 = r_m2[threadIdx.x + off];
+            const int ai = r_i1[threadIdx.x], bi = r_i1[threadIdx.x + off];
+            float c1, c2; int ci;
+            if (a1 > b1 || (a1 == b1 && ai < bi)) {
+                c1 = a1; ci = ai; c2 = fmaxf(a2, b1);
+            } else {
+                c1 = b1; ci = bi; c2 = fmaxf(b2, a1);
+            }
+            r_m1[threadIdx.x] = c1; r_m2[threadIdx.x] = c2; r_i1[threadIdx.x] = ci;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float M = r_m1[0];
+        const int g = r_i1[0];
+        float mB = M;
+        const int n_g = P.counts[g];
+        if (n_g >= 2 && vs_group_has_value(v, g, x)) {
+            const float s_own =
+                vs_own_score(P, v, g, n_g, x, lf, P.scalars->shift);
+            mB = fmaxf(s_own, r_m2[0]);
+        }
+        T.M[x] = M; T.mB[x] = mB; T.argmax[x] = g;
+        sh_M = M; sh_mB = mB;
+    }
+    __syncthreads();
+    const float M = sh_M, mB = sh_mB;
+    const float ea = u2f(g_tables_dev.exp_ab[0]);
+    const float eb = u2f(g_tables_dev.exp_ab[1]);
+    for (int k = threadIdx.x; k < T.Kpad; k += kBlock) {
+        float a = 0.f, b = 0.f;
+        if (k < K) {
+            const float s = la[k];
+            a = fast_exp_nonpos(s - M, g_tables_dev.exp_table, ea, eb);
+            b = fast_exp_nonpos(s - mB, g_tables_dev.exp_table, ea, eb);
+        }
+        la[k] = a;
+        lb[k] = b;
+    }
+}
+
+constexpr int kVsUnroll = 8;
+
+template <int KIND>
+__global__ __launch_bounds__(kBlock) void k_vs_sample(
+        SweepParams P, VsTables T, const VsTile * __restrict__ tiles,
+        uint32_t n_tiles, const uint32_t * __restrict__ sorted_rows,
+        uint32_t * __restrict__ deferred, uint32_t * deferred_count) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t tile_id = __builtin_amdgcn_readfirstlane(
+        blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6));
+    if (tile_id >= n_tiles) return;
+    const uint32_t x = __builtin_amdgcn_readfirstlane(tiles[tile_id].x);
+    const uint32_t pos = __builtin_amdgcn_readfirstlane(tiles[tile_id].pos);
+    const uint32_t n = __builtin_amdgcn_readfirstlane(tiles[tile_id].n);
+    SlaveView v = P.feat[0];
+    v.kind = KIND;
+    const int K = P.K;
+    const float shift = P.scalars->shift;
+    const float M = T.M[x], mB = T.mB[x];
+    const int amax = T.argmax[x];
+
+    bool valid = (uint32_t)lane < n;
+    size_t row = 0;
+    int g = -1;
+    bool classB = false;
+    float l_own = 0.f, u = 0.f;
+    if (valid) {
+        row = P.row_begin + sorted_rows[pos + lane];
+        g = P.g2p[P.assign[row]];
+        const int n_g = P.counts[g];
+        classB = (g == amax);
+        float m = classB ? mB : M;
+        float s_own = 0.f;
+        bool defer = (n_g == 1);
+        if (!defer) {
+            s_own = vs_own_score(P, v, g, n_g, x, 0.f, shift);
+            defer = !classB && s_own > M;   // table rounding lifted it over M
+        }
+        if (defer) {
+            deferred[atomicAdd(deferred_count, 1u)] = (uint32_t)row;
+            valid = false;
+            g = -1;
+        } else {
+            l_own = fast_exp_nonpos(s_own - m, g_tables_dev.exp_table,
+                                    u2f(g_tables_dev.exp_ab[0]),
+                                    u2f(g_tables_dev.exp_ab[1]));
+            const unsigned long long draw =
+                P.draw_base + P.row_offset + (unsigned long long)row;
+            u = lcg_unif01(lcg_jump(P.seed_state, draw + 1ull));
+        }
+    }
+    if (!__any(valid)) return;
+    const float * __restrict__ la = T.LA + (size_t)x * T.Kpad;
+    const float * __restrict__ lb = T.LB + (size_t)x * T.Kpad;
+
+    // scores_to_likelihoods: total in index order (random.cc:100-103)
+    float total = 0.f;
+    for (int k0 = 0; k0 < K; k0 += kVsUnroll) {
+        float a[kVsUnroll], b[kVsUnroll];
+#pragma unroll
+        for (int j = 0; j < kVsUnroll; ++j) { a[j] = la[k0 + j]; b[j] = lb[k0 + j]; }
+#pragma unroll
+        for (int j = 0; j < kVsUnroll; ++j) {
+            float l = classB ? b[j] : a[j];
+            l = (k0 + j == g) ? l_own : l;
+            total += l;   // entries k >= K are zero-padded
+        }
+    }
+    // sample_from_likelihoods (random.hpp:316-333)
+    float t = total * u;
+    int found = -1;
+    for (int k0 = 0; k0 < K; k0 += kVsUnroll) {
+        float a[kVsUnroll], b[kVsUnroll];
+#pragma unroll
+        for (int j = 0; j < kVsUnroll; ++j) { a[j] = la[k0 + j]; b[j] = lb[k0 + j]; }
+#pragma unroll
+        for (int j = 0; j < kVsUnroll; ++j) {
+            float l = classB ? b[j] : a[j];
+            l = (k0 + j == g) ? l_own : l;
+            t -= l;
+            if (found < 0 && t <= 0.f && k0 + j < K) found = k0 + j;
+        }
+        if (__all(found >= 0 || !valid)) break;
+    }
+    if (valid) {
+        const int g2 = found < 0 ? K - 1 : found;
+        const size_t bidx = row - P.row_begin;
+        P.old_packed[bidx] = (uint32_t)g;
+        P.new_packed[bidx] = (uint32_t)g2;
+    }
+}
+
+// counting sort of a batch's rows by value (one-time per batch range)
+__global__ void k_vs_hist(const uint32_t * __restrict__ values,
+                          size_t row_begin, size_t n, uint32_t nvals,
+                          uint32_t * __restrict__ hist) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t x = values[row_begin + i];
+    atomicAdd(&hist[x < nvals ? x : nvals], 1u);   // last bin: OTHER
+}
+__global__ void k_vs_scatter(const uint32_t * __restrict__ values,
+                             size_t row_begin, size_t n, uint32_t nvals,
+                             uint32_t * __restrict__ cursor,
+                             uint32_t * __restrict__ sorted_rows) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t x = values[row_begin + i];
+    sorted_rows[atomicAdd(&cursor[x < nvals ? x : nvals], 1u)] = (uint32_t)i;
 }
 
 // ---------------------------------------------------------------------------

@@ -97,6 +97,12 @@ class Gibbs(object):
     def kernel_stats(self, reset=False):
         return self.core.kernel_stats(reset)
 
+    def set_option(self, name, value):
+        self.core.set_option(name, value)
+
+    def path_counts(self):
+        return self.core.path_counts()
+
 
 class ShardedGibbs(object):
     """Row-sharded Gibbs over the ranks of a torch.distributed process group.

@@ -245,6 +245,12 @@ int dist_gibbs_packed_to_global(const dist_gibbs_t * g, uint32_t packed,
                                 uint32_t * global_out);
 int dist_gibbs_global_to_packed(const dist_gibbs_t * g, uint32_t global,
                                 uint32_t * packed_out);
+/* options: "value_sorted" = 0 (generic kernel only), 1 (auto, default),
+ * 2 (value-sorted kernel whenever the feature list allows it) */
+int dist_gibbs_set_option(dist_gibbs_t * g, const char * name, int value);
+/* how many batches each score+sample kernel has served */
+int dist_gibbs_path_counts(const dist_gibbs_t * g, uint64_t * value_sorted,
+                           uint64_t * generic);
 /* HIP-event time (ms) and launch count of the score+sample kernel since the
  * last reset, measured on the engine's stream */
 int dist_gibbs_kernel_stats(dist_gibbs_t * g, double * ms_out,

@@ -10,12 +10,20 @@ import workloads
 pytestmark = pytest.mark.gpu
 
 
-def both(config, n, k, alpha, d, empty=1, dim=None, seed=workloads.SEED):
+VS_ELIGIBLE = ("dd", "dd_skew", "bb", "dpd", "dpd_other")
+
+
+def both(config, n, k, alpha, d, empty=1, dim=None, seed=workloads.SEED,
+         mode=None):
+    """mode: None = library default; 0 = generic kernel only; 2 = the
+    value-sorted kernel whenever the feature list allows it."""
     from distributions_amd import engine
     osh, gsh, vals, assign = workloads.make(config, n, k, seed=seed, dim=dim)
     orc = ol.OracleMixture(alpha, d, osh)
     orc.init_from_assignments(vals, assign, k, empty)
     gpu = engine.Gibbs(alpha, d, gsh)
+    if mode is not None:
+        gpu.set_option("value_sorted", mode)
     gpu.load_rows(vals, assign, k, empty)
     return orc, gpu
 
@@ -34,7 +42,8 @@ def assert_same_state(orc, gpu, what=""):
                 err_msg="%s feature %d group %d" % (what, f, g))
 
 
-CONFIGS = ["dd", "dd_skew", "bb", "gp", "nich", "gp_nich", "dpd", "dd_bb_gp"]
+CONFIGS = ["dd", "dd_skew", "bb", "gp", "nich", "gp_nich", "dpd",
+           "dpd_other", "dd_bb_gp"]
 
 
 @pytest.mark.parametrize("config", CONFIGS)
@@ -61,9 +70,12 @@ def test_row_scores_match_oracle(config):
 
 @pytest.mark.parametrize("config", CONFIGS)
 @pytest.mark.parametrize("batch", [256, 1000, 4096])
-def test_batch_sweeps_bit_exact(config, batch):
+@pytest.mark.parametrize("mode", [0, 2])
+def test_batch_sweeps_bit_exact(config, batch, mode):
+    if mode == 2 and config not in VS_ELIGIBLE:
+        pytest.skip("value-sorted kernel needs one small-domain feature")
     n, k = 4096, 32
-    orc, gpu = both(config, n, k, 1.0, 0.2)
+    orc, gpu = both(config, n, k, 1.0, 0.2, mode=mode)
     seed = 12345
     st = ol.oracle().orc_rng_seed(seed)
     for sweep in range(2):
@@ -72,6 +84,25 @@ def test_batch_sweeps_bit_exact(config, batch):
             orc.gibbs_batch(b, min(n, b + batch), st, base)
         gpu.sweep(0, n, batch, seed, draw_base=base)
         assert_same_state(orc, gpu, "%s sweep %d batch %d" % (config, sweep, batch))
+    vs, generic = gpu.path_counts()
+    assert (vs > 0 and generic == 0) if mode == 2 else (vs == 0)
+
+
+@pytest.mark.parametrize("config,dim,k", [("dd", 256, 64), ("dd_skew", 64, 16),
+                                          ("dpd_other", 300, 24), ("bb", None, 8)])
+def test_value_sorted_larger_batches(config, dim, k):
+    """default mode picks the value-sorted kernel for large batches; groups of
+    very different sizes make rows sit in the arg-max group (class B)."""
+    n = 60000
+    orc, gpu = both(config, n, k, 1.0, 0.1, dim=dim)
+    seed = 2024
+    st = ol.oracle().orc_rng_seed(seed)
+    for sweep in range(3):
+        for b in range(0, n, 20000):
+            orc.gibbs_batch(b, b + 20000, st, sweep * n)
+        gpu.sweep(0, n, 20000, seed, draw_base=sweep * n)
+        assert_same_state(orc, gpu, "%s sweep %d" % (config, sweep))
+    assert gpu.path_counts()[0] == 9
 
 
 @pytest.mark.parametrize("config", ["dd", "gp_nich", "bb"])
@@ -86,13 +117,14 @@ def test_sequential_chain_bit_exact(config):
     assert_same_state(orc, gpu, config + " sequential")
 
 
-@pytest.mark.parametrize("config", ["dd", "gp_nich"])
+@pytest.mark.parametrize("config,mode", [("dd", 0), ("dd", 2), ("gp_nich", 0),
+                                         ("bb", 2)])
 @pytest.mark.parametrize("empty", [1, 3])
-def test_group_creation_and_removal(config, empty):
+def test_group_creation_and_removal(config, mode, empty):
     """Many groups, few rows, large alpha: rows are alone in their group,
     groups die and empty groups get filled (mixture.hpp:84-89,108-119)."""
     n, k = 96, 48
-    orc, gpu = both(config, n, k, 20.0, 0.5, empty=empty)
+    orc, gpu = both(config, n, k, 20.0, 0.5, empty=empty, mode=mode)
     seed = 99
     st = ol.oracle().orc_rng_seed(seed)
     for sweep in range(4):

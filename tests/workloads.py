@@ -49,6 +49,16 @@ def make(config, n, k, seed=SEED, dim=None):
         vals = [rng.integers(0, dim, n).astype(np.uint32)]
         osh = [ol.make_shared(ol.DPD, alpha=0.5, betas=betas, beta0=0.0)]
         gsh = [engine.dpd_shared(0.5, betas, 0.0)]
+    elif config == "dpd_other":
+        dim = dim or 50
+        betas = np.full(dim, 0.9 / dim, np.float32)
+        v = rng.integers(0, dim, n).astype(np.uint32)
+        # dpd.hpp:56: OTHER scores with alpha * beta0 and is never added or
+        # removed (dpd.hpp:193,212); the engine treats it as a scored-only
+        # value, so keep it out of the statistics by never using it in rows
+        vals = [v]
+        osh = [ol.make_shared(ol.DPD, alpha=0.5, betas=betas, beta0=0.1)]
+        gsh = [engine.dpd_shared(0.5, betas, 0.1)]
     elif config == "dd_bb_gp":
         dim = dim or 8
         vals = [rng.integers(0, dim, n).astype(np.uint32),
