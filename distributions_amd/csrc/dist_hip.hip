@@ -481,6 +481,7 @@ struct Gibbs {
 
     size_t batch_begin = 0, batch_end = 0;   // rows of the open batch
     bool batch_open = false;
+    bool batch_value_sorted = false;
 
     // value-sorted path (single small-domain feature): rows of a batch range
     // sorted by value once, tiles of <= 64 equal-valued rows
@@ -489,6 +490,8 @@ struct Gibbs {
         DeviceBuf<uint32_t> sorted_rows;
         DeviceBuf<VsTile> tiles;
         uint32_t n_tiles = 0;
+        DeviceBuf<VsTile> chunks;          // apply work items, one value each
+        uint32_t n_chunks = 0;
         DeviceBuf<uint32_t> other_rows;   // rows the tiles do not cover
         uint32_t n_other = 0;
     };
@@ -777,6 +780,14 @@ struct Gibbs {
                                        std::min<uint32_t>(64, h[x] - off)});
         c->n_tiles = (uint32_t)tiles.size();
         c->tiles.upload(tiles.data(), tiles.size());
+        std::vector<VsTile> chunks;
+        for (uint32_t x = 0; x <= nv; ++x)
+            for (uint32_t off = 0; off < h[x]; off += kVsApplyRows)
+                chunks.push_back(VsTile{x, start[x] + off,
+                                        std::min<uint32_t>(kVsApplyRows,
+                                                           h[x] - off)});
+        c->n_chunks = (uint32_t)chunks.size();
+        c->chunks.upload(chunks.data(), chunks.size());
         // rows whose value is outside the table (DPD OTHER): generic kernel
         c->n_other = h[nv];
         if (c->n_other) {
@@ -870,10 +881,12 @@ struct Gibbs {
         batch_begin = r0;
         batch_end = r1;
         batch_open = true;
+        batch_value_sorted = false;
         if (r0 == r1) return;
         upload_maps();
         SweepParams P = params(r0, r1, seed, draw_base);
-        if (use_value_sorted(r1 - r0)) {
+        batch_value_sorted = use_value_sorted(r1 - r0);
+        if (batch_value_sorted) {
             sample_value_sorted(P);
             vs_batches += 1;
         } else {
@@ -902,12 +915,37 @@ struct Gibbs {
         }
     }
 
+    // integer statistics of the open batch into `img` (live arrays or a
+    // zeroed delta image)
+    void apply_ints(StatImage img) {
+        const size_t n = batch_end - batch_begin;
+        SweepParams P = params(batch_begin, batch_end, 0, 0);
+        if (batch_value_sorted && (size_t)K() * 4 <= 48 * 1024) {
+            VsCache & c = vs_get(batch_begin, batch_end);
+            const size_t lds = (size_t)K() * 4;
+            switch (feats[0]->sh.kind) {
+            case DIST_BB:
+                hipLaunchKernelGGL((k_vs_apply<DIST_BB>), dim3(c.n_chunks),
+                                   dim3(kBlock), lds, stream(), P, img,
+                                   c.chunks.p, c.sorted_rows.p, d_p2g.p,
+                                   assign);
+                break;
+            default:
+                hipLaunchKernelGGL((k_vs_apply<DIST_DD>), dim3(c.n_chunks),
+                                   dim3(kBlock), lds, stream(), P, img,
+                                   c.chunks.p, c.sorted_rows.p, d_p2g.p,
+                                   assign);
+                break;
+            }
+            HIP_CHECK(hipGetLastError());
+        } else {
+            LAUNCH(k_apply_moves, n, P, img, d_p2g.p, assign);
+        }
+    }
     void batch_apply_local() {
         DIST_REQUIRE(batch_open, "no open batch");
-        const size_t n = batch_end - batch_begin;
-        if (!n) return;
-        SweepParams P = params(batch_begin, batch_end, 0, 0);
-        LAUNCH(k_apply_moves, n, P, live_image(), d_p2g.p, assign);
+        if (batch_end == batch_begin) return;
+        apply_ints(live_image());
         replay_floats();
     }
     void batch_delta(int32_t * delta_dev) {
@@ -917,10 +955,8 @@ struct Gibbs {
                          "NormalInverseChiSq statistics are order-dependent: "
                          "no integer delta (single-GPU only in this round)");
         HIP_CHECK(hipMemsetAsync(delta_dev, 0, stat_words() * 4, stream()));
-        const size_t n = batch_end - batch_begin;
-        if (!n) return;
-        SweepParams P = params(batch_begin, batch_end, 0, 0);
-        LAUNCH(k_apply_moves, n, P, word_image(delta_dev), d_p2g.p, assign);
+        if (batch_end == batch_begin) return;
+        apply_ints(word_image(delta_dev));
     }
     void batch_apply_delta(const int32_t * delta_dev) {
         DIST_REQUIRE(batch_open, "no open batch");

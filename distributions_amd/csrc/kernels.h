@@ -238,6 +238,17 @@ struct SweepParams {
     const uint32_t * row_list_count;
 };
 
+// Integer statistics are exact under atomics.  `stats` is either the live
+// state or a zeroed delta image in the stat-word layout:
+//   counts[K] | per feature: i0[K] i1[K] (categorical: cnt[K][dim])
+// NormalInverseChiSq's count moves with its float statistics in k_replay.
+struct StatImage {
+    int32_t * counts;
+    int32_t * i0[kMaxF];
+    int32_t * i1[kMaxF];
+    int32_t * cnt[kMaxF];
+};
+
 // base[k], the scalars and (categorical feature 0) the folded k-major table
 //   table0[k][v] = (base[k] + S[v][k]) - shift0[k]
 // which is the row score for value v at group k when no self-removal applies;
@@ -567,7 +578,48 @@ __global__ __launch_bounds__(kBlock) void k_vs_prepare(SweepParams P,
     }
 }
 
-constexpr int kVsUnroll = 8;
+constexpr int kVsUnroll = 16;
+
+// wave-uniform read-only data: loads through the constant address space are
+// issued as scalar loads (s_load_dwordx8/x16) when the address is uniform
+typedef const float __attribute__((address_space(4))) * uniform_fp;
+__device__ __forceinline__ uniform_fp as_uniform(const float * p) {
+    return (uniform_fp)(unsigned long long)p;
+}
+
+// The two order-sensitive recurrences for the lanes whose likelihood vector
+// is `lp` (wave-uniform), own slot replaced by the lane's l_own:
+//   total = ((l_0 + l_1) + l_2) + ...                  random.cc:100-103
+//   t = total*u; t -= l_k until t <= 0                 random.hpp:323-330
+// Subtracting non-negative terms never increases t, so the index of the first
+// t <= 0 equals the number of steps after which t is still positive.
+__device__ __forceinline__ int vs_sum_and_scan(uniform_fp lp, int K, int g,
+                                               float l_own, float u,
+                                               bool active) {
+    float total = 0.f;
+    for (int k0 = 0; k0 < K; k0 += kVsUnroll) {
+        float l[kVsUnroll];
+#pragma unroll
+        for (int j = 0; j < kVsUnroll; ++j) l[j] = lp[k0 + j];
+#pragma unroll
+        for (int j = 0; j < kVsUnroll; ++j)
+            total += (k0 + j == g) ? l_own : l[j];   // k >= K: zero padding
+    }
+    float t = total * u;
+    int steps = 0;
+    for (int k0 = 0; k0 < K; k0 += kVsUnroll) {
+        float l[kVsUnroll];
+#pragma unroll
+        for (int j = 0; j < kVsUnroll; ++j) l[j] = lp[k0 + j];
+#pragma unroll
+        for (int j = 0; j < kVsUnroll; ++j) {
+            t -= (k0 + j == g) ? l_own : l[j];
+            steps += (t > 0.f) ? 1 : 0;
+        }
+        if (!__any(active && t > 0.f)) break;
+    }
+    return steps < K - 1 ? steps : K - 1;
+}
 
 template <int KIND>
 __global__ __launch_bounds__(kBlock) void k_vs_sample(
@@ -598,7 +650,7 @@ __global__ __launch_bounds__(kBlock) void k_vs_sample(
         g = P.g2p[P.assign[row]];
         const int n_g = P.counts[g];
         classB = (g == amax);
-        float m = classB ? mB : M;
+        const float m = classB ? mB : M;
         float s_own = 0.f;
         bool defer = (n_g == 1);
         if (!defer) {
@@ -608,7 +660,6 @@ __global__ __launch_bounds__(kBlock) void k_vs_sample(
         if (defer) {
             deferred[atomicAdd(deferred_count, 1u)] = (uint32_t)row;
             valid = false;
-            g = -1;
         } else {
             l_own = fast_exp_nonpos(s_own - m, g_tables_dev.exp_table,
                                     u2f(g_tables_dev.exp_ab[0]),
@@ -618,44 +669,66 @@ __global__ __launch_bounds__(kBlock) void k_vs_sample(
             u = lcg_unif01(lcg_jump(P.seed_state, draw + 1ull));
         }
     }
-    if (!__any(valid)) return;
-    const float * __restrict__ la = T.LA + (size_t)x * T.Kpad;
-    const float * __restrict__ lb = T.LB + (size_t)x * T.Kpad;
-
-    // scores_to_likelihoods: total in index order (random.cc:100-103)
-    float total = 0.f;
-    for (int k0 = 0; k0 < K; k0 += kVsUnroll) {
-        float a[kVsUnroll], b[kVsUnroll];
-#pragma unroll
-        for (int j = 0; j < kVsUnroll; ++j) { a[j] = la[k0 + j]; b[j] = lb[k0 + j]; }
-#pragma unroll
-        for (int j = 0; j < kVsUnroll; ++j) {
-            float l = classB ? b[j] : a[j];
-            l = (k0 + j == g) ? l_own : l;
-            total += l;   // entries k >= K are zero-padded
-        }
+    const bool inA = valid && !classB, inB = valid && classB;
+    int g2 = 0;
+    if (__any(inA)) {
+        const int r = vs_sum_and_scan(as_uniform(T.LA + (size_t)x * T.Kpad), K,
+                                      g, l_own, u, inA);
+        g2 = inA ? r : g2;
     }
-    // sample_from_likelihoods (random.hpp:316-333)
-    float t = total * u;
-    int found = -1;
-    for (int k0 = 0; k0 < K; k0 += kVsUnroll) {
-        float a[kVsUnroll], b[kVsUnroll];
-#pragma unroll
-        for (int j = 0; j < kVsUnroll; ++j) { a[j] = la[k0 + j]; b[j] = lb[k0 + j]; }
-#pragma unroll
-        for (int j = 0; j < kVsUnroll; ++j) {
-            float l = classB ? b[j] : a[j];
-            l = (k0 + j == g) ? l_own : l;
-            t -= l;
-            if (found < 0 && t <= 0.f && k0 + j < K) found = k0 + j;
-        }
-        if (__all(found >= 0 || !valid)) break;
+    if (__any(inB)) {
+        const int r = vs_sum_and_scan(as_uniform(T.LB + (size_t)x * T.Kpad), K,
+                                      g, l_own, u, inB);
+        g2 = inB ? r : g2;
     }
     if (valid) {
-        const int g2 = found < 0 ? K - 1 : found;
         const size_t bidx = row - P.row_begin;
         P.old_packed[bidx] = (uint32_t)g;
         P.new_packed[bidx] = (uint32_t)g2;
+    }
+}
+
+// Applying a batch's moves in value-sorted order: one workgroup takes up to
+// kVsApplyRows rows of ONE value x, accumulates the per-group change in LDS
+// and flushes each non-zero entry with one global atomic per statistic:
+//   counts[k] += d[k];  DD/DPD: count_sum[k] += d[k], cnt[k][x] += d[k];
+//   BB: (x ? heads : tails)[k] += d[k]
+// (6 global atomics per moved row become <= 3 per touched group and chunk).
+constexpr int kVsApplyRows = 2048;
+
+template <int KIND>
+__global__ __launch_bounds__(kBlock) void k_vs_apply(
+        SweepParams P, StatImage img, const VsTile * __restrict__ chunks,
+        const uint32_t * __restrict__ sorted_rows,
+        const uint32_t * __restrict__ p2g, uint32_t * __restrict__ assign) {
+    extern __shared__ int vs_delta[];
+    const int K = P.K;
+    const uint32_t x = chunks[blockIdx.x].x;
+    const uint32_t pos = chunks[blockIdx.x].pos;
+    const uint32_t n = chunks[blockIdx.x].n;
+    for (int k = threadIdx.x; k < K; k += kBlock) vs_delta[k] = 0;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += kBlock) {
+        const uint32_t b = sorted_rows[pos + i];
+        const uint32_t go = P.old_packed[b], gn = P.new_packed[b];
+        if (assign) assign[P.row_begin + b] = p2g[gn];
+        if (go != gn) {
+            atomicAdd(&vs_delta[go], -1);
+            atomicAdd(&vs_delta[gn], 1);
+        }
+    }
+    __syncthreads();
+    const int dim = P.feat[0].dim;
+    for (int k = threadIdx.x; k < K; k += kBlock) {
+        const int dlt = vs_delta[k];
+        if (dlt == 0) continue;
+        atomicAdd(&img.counts[k], dlt);
+        if (KIND == DIST_BB) {
+            atomicAdd(x ? &img.i0[0][k] : &img.i1[0][k], dlt);
+        } else {
+            atomicAdd(&img.i0[0][k], dlt);
+            atomicAdd(&img.cnt[0][(size_t)k * dim + x], dlt);
+        }
     }
 }
 
@@ -680,17 +753,6 @@ __global__ void k_vs_scatter(const uint32_t * __restrict__ values,
 
 // ---------------------------------------------------------------------------
 // applying a batch of moves
-
-// Integer statistics are exact under atomics.  `stats` is either the live
-// state or a zeroed delta image in the stat-word layout:
-//   counts[K] | per feature: i0[K] i1[K] (categorical: cnt[K][dim])
-// NormalInverseChiSq's count moves with its float statistics in k_replay.
-struct StatImage {
-    int32_t * counts;
-    int32_t * i0[kMaxF];
-    int32_t * i1[kMaxF];
-    int32_t * cnt[kMaxF];
-};
 
 __global__ void k_apply_moves(SweepParams P, StatImage img,
                               const uint32_t * __restrict__ p2g,
