@@ -474,6 +474,8 @@ struct Gibbs {
     bool maps_dirty = true;
 
     DeviceBuf<uint32_t> old_packed, new_packed;
+    DeviceBuf<uint32_t> pow_lo, pow_hi;   // 16807^i, 16807^(4096 i) mod 2^31-1
+    uint32_t n_pow_hi = 0;
     DeviceBuf<float> base, table0;
     DeviceBuf<SweepScalars> scalars;
     DeviceBuf<float> row_scores;
@@ -559,7 +561,22 @@ struct Gibbs {
         P.row_offset = row_offset;
         P.draw_base = draw_base;
         P.seed_state = seed;
+        // the state one step before the first row's draw, then per-row powers
+        P.seed_batch = lcg_jump(seed, draw_base + row_offset + r0 + 1ull);
+        ensure_pow_tables(r1 - r0);
+        P.pow_lo = pow_lo.p;
+        P.pow_hi = pow_hi.p;
         return P;
+    }
+
+    void ensure_pow_tables(size_t batch_rows) {
+        const uint32_t need = (uint32_t)(batch_rows / 4096 + 1);
+        if (pow_lo.p && need <= n_pow_hi) return;
+        n_pow_hi = std::max<uint32_t>(4096, need * 2);
+        pow_lo.reserve(4096, 0);
+        pow_hi.reserve(n_pow_hi, 0);
+        LAUNCH(k_pow_tables, (size_t)std::max<uint32_t>(4096, n_pow_hi),
+               pow_lo.p, pow_hi.p, n_pow_hi);
     }
 
     StatImage live_image() {
@@ -920,23 +937,23 @@ struct Gibbs {
     void apply_ints(StatImage img) {
         const size_t n = batch_end - batch_begin;
         SweepParams P = params(batch_begin, batch_end, 0, 0);
-        if (batch_value_sorted && (size_t)K() * 4 <= 48 * 1024) {
+        const size_t lds_sort =
+            ((size_t)K() * 2 + kBlock + 2 * kVsApplyRows) * 4;
+        const size_t lds_plain = (size_t)K() * 4;
+        if (batch_value_sorted && lds_plain <= 60 * 1024) {
             VsCache & c = vs_get(batch_begin, batch_end);
-            const size_t lds = (size_t)K() * 4;
-            switch (feats[0]->sh.kind) {
-            case DIST_BB:
-                hipLaunchKernelGGL((k_vs_apply<DIST_BB>), dim3(c.n_chunks),
-                                   dim3(kBlock), lds, stream(), P, img,
-                                   c.chunks.p, c.sorted_rows.p, d_p2g.p,
-                                   assign);
-                break;
-            default:
-                hipLaunchKernelGGL((k_vs_apply<DIST_DD>), dim3(c.n_chunks),
-                                   dim3(kBlock), lds, stream(), P, img,
-                                   c.chunks.p, c.sorted_rows.p, d_p2g.p,
-                                   assign);
-                break;
-            }
+            const bool sort = lds_sort <= 60 * 1024;
+            const bool bb = feats[0]->sh.kind == DIST_BB;
+            const dim3 grid(c.n_chunks), block(kBlock);
+#define VS_APPLY(KIND, SORT, LDS)                                            \
+            hipLaunchKernelGGL((k_vs_apply<KIND, SORT>), grid, block, LDS,   \
+                               stream(), P, img, c.chunks.p,                 \
+                               c.sorted_rows.p, d_p2g.p, assign)
+            if (bb && sort) VS_APPLY(DIST_BB, true, lds_sort);
+            else if (bb) VS_APPLY(DIST_BB, false, lds_plain);
+            else if (sort) VS_APPLY(DIST_DD, true, lds_sort);
+            else VS_APPLY(DIST_DD, false, lds_plain);
+#undef VS_APPLY
             HIP_CHECK(hipGetLastError());
         } else {
             LAUNCH(k_apply_moves, n, P, img, d_p2g.p, assign);

@@ -232,6 +232,12 @@ struct SweepParams {
     unsigned long long row_offset;   // global index of local row 0
     unsigned long long draw_base;
     uint32_t seed_state;
+    // entropy of the open batch: row (row_begin + b) draws with engine state
+    //   seed_batch * 16807^b  =  seed_state * 16807^(draw_base+row_offset+row+1)
+    // 16807^b = pow_lo[b & 4095] * pow_hi[b >> 12]   (mod 2^31-1)
+    uint32_t seed_batch;
+    const uint32_t * pow_lo;   // [4096]  16807^i
+    const uint32_t * pow_hi;   // [..]    16807^(4096 i)
     // when set, the generic kernel scores rows row_list[0 .. *row_list_count)
     // (rows the value-sorted kernel handed over) instead of the whole range
     const uint32_t * row_list;
@@ -248,6 +254,23 @@ struct StatImage {
     int32_t * i1[kMaxF];
     int32_t * cnt[kMaxF];
 };
+
+// sample_unif01 of batch row b (random.hpp:47-50): one engine step per row,
+// the step the sequential chain would have used for it
+__device__ __forceinline__ float batch_row_unif01(const SweepParams & P,
+                                                  size_t row) {
+    const size_t b = row - P.row_begin;
+    uint32_t xs = lcg_mulmod(P.seed_batch, P.pow_lo[b & 4095]);
+    xs = lcg_mulmod(xs, P.pow_hi[b >> 12]);
+    return lcg_unif01(xs);
+}
+
+__global__ void k_pow_tables(uint32_t * pow_lo, uint32_t * pow_hi,
+                             uint32_t n_hi) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 4096) pow_lo[i] = lcg_jump(1u, i);
+    if (i < n_hi) pow_hi[i] = lcg_jump(1u, 4096ull * i);
+}
 
 // base[k], the scalars and (categorical feature 0) the folded k-major table
 //   table0[k][v] = (base[k] + S[v][k]) - shift0[k]
@@ -410,10 +433,7 @@ __global__ __launch_bounds__(kBlock) void k_sweep_sample(SweepParams P) {
             total += (k < Kl) ? l : 0.f;
         }
         // sample_unif01: engine step (draw_base + global row + 1)
-        const unsigned long long draw =
-            P.draw_base + P.row_offset + (unsigned long long)row;
-        const uint32_t xs = lcg_jump(P.seed_state, draw + 1ull);
-        const float u = lcg_unif01(xs);
+        const float u = batch_row_unif01(P, row);
         // sample_from_likelihoods
         float t = total * u;
         int found = -1;
@@ -591,34 +611,67 @@ __device__ __forceinline__ uniform_fp as_uniform(const float * p) {
 // is `lp` (wave-uniform), own slot replaced by the lane's l_own:
 //   total = ((l_0 + l_1) + l_2) + ...                  random.cc:100-103
 //   t = total*u; t -= l_k until t <= 0                 random.hpp:323-330
-// Subtracting non-negative terms never increases t, so the index of the first
-// t <= 0 equals the number of steps after which t is still positive.
-__device__ __forceinline__ int vs_sum_and_scan(uniform_fp lp, int K, int g,
-                                               float l_own, float u,
+// The vector is consumed in chunks of 16 scalar-loaded entries.  A chunk that
+// holds no lane's own slot is pure uniform arithmetic (one VALU op per entry
+// and pass); a chunk that does takes the per-lane select.  Subtracting
+// non-negative terms never increases t, so each lane crosses zero in exactly
+// one chunk; the scan only records that chunk and the value of t on entry,
+// and the lane then replays its 16 subtractions to get the exact index.
+__device__ __forceinline__ int vs_sum_and_scan(uniform_fp lp,
+                                               const float * lp_vec, int K,
+                                               int g, float l_own, float u,
                                                bool active) {
+    const int gchunk = active ? (g / kVsUnroll) : -1;
     float total = 0.f;
-    for (int k0 = 0; k0 < K; k0 += kVsUnroll) {
+    for (int c = 0, k0 = 0; k0 < K; ++c, k0 += kVsUnroll) {
         float l[kVsUnroll];
 #pragma unroll
         for (int j = 0; j < kVsUnroll; ++j) l[j] = lp[k0 + j];
+        if (__any(gchunk == c)) {
 #pragma unroll
-        for (int j = 0; j < kVsUnroll; ++j)
-            total += (k0 + j == g) ? l_own : l[j];   // k >= K: zero padding
+            for (int j = 0; j < kVsUnroll; ++j)
+                total += (k0 + j == g) ? l_own : l[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < kVsUnroll; ++j) total += l[j];
+        }
     }
     float t = total * u;
-    int steps = 0;
-    for (int k0 = 0; k0 < K; k0 += kVsUnroll) {
+    int cross = -1;
+    float t_start = 0.f;
+    for (int c = 0, k0 = 0; k0 < K; ++c, k0 += kVsUnroll) {
+        const float t0 = t;
         float l[kVsUnroll];
 #pragma unroll
         for (int j = 0; j < kVsUnroll; ++j) l[j] = lp[k0 + j];
+        if (__any(gchunk == c)) {
 #pragma unroll
-        for (int j = 0; j < kVsUnroll; ++j) {
-            t -= (k0 + j == g) ? l_own : l[j];
-            steps += (t > 0.f) ? 1 : 0;
+            for (int j = 0; j < kVsUnroll; ++j)
+                t -= (k0 + j == g) ? l_own : l[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < kVsUnroll; ++j) t -= l[j];
         }
+        // the walk starts "above zero" by definition: a first t <= 0 at k = 0
+        // is index 0 (random.hpp:326-329)
+        const bool crossed = (c == 0 || t0 > 0.f) && !(t > 0.f);
+        cross = crossed ? c : cross;
+        t_start = crossed ? t0 : t_start;
         if (!__any(active && t > 0.f)) break;
     }
-    return steps < K - 1 ? steps : K - 1;
+    int found = K - 1;
+    if (active && cross >= 0) {
+        float tt = t_start;
+        int steps = 0;
+#pragma unroll
+        for (int j = 0; j < kVsUnroll; ++j) {
+            const int k = cross * kVsUnroll + j;
+            tt -= (k == g) ? l_own : lp_vec[k];
+            steps += (tt > 0.f) ? 1 : 0;
+        }
+        found = cross * kVsUnroll + steps;
+    }
+    return found < K - 1 ? found : K - 1;
 }
 
 template <int KIND>
@@ -664,21 +717,21 @@ __global__ __launch_bounds__(kBlock) void k_vs_sample(
             l_own = fast_exp_nonpos(s_own - m, g_tables_dev.exp_table,
                                     u2f(g_tables_dev.exp_ab[0]),
                                     u2f(g_tables_dev.exp_ab[1]));
-            const unsigned long long draw =
-                P.draw_base + P.row_offset + (unsigned long long)row;
-            u = lcg_unif01(lcg_jump(P.seed_state, draw + 1ull));
+            u = batch_row_unif01(P, row);
         }
     }
     const bool inA = valid && !classB, inB = valid && classB;
     int g2 = 0;
     if (__any(inA)) {
-        const int r = vs_sum_and_scan(as_uniform(T.LA + (size_t)x * T.Kpad), K,
-                                      g, l_own, u, inA);
+        const float * vec = T.LA + (size_t)x * T.Kpad;
+        const int r = vs_sum_and_scan(as_uniform(vec), vec, K, g, l_own, u,
+                                      inA);
         g2 = inA ? r : g2;
     }
     if (__any(inB)) {
-        const int r = vs_sum_and_scan(as_uniform(T.LB + (size_t)x * T.Kpad), K,
-                                      g, l_own, u, inB);
+        const float * vec = T.LB + (size_t)x * T.Kpad;
+        const int r = vs_sum_and_scan(as_uniform(vec), vec, K, g, l_own, u,
+                                      inB);
         g2 = inB ? r : g2;
     }
     if (valid) {
@@ -696,31 +749,50 @@ __global__ __launch_bounds__(kBlock) void k_vs_sample(
 // (6 global atomics per moved row become <= 3 per touched group and chunk).
 constexpr int kVsApplyRows = 2048;
 
-template <int KIND>
+// SORT: also reorder the chunk's rows by their NEW group (LDS counting sort),
+// in place in sorted_rows.  Next time this batch range is sampled, the 64
+// rows of a tile then sit in a narrow band of groups, so almost every
+// 16-entry chunk of the likelihood vector is free of own slots (see
+// vs_sum_and_scan).  The order is a performance hint only: results do not
+// depend on it.
+template <int KIND, bool SORT>
 __global__ __launch_bounds__(kBlock) void k_vs_apply(
         SweepParams P, StatImage img, const VsTile * __restrict__ chunks,
-        const uint32_t * __restrict__ sorted_rows,
+        uint32_t * __restrict__ sorted_rows,
         const uint32_t * __restrict__ p2g, uint32_t * __restrict__ assign) {
-    extern __shared__ int vs_delta[];
+    extern __shared__ int vs_lds[];
     const int K = P.K;
+    int * delta = vs_lds;                 // [K]
+    int * hist = vs_lds + K;              // [K]           (SORT)
+    int * part = hist + K;                // [kBlock]      (SORT)
+    uint32_t * rows_l = (uint32_t *)(part + kBlock);       // [kVsApplyRows]
+    uint32_t * gn_l = rows_l + kVsApplyRows;               // [kVsApplyRows]
     const uint32_t x = chunks[blockIdx.x].x;
     const uint32_t pos = chunks[blockIdx.x].pos;
     const uint32_t n = chunks[blockIdx.x].n;
-    for (int k = threadIdx.x; k < K; k += kBlock) vs_delta[k] = 0;
+    for (int k = threadIdx.x; k < K; k += kBlock) {
+        delta[k] = 0;
+        if (SORT) hist[k] = 0;
+    }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < n; i += kBlock) {
         const uint32_t b = sorted_rows[pos + i];
         const uint32_t go = P.old_packed[b], gn = P.new_packed[b];
         if (assign) assign[P.row_begin + b] = p2g[gn];
         if (go != gn) {
-            atomicAdd(&vs_delta[go], -1);
-            atomicAdd(&vs_delta[gn], 1);
+            atomicAdd(&delta[go], -1);
+            atomicAdd(&delta[gn], 1);
+        }
+        if (SORT) {
+            rows_l[i] = b;
+            gn_l[i] = gn;
+            atomicAdd(&hist[gn], 1);
         }
     }
     __syncthreads();
     const int dim = P.feat[0].dim;
     for (int k = threadIdx.x; k < K; k += kBlock) {
-        const int dlt = vs_delta[k];
+        const int dlt = delta[k];
         if (dlt == 0) continue;
         atomicAdd(&img.counts[k], dlt);
         if (KIND == DIST_BB) {
@@ -729,6 +801,32 @@ __global__ __launch_bounds__(kBlock) void k_vs_apply(
             atomicAdd(&img.i0[0][k], dlt);
             atomicAdd(&img.cnt[0][(size_t)k * dim + x], dlt);
         }
+    }
+    if (!SORT) return;
+    // exclusive scan of hist over k (each thread owns a contiguous slice)
+    const int per = (K + kBlock - 1) / kBlock;
+    const int lo = threadIdx.x * per;
+    const int hi = lo + per < K ? lo + per : K;
+    int sum = 0;
+    for (int k = lo; k < hi; ++k) sum += hist[k];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int off = 1; off < kBlock; off <<= 1) {
+        const int add = (int)threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+        __syncthreads();
+        part[threadIdx.x] += add;
+        __syncthreads();
+    }
+    int run = part[threadIdx.x] - sum;
+    for (int k = lo; k < hi; ++k) {
+        const int c = hist[k];
+        hist[k] = run;
+        run += c;
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += kBlock) {
+        const int p = atomicAdd(&hist[gn_l[i]], 1);
+        sorted_rows[pos + p] = rows_l[i];
     }
 }
 
