@@ -52,6 +52,12 @@ int guarded(F && body) {
 void ensure_device_ready();
 hipStream_t stream();
 
+inline size_t grow_capacity(size_t need) {
+    size_t c = 64;
+    while (c < need) c *= 2;
+    return c;
+}
+
 template <class T>
 struct DeviceBuf {
     T * p = nullptr;
@@ -84,7 +90,7 @@ struct DeviceBuf {
         cap = n;
     }
     void upload(const T * host, size_t n) {
-        reserve(n, 0);
+        if (n > cap) reserve(grow_capacity(n), 0);   // headroom: no realloc per call
         if (n)
             HIP_CHECK(hipMemcpyAsync(p, host, n * sizeof(T),
                                      hipMemcpyHostToDevice, stream()));
@@ -96,11 +102,5 @@ struct DeviceBuf {
         HIP_CHECK(hipStreamSynchronize(stream()));
     }
 };
-
-inline size_t grow_capacity(size_t need) {
-    size_t c = 64;
-    while (c < need) c *= 2;
-    return c;
-}
 
 }  // namespace dist

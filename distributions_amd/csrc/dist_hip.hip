@@ -484,6 +484,9 @@ struct Gibbs {
     size_t batch_begin = 0, batch_end = 0;   // rows of the open batch
     bool batch_open = false;
     bool batch_value_sorted = false;
+    bool timing_pending = false;
+    int * pinned_counts = nullptr;
+    size_t pinned_cap = 0;
 
     // value-sorted path (single small-domain feature): rows of a batch range
     // sorted by value once, tiles of <= 64 equal-valued rows
@@ -522,6 +525,7 @@ struct Gibbs {
     ~Gibbs() {
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
+        if (pinned_counts) (void)hipHostFree(pinned_counts);
     }
 
     int F() const { return (int)feats.size(); }
@@ -631,8 +635,16 @@ struct Gibbs {
         for (auto & s : feats) s->init();
     }
     void refresh_host_counts() {
-        py.counts.resize((size_t)K());
-        py.d_counts.download(py.counts.data(), py.counts.size());
+        const size_t n = (size_t)K();
+        if (n > pinned_cap) {
+            if (pinned_counts) (void)hipHostFree(pinned_counts);
+            pinned_cap = grow_capacity(n);
+            HIP_CHECK(hipHostMalloc((void **)&pinned_counts,
+                                    pinned_cap * sizeof(int), 0));
+        }
+        py.counts.resize(n);
+        py.d_counts.download(pinned_counts, n);   // synchronises the stream
+        std::copy(pinned_counts, pinned_counts + n, py.counts.begin());
     }
 
     void load(size_t n, const uint32_t * const * vals, bool vals_on_device,
@@ -768,7 +780,7 @@ struct Gibbs {
         const int kind = feats[0]->sh.kind;
         if (kind != DIST_DD && kind != DIST_DPD && kind != DIST_BB) return false;
         if (value_sorted_mode == 2) return true;
-        return rows >= (size_t)16 * vs_nvals() && rows >= 4096;
+        return rows >= (size_t)64 * vs_nvals() && rows >= 4096;
     }
 
     VsCache & vs_get(size_t r0, size_t r1) {
@@ -792,9 +804,10 @@ struct Gibbs {
                c->sorted_rows.p);
         std::vector<VsTile> tiles;
         for (uint32_t x = 0; x < nv; ++x)
-            for (uint32_t off = 0; off < h[x]; off += 64)
+            for (uint32_t off = 0; off < h[x]; off += 64 * kVsR)
                 tiles.push_back(VsTile{x, start[x] + off,
-                                       std::min<uint32_t>(64, h[x] - off)});
+                                       std::min<uint32_t>(64 * kVsR,
+                                                          h[x] - off)});
         c->n_tiles = (uint32_t)tiles.size();
         c->tiles.upload(tiles.data(), tiles.size());
         std::vector<VsTile> chunks;
@@ -830,7 +843,8 @@ struct Gibbs {
         void go() {
             const uint32_t nv = (uint32_t)self->vs_nvals();
             hipLaunchKernelGGL((k_vs_prepare<KIND>), dim3(nv), dim3(kBlock), 0,
-                               stream(), *P, T);
+                               stream(), *P, T, self->deferred_count.p,
+                               c->n_other);
             HIP_CHECK(hipGetLastError());
             HIP_CHECK(hipEventRecord(self->ev0, stream()));
             hipLaunchKernelGGL((k_vs_sample<KIND>),
@@ -862,8 +876,6 @@ struct Gibbs {
         P.table0 = nullptr;
         LAUNCH(k_sweep_prepare, (size_t)K(), P, base.p, (float *)nullptr,
                scalars.p);
-        HIP_CHECK(hipMemcpyAsync(deferred_count.p, &c.n_other, 4,
-                                 hipMemcpyHostToDevice, stream()));
         if (c.n_other)
             HIP_CHECK(hipMemcpyAsync(deferred.p, c.other_rows.p,
                                      4 * (size_t)c.n_other,
@@ -886,7 +898,7 @@ struct Gibbs {
         SweepParams * P;
         template <int A, int B, int NF>
         void run() {
-            hipLaunchKernelGGL((k_sweep_sample<A, B, NF>), dim3(64),
+            hipLaunchKernelGGL((k_sweep_sample<A, B, NF>), dim3(16),
                                dim3(kBlock), 0, stream(), *P);
             HIP_CHECK(hipGetLastError());
         }
@@ -912,12 +924,19 @@ struct Gibbs {
             dispatch(L);
             generic_batches += 1;
         }
+        timing_pending = true;
+    }
+    // the events of the open batch are read once the batch has been drained
+    // (batch_finish has synchronised by then): no extra host sync per batch
+    void collect_timing() {
+        if (!timing_pending) return;
+        timing_pending = false;
         HIP_CHECK(hipEventSynchronize(ev1));
         float ms = 0.f;
         HIP_CHECK(hipEventElapsedTime(&ms, ev0, ev1));
         kernel_ms += ms;
         kernel_launches += 1;
-        kernel_rows += r1 - r0;
+        kernel_rows += batch_end - batch_begin;
     }
 
     void replay_floats() {
@@ -1002,6 +1021,7 @@ struct Gibbs {
         const std::vector<int> snap = py.counts;
         const int K0 = K();
         refresh_host_counts();
+        collect_timing();
         int created = 0;
         for (int k = 0; k < K0; ++k)
             if (snap[k] == 0 && py.counts[k] > 0) created += 1;

@@ -531,8 +531,10 @@ __device__ __forceinline__ bool vs_group_has_value(const SlaveView & v, int g,
 }
 
 template <int KIND>
-__global__ __launch_bounds__(kBlock) void k_vs_prepare(SweepParams P,
-                                                       VsTables T) {
+__global__ __launch_bounds__(kBlock) void k_vs_prepare(
+        SweepParams P, VsTables T, uint32_t * deferred_count,
+        uint32_t deferred_initial) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *deferred_count = deferred_initial;
     __shared__ float r_m1[kBlock], r_m2[kBlock];
     __shared__ int r_i1[kBlock];
     __shared__ float sh_M, sh_mB;
@@ -598,7 +600,7 @@ __global__ __launch_bounds__(kBlock) void k_vs_prepare(SweepParams P,
     }
 }
 
-constexpr int kVsUnroll = 16;
+constexpr int kVsUnroll = 32;
 
 // wave-uniform read-only data: loads through the constant address space are
 // issued as scalar loads (s_load_dwordx8/x16) when the address is uniform
@@ -607,71 +609,98 @@ __device__ __forceinline__ uniform_fp as_uniform(const float * p) {
     return (uniform_fp)(unsigned long long)p;
 }
 
+// rows per wave = 64 * kVsR: R consecutive tiles of one value share every
+// scalar load of the likelihood vector, so a 16-entry chunk feeds 16*R vector
+// ops and the scalar-load latency hides behind them
+constexpr int kVsR = 1;
+
 // The two order-sensitive recurrences for the lanes whose likelihood vector
 // is `lp` (wave-uniform), own slot replaced by the lane's l_own:
 //   total = ((l_0 + l_1) + l_2) + ...                  random.cc:100-103
 //   t = total*u; t -= l_k until t <= 0                 random.hpp:323-330
-// The vector is consumed in chunks of 16 scalar-loaded entries.  A chunk that
-// holds no lane's own slot is pure uniform arithmetic (one VALU op per entry
-// and pass); a chunk that does takes the per-lane select.  Subtracting
-// non-negative terms never increases t, so each lane crosses zero in exactly
-// one chunk; the scan only records that chunk and the value of t on entry,
-// and the lane then replays its 16 subtractions to get the exact index.
-__device__ __forceinline__ int vs_sum_and_scan(uniform_fp lp,
-                                               const float * lp_vec, int K,
-                                               int g, float l_own, float u,
-                                               bool active) {
-    const int gchunk = active ? (g / kVsUnroll) : -1;
-    float total = 0.f;
+// The vector is consumed in chunks of 16 scalar-loaded entries.  For a
+// sub-tile in which no lane's own slot falls into the chunk, the chunk is
+// pure uniform arithmetic (one VALU op per entry and pass); otherwise it takes
+// the per-lane select.  Subtracting non-negative terms never increases t, so
+// each lane crosses zero in exactly one chunk; the scan only records that
+// chunk and the value of t on entry, and the lane then replays its 16
+// subtractions to get the exact index.
+__device__ __forceinline__ void vs_sum_and_scan(
+        uniform_fp lp, const float * lp_vec, int K, const int (&g)[kVsR],
+        const float (&l_own)[kVsR], const float (&u)[kVsR],
+        const bool (&active)[kVsR], int (&found)[kVsR]) {
+    int gchunk[kVsR];
+    float total[kVsR];
+#pragma unroll
+    for (int r = 0; r < kVsR; ++r) {
+        gchunk[r] = active[r] ? (g[r] / kVsUnroll) : -1;
+        total[r] = 0.f;
+    }
     for (int c = 0, k0 = 0; k0 < K; ++c, k0 += kVsUnroll) {
         float l[kVsUnroll];
 #pragma unroll
         for (int j = 0; j < kVsUnroll; ++j) l[j] = lp[k0 + j];
-        if (__any(gchunk == c)) {
 #pragma unroll
-            for (int j = 0; j < kVsUnroll; ++j)
-                total += (k0 + j == g) ? l_own : l[j];
-        } else {
+        for (int r = 0; r < kVsR; ++r) {
+            if (__any(gchunk[r] == c)) {
 #pragma unroll
-            for (int j = 0; j < kVsUnroll; ++j) total += l[j];
+                for (int j = 0; j < kVsUnroll; ++j)
+                    total[r] += (k0 + j == g[r]) ? l_own[r] : l[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < kVsUnroll; ++j) total[r] += l[j];
+            }
         }
     }
-    float t = total * u;
-    int cross = -1;
-    float t_start = 0.f;
+    float t[kVsR], t_start[kVsR];
+    int cross[kVsR];
+#pragma unroll
+    for (int r = 0; r < kVsR; ++r) {
+        t[r] = total[r] * u[r];
+        t_start[r] = 0.f;
+        cross[r] = -1;
+    }
     for (int c = 0, k0 = 0; k0 < K; ++c, k0 += kVsUnroll) {
-        const float t0 = t;
         float l[kVsUnroll];
 #pragma unroll
         for (int j = 0; j < kVsUnroll; ++j) l[j] = lp[k0 + j];
-        if (__any(gchunk == c)) {
+        bool more = false;
 #pragma unroll
-            for (int j = 0; j < kVsUnroll; ++j)
-                t -= (k0 + j == g) ? l_own : l[j];
-        } else {
+        for (int r = 0; r < kVsR; ++r) {
+            const float t0 = t[r];
+            if (__any(gchunk[r] == c)) {
 #pragma unroll
-            for (int j = 0; j < kVsUnroll; ++j) t -= l[j];
+                for (int j = 0; j < kVsUnroll; ++j)
+                    t[r] -= (k0 + j == g[r]) ? l_own[r] : l[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < kVsUnroll; ++j) t[r] -= l[j];
+            }
+            // the walk starts "above zero" by definition: a first t <= 0 at
+            // k = 0 is index 0 (random.hpp:326-329)
+            const bool crossed = (c == 0 || t0 > 0.f) && !(t[r] > 0.f);
+            cross[r] = crossed ? c : cross[r];
+            t_start[r] = crossed ? t0 : t_start[r];
+            more = more || (active[r] && t[r] > 0.f);
         }
-        // the walk starts "above zero" by definition: a first t <= 0 at k = 0
-        // is index 0 (random.hpp:326-329)
-        const bool crossed = (c == 0 || t0 > 0.f) && !(t > 0.f);
-        cross = crossed ? c : cross;
-        t_start = crossed ? t0 : t_start;
-        if (!__any(active && t > 0.f)) break;
+        if (!__any(more)) break;
     }
-    int found = K - 1;
-    if (active && cross >= 0) {
-        float tt = t_start;
-        int steps = 0;
 #pragma unroll
-        for (int j = 0; j < kVsUnroll; ++j) {
-            const int k = cross * kVsUnroll + j;
-            tt -= (k == g) ? l_own : lp_vec[k];
-            steps += (tt > 0.f) ? 1 : 0;
+    for (int r = 0; r < kVsR; ++r) {
+        int f = K - 1;
+        if (active[r] && cross[r] >= 0) {
+            float tt = t_start[r];
+            int steps = 0;
+#pragma unroll
+            for (int j = 0; j < kVsUnroll; ++j) {
+                const int k = cross[r] * kVsUnroll + j;
+                tt -= (k == g[r]) ? l_own[r] : lp_vec[k];
+                steps += (tt > 0.f) ? 1 : 0;
+            }
+            f = cross[r] * kVsUnroll + steps;
         }
-        found = cross * kVsUnroll + steps;
+        found[r] = f < K - 1 ? f : K - 1;
     }
-    return found < K - 1 ? found : K - 1;
 }
 
 template <int KIND>
@@ -692,52 +721,70 @@ __global__ __launch_bounds__(kBlock) void k_vs_sample(
     const float shift = P.scalars->shift;
     const float M = T.M[x], mB = T.mB[x];
     const int amax = T.argmax[x];
+    const float ea = u2f(g_tables_dev.exp_ab[0]);
+    const float eb = u2f(g_tables_dev.exp_ab[1]);
 
-    bool valid = (uint32_t)lane < n;
-    size_t row = 0;
-    int g = -1;
-    bool classB = false;
-    float l_own = 0.f, u = 0.f;
-    if (valid) {
-        row = P.row_begin + sorted_rows[pos + lane];
-        g = P.g2p[P.assign[row]];
-        const int n_g = P.counts[g];
-        classB = (g == amax);
-        const float m = classB ? mB : M;
-        float s_own = 0.f;
-        bool defer = (n_g == 1);
-        if (!defer) {
-            s_own = vs_own_score(P, v, g, n_g, x, 0.f, shift);
-            defer = !classB && s_own > M;   // table rounding lifted it over M
+    bool valid[kVsR], inA[kVsR], inB[kVsR];
+    size_t row[kVsR];
+    int g[kVsR], g2[kVsR];
+    float l_own[kVsR], u[kVsR];
+    bool anyA = false, anyB = false;
+#pragma unroll
+    for (int r = 0; r < kVsR; ++r) {
+        valid[r] = (uint32_t)(lane + 64 * r) < n;
+        row[r] = 0;
+        g[r] = -1;
+        g2[r] = 0;
+        l_own[r] = 0.f;
+        u[r] = 0.f;
+        bool classB = false;
+        if (valid[r]) {
+            row[r] = P.row_begin + sorted_rows[pos + lane + 64 * r];
+            g[r] = P.g2p[P.assign[row[r]]];
+            const int n_g = P.counts[g[r]];
+            classB = (g[r] == amax);
+            const float m = classB ? mB : M;
+            float s_own = 0.f;
+            bool defer = (n_g == 1);
+            if (!defer) {
+                s_own = vs_own_score(P, v, g[r], n_g, x, 0.f, shift);
+                defer = !classB && s_own > M;   // table rounding lifted it
+            }
+            if (defer) {
+                deferred[atomicAdd(deferred_count, 1u)] = (uint32_t)row[r];
+                valid[r] = false;
+            } else {
+                l_own[r] = fast_exp_nonpos(s_own - m, g_tables_dev.exp_table,
+                                           ea, eb);
+                u[r] = batch_row_unif01(P, row[r]);
+            }
         }
-        if (defer) {
-            deferred[atomicAdd(deferred_count, 1u)] = (uint32_t)row;
-            valid = false;
-        } else {
-            l_own = fast_exp_nonpos(s_own - m, g_tables_dev.exp_table,
-                                    u2f(g_tables_dev.exp_ab[0]),
-                                    u2f(g_tables_dev.exp_ab[1]));
-            u = batch_row_unif01(P, row);
-        }
+        inA[r] = valid[r] && !classB;
+        inB[r] = valid[r] && classB;
+        anyA = anyA || inA[r];
+        anyB = anyB || inB[r];
     }
-    const bool inA = valid && !classB, inB = valid && classB;
-    int g2 = 0;
-    if (__any(inA)) {
+    if (__any(anyA)) {
         const float * vec = T.LA + (size_t)x * T.Kpad;
-        const int r = vs_sum_and_scan(as_uniform(vec), vec, K, g, l_own, u,
-                                      inA);
-        g2 = inA ? r : g2;
+        int f[kVsR];
+        vs_sum_and_scan(as_uniform(vec), vec, K, g, l_own, u, inA, f);
+#pragma unroll
+        for (int r = 0; r < kVsR; ++r) g2[r] = inA[r] ? f[r] : g2[r];
     }
-    if (__any(inB)) {
+    if (__any(anyB)) {
         const float * vec = T.LB + (size_t)x * T.Kpad;
-        const int r = vs_sum_and_scan(as_uniform(vec), vec, K, g, l_own, u,
-                                      inB);
-        g2 = inB ? r : g2;
+        int f[kVsR];
+        vs_sum_and_scan(as_uniform(vec), vec, K, g, l_own, u, inB, f);
+#pragma unroll
+        for (int r = 0; r < kVsR; ++r) g2[r] = inB[r] ? f[r] : g2[r];
     }
-    if (valid) {
-        const size_t bidx = row - P.row_begin;
-        P.old_packed[bidx] = (uint32_t)g;
-        P.new_packed[bidx] = (uint32_t)g2;
+#pragma unroll
+    for (int r = 0; r < kVsR; ++r) {
+        if (valid[r]) {
+            const size_t bidx = row[r] - P.row_begin;
+            P.old_packed[bidx] = (uint32_t)g[r];
+            P.new_packed[bidx] = (uint32_t)g2[r];
+        }
     }
 }
 
