@@ -48,6 +48,13 @@ def parse():
     ap.add_argument("--seed", type=int, default=20240601)
     ap.add_argument("--cpu-rows", type=int, default=1_000_000,
                     help="rows of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--config", default="dd",
+                    choices=["dd", "gp_nich", "dpd", "bb", "gp", "nich"],
+                    help="dd = the headline workload (BASELINE configs[1]); "
+                         "the others are the remaining BASELINE configs, for "
+                         "DESIGN.md's table (not the bench line of record)")
+    ap.add_argument("--value-sorted", type=int, default=1,
+                    help="0 generic kernel only, 1 auto, 2 force")
     return ap.parse_args()
 
 
@@ -97,12 +104,48 @@ def main():
     row_offset = rank * n
     gen = torch.Generator(device=dev)
     gen.manual_seed(args.seed + rank)
-    values = torch.randint(0, args.dim, (n,), generator=gen, device=dev,
-                           dtype=torch.int32)
     assign = (torch.arange(n, device=dev, dtype=torch.int64)
               + row_offset).remainder(k).to(torch.int32)
-    g = engine.Gibbs(args.alpha, args.d, [engine.dd_shared([0.5] * args.dim)])
-    g.load_rows_torch([values], assign, k, 1, row_offset=row_offset)
+
+    def poisson(mean):
+        return torch.poisson(torch.full((n,), mean, device=dev),
+                             generator=gen).to(torch.int32)
+
+    def normal():
+        return torch.randn((n,), generator=gen, device=dev,
+                           dtype=torch.float32)
+
+    if args.config == "dd":
+        columns = [torch.randint(0, args.dim, (n,), generator=gen, device=dev,
+                                 dtype=torch.int32)]
+        shareds = [engine.dd_shared([0.5] * args.dim)]
+        bytes_per_row = 12 * k + 12       # 4K (PY) + 2*4K (DD) + 12
+    elif args.config == "dpd":
+        columns = [torch.randint(0, args.dim, (n,), generator=gen, device=dev,
+                                 dtype=torch.int32)]
+        shareds = [engine.dpd_shared(0.5, [1.0 / args.dim] * args.dim, 0.0)]
+        bytes_per_row = 12 * k + 12
+    elif args.config == "bb":
+        columns = [(torch.rand((n,), generator=gen, device=dev) < 0.3).to(
+            torch.int32)]
+        shareds = [engine.bb_shared(0.5, 2.0)]
+        bytes_per_row = 8 * k + 12
+    elif args.config == "gp":
+        columns = [poisson(5.0)]
+        shareds = [engine.gp_shared(1.0, 1.0)]
+        bytes_per_row = 16 * k + 12
+    elif args.config == "nich":
+        columns = [normal()]
+        shareds = [engine.nich_shared(0.0, 1.0, 1.0, 1.0)]
+        bytes_per_row = 20 * k + 12
+    else:   # gp_nich: BASELINE configs[2]
+        columns = [poisson(5.0), normal()]
+        shareds = [engine.gp_shared(1.0, 1.0),
+                   engine.nich_shared(0.0, 1.0, 1.0, 1.0)]
+        bytes_per_row = 32 * k + 16       # (1+3+4)*4K + 16
+    g = engine.Gibbs(args.alpha, args.d, shareds)
+    g.set_option("value_sorted", args.value_sorted)
+    g.load_rows_torch(columns, assign, k, 1, row_offset=row_offset)
     sharded = engine.ShardedGibbs(g.core, n, row_offset, device=dev)
     sharded.sync_initial_stats()
     seed_state = _core.rng_seed(args.seed)
@@ -133,7 +176,9 @@ def main():
 
     ms, launches, rows = g.kernel_stats()
     total_rows = float(n) * world * args.steps
-    bytes_per_row = 12 * k + 12            # 4K (PY) + 2*4K (DD) + 12
+    vs_batches, generic_batches = g.path_counts()
+    kernel = ("k_vs_sample" if vs_batches else "k_sweep_sample") + "<%s>" % (
+        args.config)
     if rank == 0:
         out = {
             "metric": "row-Gibbs-updates/sec (score+sample+suffstat) at "
@@ -150,10 +195,17 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "DirichletDiscrete(dim=%d) N=%d rows/GPU K=%d+1 "
+                "workload": "%s N=%d rows/GPU K=%d+1 "
                             "PitmanYor(alpha=%g,d=%g), frozen sub-sweeps of "
-                            "%d rows" % (args.dim, n, k, args.alpha, args.d,
-                                         args.batch),
+                            "%d rows" % (
+                                {"dd": "DirichletDiscrete(dim=%d)" % args.dim,
+                                 "dpd": "DirichletProcessDiscrete(V=%d)"
+                                        % args.dim,
+                                 "bb": "BetaBernoulli", "gp": "GammaPoisson",
+                                 "nich": "NormalInverseChiSq",
+                                 "gp_nich": "GammaPoisson+NormalInverseChiSq"
+                                 }[args.config],
+                                n, k, args.alpha, args.d, args.batch),
                 "rows_per_gpu": n, "groups": k, "dim": args.dim,
                 "batch_rows": args.batch,
                 "parallelism": "rows sharded over %d GPU(s), all-reduce of "
@@ -161,7 +213,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "k_sweep_sample<DD>",
+                "kernel": kernel,
                 "achieved": (bytes_per_row * rows / max(launches, 1))
                             / (1e-3 * ms / max(launches, 1)) / 1e9,
                 "peak": HBM_PEAK_GBS,
@@ -175,7 +227,7 @@ def main():
                 "launches": launches,
             },
         }
-        if world == 1 and args.cpu_rows > 0:
+        if world == 1 and args.cpu_rows > 0 and args.config == "dd":
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)
     if world > 1:

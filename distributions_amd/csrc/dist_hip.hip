@@ -19,6 +19,12 @@
 
 namespace dist {
 
+// sort.hip
+size_t sort_pairs_temp_bytes(size_t n, int bits);
+void sort_pairs(void * temp, size_t temp_bytes, const uint32_t * keys_in,
+                uint32_t * keys_out, const uint32_t * vals_in,
+                uint32_t * vals_out, size_t n, int bits, hipStream_t stream);
+
 __device__ Tables g_tables_dev;
 static Tables g_tables_host_storage;
 const Tables * g_tables_host = nullptr;
@@ -474,9 +480,13 @@ struct Gibbs {
     bool maps_dirty = true;
 
     DeviceBuf<uint32_t> old_packed, new_packed;
+    // ordered replay of float statistics: events sorted stably by group
+    DeviceBuf<uint32_t> ev_keys, ev_vals, ev_keys_sorted, ev_vals_sorted;
+    DeviceBuf<uint32_t> seg_begin, seg_end;
+    DeviceBuf<unsigned char> sort_temp;
     DeviceBuf<uint32_t> pow_lo, pow_hi;   // 16807^i, 16807^(4096 i) mod 2^31-1
     uint32_t n_pow_hi = 0;
-    DeviceBuf<float> base, table0;
+    DeviceBuf<float> base, base_single;
     DeviceBuf<SweepScalars> scalars;
     DeviceBuf<float> row_scores;
     DeviceBuf<int> row_size;
@@ -549,6 +559,7 @@ struct Gibbs {
         P.counts = py.d_counts.p;
         P.shifted = py.d_shifted.p;
         P.base = base.p;
+        P.base_single = base_single.p;
         P.table0 = nullptr;
         P.scalars = scalars.p;
         P.K = K();
@@ -690,6 +701,7 @@ struct Gibbs {
         old_packed.reserve(std::max<size_t>(n, 1), 0);
         new_packed.reserve(std::max<size_t>(n, 1), 0);
         base.reserve((size_t)grow_capacity(Kt), 0);
+        base_single.reserve((size_t)grow_capacity(Kt), 0);
         scalars.reserve(1, 0);
         // integer statistics by atomics, float statistics replayed in row
         // order (Group::add_value per row, like GroupIoMixin.from_values,
@@ -697,14 +709,7 @@ struct Gibbs {
         SweepParams P = params(0, n, 0, 0);
         if (n) {
             LAUNCH(k_load_counts, n, P, live_image(), packed_dev);
-            for (int f = 0; f < F(); ++f) {
-                if (!has_float_stats(feats[f]->sh.kind)) continue;
-                hipLaunchKernelGGL(k_replay_floats, dim3(Kt), dim3(64), 0,
-                                   stream(), feats[f]->view(), values[f],
-                                   (const uint32_t *)nullptr, packed_dev,
-                                   (size_t)0, n);
-                HIP_CHECK(hipGetLastError());
-            }
+            replay_sorted(nullptr, packed_dev, 0, n);
             // assignments become global ids (identity map right after init)
             LAUNCH(k_packed_to_global, n, packed_dev, d_p2g.p, assign, n);
         }
@@ -730,16 +735,11 @@ struct Gibbs {
 
     void prepare(SweepParams & P) {
         base.reserve(grow_capacity((size_t)K()), 0);
-        float * t0 = nullptr;
-        size_t n = (size_t)K();
-        if (F() > 0 && is_cat(feats[0]->sh.kind)) {
-            n = (size_t)K() * feats[0]->sh.dim;
-            table0.reserve(n, 0);
-            t0 = table0.p;
-        }
+        base_single.reserve(grow_capacity((size_t)K()), 0);
         P.base = base.p;
-        LAUNCH(k_sweep_prepare, n, P, base.p, t0, scalars.p);
-        P.table0 = t0;
+        P.base_single = base_single.p;
+        LAUNCH(k_sweep_prepare, (size_t)K(), P, base.p, base_single.p,
+               scalars.p);
     }
 
     struct SampleLaunch {
@@ -869,13 +869,7 @@ struct Gibbs {
         vsArg.reserve(nv, 0);
         deferred.reserve(std::max<size_t>(n, 1), 0);
         deferred_count.reserve(1, 0);
-        // base[] and the scalars; no folded table (the deferred rows use the
-        // generic kernel unfolded, which is the same arithmetic)
-        base.reserve(grow_capacity((size_t)K()), 0);
-        P.base = base.p;
-        P.table0 = nullptr;
-        LAUNCH(k_sweep_prepare, (size_t)K(), P, base.p, (float *)nullptr,
-               scalars.p);
+        prepare(P);   // base[], base_single[] and the scalars
         if (c.n_other)
             HIP_CHECK(hipMemcpyAsync(deferred.p, c.other_rows.p,
                                      4 * (size_t)c.n_other,
@@ -939,16 +933,48 @@ struct Gibbs {
         kernel_rows += batch_end - batch_begin;
     }
 
-    void replay_floats() {
-        const size_t n = batch_end - batch_begin;
+    bool any_float_stats() const {
+        for (auto & f : feats)
+            if (has_float_stats(f->sh.kind)) return true;
+        return false;
+    }
+    // Float statistics (NICH count/mean/ctv, GP log_prod) depend on update
+    // order, so they are replayed per group in row order: the batch's events
+    // are sorted stably by group, then one wave per group walks its segment.
+    // old_dev == nullptr: rows are only added (initial load).
+    void replay_sorted(const uint32_t * old_dev, const uint32_t * new_dev,
+                       size_t row_begin, size_t n_rows) {
+        if (!any_float_stats() || !n_rows) return;
+        const size_t n_ev = old_dev ? 2 * n_rows : n_rows;
+        const size_t Kn = (size_t)K();
+        int bits = 1;
+        while ((1ull << bits) < Kn) bits += 1;
+        ev_keys.reserve(n_ev, 0); ev_vals.reserve(n_ev, 0);
+        ev_keys_sorted.reserve(n_ev, 0); ev_vals_sorted.reserve(n_ev, 0);
+        seg_begin.reserve(grow_capacity(Kn), 0);
+        seg_end.reserve(grow_capacity(Kn), 0);
+        const size_t tb = sort_pairs_temp_bytes(n_ev, bits);
+        sort_temp.reserve(tb + 256, 0);
+        LAUNCH(k_replay_events, n_rows, old_dev, new_dev, n_rows, ev_keys.p,
+               ev_vals.p);
+        sort_pairs(sort_temp.p, tb, ev_keys.p, ev_keys_sorted.p, ev_vals.p,
+                   ev_vals_sorted.p, n_ev, bits, stream());
+        HIP_CHECK(hipMemsetAsync(seg_begin.p, 0, Kn * 4, stream()));
+        HIP_CHECK(hipMemsetAsync(seg_end.p, 0, Kn * 4, stream()));
+        LAUNCH(k_replay_bounds, n_ev, ev_keys_sorted.p, n_ev, seg_begin.p,
+               seg_end.p);
         for (int f = 0; f < F(); ++f) {
             if (!has_float_stats(feats[f]->sh.kind)) continue;
-            hipLaunchKernelGGL(k_replay_floats, dim3(K()), dim3(64), 0,
-                               stream(), feats[f]->view(), values[f],
-                               (const uint32_t *)old_packed.p,
-                               (const uint32_t *)new_packed.p, batch_begin, n);
+            hipLaunchKernelGGL(k_replay_sorted, dim3((unsigned)Kn), dim3(64),
+                               0, stream(), feats[f]->view(), values[f],
+                               row_begin, ev_vals_sorted.p, seg_begin.p,
+                               seg_end.p);
             HIP_CHECK(hipGetLastError());
         }
+    }
+    void replay_floats() {
+        replay_sorted(old_packed.p, new_packed.p, batch_begin,
+                      batch_end - batch_begin);
     }
 
     // integer statistics of the open batch into `img` (live arrays or a

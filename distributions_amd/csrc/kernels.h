@@ -218,7 +218,10 @@ struct SweepParams {
     const int32_t * counts;    // driver counts[K] at batch entry
     const float * shifted;     // clustering.hpp shifted_scores_[K]
     const float * base;        // shifted[k] + shift
-    const float * table0;      // feature 0 folded, k-major: [K][dim0] or null
+    const float * base_single; // the same for a row that was alone in its
+                               // group: empty slots score with one non-empty
+                               // group fewer (clustering.hpp:221-230)
+    const float * table0;      // unused by the kernels (kept for layout)
     const SweepScalars * scalars;
     int K;
     int n_empty;
@@ -255,6 +258,13 @@ struct StatImage {
     int32_t * cnt[kMaxF];
 };
 
+// wave-uniform read-only data: loads through the constant address space are
+// issued as scalar loads (s_load_dwordx8/x16) when the address is uniform
+typedef const float __attribute__((address_space(4))) * uniform_fp;
+__device__ __forceinline__ uniform_fp as_uniform(const float * p) {
+    return (uniform_fp)(unsigned long long)p;
+}
+
 // sample_unif01 of batch row b (random.hpp:47-50): one engine step per row,
 // the step the sequential chain would have used for it
 __device__ __forceinline__ float batch_row_unif01(const SweepParams & P,
@@ -272,33 +282,22 @@ __global__ void k_pow_tables(uint32_t * pow_lo, uint32_t * pow_hi,
     if (i < n_hi) pow_hi[i] = lcg_jump(1u, 4096ull * i);
 }
 
-// base[k], the scalars and (categorical feature 0) the folded k-major table
-//   table0[k][v] = (base[k] + S[v][k]) - shift0[k]
-// which is the row score for value v at group k when no self-removal applies;
-// the two float operations are the reference's, in its order.
+// base[k], base_single[k] and the scalars of a batch
 __global__ void k_sweep_prepare(SweepParams P, float * __restrict__ base,
-                                float * __restrict__ table0,
+                                float * __restrict__ base_single,
                                 SweepScalars * scalars) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const float shift = py_shift(P.sample_size - 1, P.alpha);
+    const float empty_single =
+        py_empty_score(P.alpha, P.d, P.K - P.n_empty - 1, P.n_empty);
     if (i == 0) {
         scalars->shift = shift;
         scalars->shift_full = py_shift(P.sample_size, P.alpha);
-        scalars->empty_single = py_empty_score(
-            P.alpha, P.d, P.K - P.n_empty - 1, P.n_empty);
+        scalars->empty_single = empty_single;
     }
-    if (table0) {
-        const SlaveView & s = P.feat[0];
-        if (i >= (size_t)P.K * s.dim) return;
-        const int k = (int)(i / s.dim);
-        const int v = (int)(i % s.dim);
-        const float b = P.shifted[k] + shift;
-        if (v == 0) base[k] = b;
-        table0[i] = (b + s.S[(size_t)v * s.cap + k]) - s.c0[k];
-    } else {
-        if (i >= (size_t)P.K) return;
-        base[i] = P.shifted[i] + shift;
-    }
+    if (i >= (size_t)P.K) return;
+    base[i] = P.shifted[i] + shift;
+    base_single[i] = (P.counts[i] == 0 ? empty_single : P.shifted[i]) + shift;
 }
 
 // Scores of one row in batch semantics: state at batch entry minus the row.
@@ -319,7 +318,6 @@ struct RowScorer {
     int singleton;
     int Kl;
     float s_own;
-    float shift, empty_single;
 
     __device__ __forceinline__ int nf() const { return NF > 0 ? NF : P.F; }
     __device__ __forceinline__ int kind_of(int f) const {
@@ -328,10 +326,43 @@ struct RowScorer {
         return P.feat[f].kind;
     }
 
+    // the cache entry of slot k (wave-uniform k): scalar loads for the
+    // per-group parameters, a per-lane gather only for a categorical table
+    __device__ __forceinline__ Entry entry_at(const SlaveView & v, int kind,
+                                              int k, uint32_t xv) const {
+        Entry e;
+        e.c0 = as_uniform(v.c0)[k];
+        if (is_cat(kind)) {
+            e.c1 = (kind == DIST_DPD && xv == DIST_DPD_OTHER)
+                       ? v.other
+                       : v.S[(size_t)xv * v.cap + k];
+            e.c2 = 0.f;
+            e.c3 = 0.f;
+        } else {
+            e.c1 = as_uniform(v.c1)[k];
+            e.c2 = as_uniform(v.c2)[k];
+            e.c3 = as_uniform(v.c3)[k];
+        }
+        return e;
+    }
+
+    // score of slot k from the caches (k wave-uniform)
+    __device__ __forceinline__ float cached(int k) const {
+        const float b = as_uniform(P.base)[k];
+        const float bs = as_uniform(P.base_single)[k];
+        float s = singleton ? bs : b;
+#pragma unroll kUnroll
+        for (int f = 0; f < nf(); ++f) {
+            const int kind = kind_of(f);
+            s = accumulate(kind, s, entry_at(P.feat[f], kind, k, x[f]), x[f],
+                           lf[f]);
+        }
+        return s;
+    }
+
     __device__ __forceinline__ RowScorer(const SweepParams & P_, size_t row)
         : P(P_) {
-        shift = P.scalars->shift;
-        empty_single = P.scalars->empty_single;
+        const float shift = P.scalars->shift;
         g = P.g2p[P.assign[row]];
         const int n_g = P.counts[g];
         singleton = (n_g == 1);
@@ -352,46 +383,24 @@ struct RowScorer {
             }
             s_own = s;
         } else {
-            s_own = unfolded(P.K - 1, true);
-        }
-    }
-
-    // score of slot `src` from the caches, nothing folded
-    __device__ __forceinline__ float unfolded(int src, bool single) const {
-        const float c = (single && P.counts[src] == 0) ? empty_single
-                                                        : P.shifted[src];
-        float s = c + shift;
+            // slot g holds what was the last group (per-lane index: plain loads)
+            const int src = P.K - 1;
+            float s = P.base_single[src];
 #pragma unroll kUnroll
-        for (int f = 0; f < nf(); ++f) {
-            SlaveView v = P.feat[f];
-            v.kind = kind_of(f);
-            s = accumulate(v.kind, s, load_entry(v, src, x[f]), x[f], lf[f]);
+            for (int f = 0; f < nf(); ++f) {
+                SlaveView v = P.feat[f];
+                v.kind = kind_of(f);
+                s = accumulate(v.kind, s, load_entry(v, src, x[f]), x[f],
+                               lf[f]);
+            }
+            s_own = s;
         }
-        return s;
     }
 
-    // score of local slot k (k < K; slots >= Kl are not part of the row's
-    // view and are masked by the caller)
+    // score of local slot k (k < K, wave-uniform; slots >= Kl are not part of
+    // the row's view and are masked by the caller)
     __device__ __forceinline__ float at(int k) const {
-        float s;
-        int f0 = 0;
-        if (P.table0 != nullptr
-            && !(KIND0 == DIST_DPD && x[0] == DIST_DPD_OTHER)) {
-            s = P.table0[(size_t)k * P.feat[0].dim + x[0]];
-            f0 = 1;
-        } else {
-            s = P.base[k];
-        }
-#pragma unroll kUnroll
-        for (int f = f0; f < nf(); ++f) {
-            SlaveView v = P.feat[f];
-            v.kind = kind_of(f);
-            s = accumulate(v.kind, s, load_entry(v, k, x[f]), x[f], lf[f]);
-        }
-        if (P.counts[k] == 0) {   // uniform across the wave, rare
-            const float s2 = unfolded(k, true);
-            s = singleton ? s2 : s;
-        }
+        const float s = cached(k);
         return k == g ? s_own : s;
     }
 };
@@ -400,6 +409,10 @@ struct RowScorer {
 // the scalar recurrences of scores_to_likelihoods (random.cc:94-106) and
 // sample_from_likelihoods (random.hpp:316-333).  Rows are independent, so the
 // float sums keep the reference's association while 64 rows run per wave.
+// Per-group parameters arrive by scalar loads; the loops are unrolled so that
+// those loads are issued ahead of the arithmetic that consumes them.
+constexpr int kSweepUnroll = 4;
+
 template <int KIND0, int KIND1, int NF>
 __global__ __launch_bounds__(kBlock) void k_sweep_sample(SweepParams P) {
     __shared__ uint32_t s_exp[1024];
@@ -413,41 +426,57 @@ __global__ __launch_bounds__(kBlock) void k_sweep_sample(SweepParams P) {
     const size_t stride = (size_t)gridDim.x * kBlock;
     const size_t n_items = P.row_list ? (size_t)*P.row_list_count
                                       : P.row_end - P.row_begin;
+    // whole waves iterate together (inactive lanes idle) so that the
+    // wave-level votes below see every lane
+    const size_t n_round = (n_items + 63) / 64 * 64;
     for (size_t item = (size_t)blockIdx.x * kBlock + threadIdx.x;
-         item < n_items; item += stride) {
-        const size_t row = P.row_list ? (size_t)P.row_list[item]
-                                      : P.row_begin + item;
+         item < n_round; item += stride) {
+        const bool live = item < n_items;
+        const size_t row = !live ? P.row_begin
+                           : P.row_list ? (size_t)P.row_list[item]
+                                        : P.row_begin + item;
         const RowScorer<KIND0, KIND1, NF> rs(P, row);
         const int Kl = rs.Kl;
 
         // vector_max (vector_math.cc:74-83)
         float m = rs.at(0);
+#pragma unroll kSweepUnroll
         for (int k = 1; k < K; ++k) {
             const float s = rs.at(k);
             m = (k < Kl && s > m) ? s : m;
         }
         // scores_to_likelihoods: total in index order
         float total = 0.f;
+#pragma unroll kSweepUnroll
         for (int k = 0; k < K; ++k) {
             const float l = fast_exp_nonpos(rs.at(k) - m, s_exp, ea, eb);
             total += (k < Kl) ? l : 0.f;
         }
-        // sample_unif01: engine step (draw_base + global row + 1)
-        const float u = batch_row_unif01(P, row);
-        // sample_from_likelihoods
-        float t = total * u;
-        int found = -1;
-        for (int k = 0; k < K; ++k) {
-            const float l = fast_exp_nonpos(rs.at(k) - m, s_exp, ea, eb);
-            t -= (k < Kl) ? l : 0.f;
-            if (found < 0 && k < Kl && t <= 0.f) found = k;
-            if (__all(found >= 0)) break;
+        // sample_from_likelihoods: subtracting non-negative terms never
+        // increases t, so the first index with t <= 0 is the number of steps
+        // after which t is still positive
+        float t = total * batch_row_unif01(P, row);
+        int steps = 0;
+        for (int k0 = 0; k0 < K; k0 += kSweepUnroll) {
+#pragma unroll
+            for (int j = 0; j < kSweepUnroll; ++j) {
+                const int k = k0 + j;
+                if (k < K) {
+                    const float l =
+                        fast_exp_nonpos(rs.at(k) - m, s_exp, ea, eb);
+                    t -= (k < Kl) ? l : 0.f;
+                    steps += (k < Kl && t > 0.f) ? 1 : 0;
+                }
+            }
+            if (!__any(live && t > 0.f)) break;
         }
-        int g2 = found < 0 ? Kl - 1 : found;
+        int g2 = steps < Kl - 1 ? steps : Kl - 1;
         if (rs.singleton && g2 == rs.g) g2 = K - 1;   // slot g held group K-1
-        const size_t b = row - P.row_begin;
-        P.old_packed[b] = (uint32_t)rs.g;
-        P.new_packed[b] = (uint32_t)g2;
+        if (live) {
+            const size_t b = row - P.row_begin;
+            P.old_packed[b] = (uint32_t)rs.g;
+            P.new_packed[b] = (uint32_t)g2;
+        }
     }
 }
 
@@ -601,13 +630,6 @@ __global__ __launch_bounds__(kBlock) void k_vs_prepare(
 }
 
 constexpr int kVsUnroll = 32;
-
-// wave-uniform read-only data: loads through the constant address space are
-// issued as scalar loads (s_load_dwordx8/x16) when the address is uniform
-typedef const float __attribute__((address_space(4))) * uniform_fp;
-__device__ __forceinline__ uniform_fp as_uniform(const float * p) {
-    return (uniform_fp)(unsigned long long)p;
-}
 
 // rows per wave = 64 * kVsR: R consecutive tiles of one value share every
 // scalar load of the likelihood vector, so a 16-entry chunk feeds 16*R vector
@@ -987,6 +1009,73 @@ __global__ __launch_bounds__(64) void k_replay_floats(
         s.f0[k] = fl.f0;
         s.f1[k] = fl.f1;
         if (ints_too) s.i0[k] = fl.i0;
+    }
+}
+
+// ---- ordered replay through a stable sort of the events by group ----------
+// events of batch row b: 2b = "remove from old[b]", 2b+1 = "add to new[b]";
+// sorted stably by group they are, per group, in row order with the removal
+// of a row ahead of its own addition.
+__global__ void k_replay_events(const uint32_t * __restrict__ old_packed,
+                                const uint32_t * __restrict__ new_packed,
+                                size_t n_rows, uint32_t * __restrict__ keys,
+                                uint32_t * __restrict__ vals) {
+    const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_rows) return;
+    if (old_packed) {
+        keys[2 * b] = old_packed[b];
+        vals[2 * b] = (uint32_t)(2 * b);
+        keys[2 * b + 1] = new_packed[b];
+        vals[2 * b + 1] = (uint32_t)(2 * b + 1);
+    } else {   // initial load: additions only
+        keys[b] = new_packed[b];
+        vals[b] = (uint32_t)(2 * b + 1);
+    }
+}
+
+// first/one-past-last position of every group's events in the sorted list
+__global__ void k_replay_bounds(const uint32_t * __restrict__ keys_sorted,
+                                size_t n, uint32_t * __restrict__ seg_begin,
+                                uint32_t * __restrict__ seg_end) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t k = keys_sorted[i];
+    if (i == 0 || keys_sorted[i - 1] != k) seg_begin[k] = (uint32_t)i;
+    if (i + 1 == n || keys_sorted[i + 1] != k) seg_end[k] = (uint32_t)(i + 1);
+}
+
+// one wave per group: 64 events are fetched at a time (coalesced ids, gathered
+// values) and then applied one after the other, every lane computing the same
+// scalar update (nich.hpp:125-165 / gp.hpp:109-135)
+__global__ __launch_bounds__(64) void k_replay_sorted(
+        SlaveView s, const uint32_t * __restrict__ values, size_t row_begin,
+        const uint32_t * __restrict__ vals_sorted,
+        const uint32_t * __restrict__ seg_begin,
+        const uint32_t * __restrict__ seg_end) {
+    const int k = blockIdx.x;
+    const int lane = threadIdx.x;
+    const uint32_t lo = seg_begin[k], hi = seg_end[k];
+    if (lo >= hi) return;
+    Stats fl = load_stats(s, k);
+    for (uint32_t base = lo; base < hi; base += 64) {
+        const uint32_t i = base + lane;
+        uint32_t e = 0, x = 0;
+        if (i < hi) {
+            e = vals_sorted[i];
+            x = values[row_begin + (e >> 1)];
+        }
+        const int cnt = (int)min(64u, hi - base);
+        for (int j = 0; j < cnt; ++j) {
+            const uint32_t ej = __builtin_amdgcn_readlane((int)e, j);
+            const uint32_t xj = __builtin_amdgcn_readlane((int)x, j);
+            if (ej & 1u) stats_add(s.kind, fl, xj);
+            else stats_remove(s.kind, fl, xj);
+        }
+    }
+    if (lane == 0) {
+        s.f0[k] = fl.f0;
+        s.f1[k] = fl.f1;
+        if (s.kind == DIST_NICH) s.i0[k] = fl.i0;
     }
 }
 
