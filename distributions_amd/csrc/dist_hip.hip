@@ -487,6 +487,8 @@ struct Gibbs {
     DeviceBuf<uint32_t> pow_lo, pow_hi;   // 16807^i, 16807^(4096 i) mod 2^31-1
     uint32_t n_pow_hi = 0;
     DeviceBuf<float> base, base_single;
+    std::vector<DeviceBuf<float>> ktab;     // per feature, see SweepParams
+    std::vector<uint32_t> max_value;        // per feature (discrete kinds)
     DeviceBuf<SweepScalars> scalars;
     DeviceBuf<float> row_scores;
     DeviceBuf<int> row_size;
@@ -560,7 +562,6 @@ struct Gibbs {
         P.shifted = py.d_shifted.p;
         P.base = base.p;
         P.base_single = base_single.p;
-        P.table0 = nullptr;
         P.scalars = scalars.p;
         P.K = K();
         P.n_empty = py.n_empty;
@@ -687,6 +688,16 @@ struct Gibbs {
             packed_dev = own_assign.p;
             assign = own_assign.p;
         }
+        // largest value of each count-valued feature (sizes the value tables)
+        max_value.assign((size_t)F(), 0);
+        vs_cache.clear();
+        for (int f = 0; f < F(); ++f) {
+            if (feats[f]->sh.kind != DIST_GP || !n) continue;
+            DeviceBuf<uint32_t> mx;
+            mx.reserve(1, 0);
+            LAUNCH(k_max_value, n, values[f], n, mx.p);
+            mx.download(&max_value[f], 1);
+        }
         // empty statistics for all groups
         py.counts.assign((size_t)Kt, 0);
         py.reserve(Kt);
@@ -733,13 +744,36 @@ struct Gibbs {
         return fn.template run<-1, -1, 0>();
     }
 
-    void prepare(SweepParams & P) {
+    // size of feature f's k-major gather table (0 = none)
+    int ktab_values(int f) const {
+        const dist_shared_t & sh = feats[f]->sh;
+        size_t nv = 0;
+        if (sh.kind == DIST_GP) nv = std::min<size_t>(max_value[f] + 1, 64);
+        if (is_cat(sh.kind)) nv = (size_t)sh.dim;
+        if (nv * (size_t)K() > ((size_t)64 << 20)) return 0;   // > 256 MiB
+        return (int)nv;
+    }
+    // with_ktab = false: only tables that cost next to nothing are built
+    void prepare(SweepParams & P, bool with_ktab = true) {
         base.reserve(grow_capacity((size_t)K()), 0);
         base_single.reserve(grow_capacity((size_t)K()), 0);
         P.base = base.p;
         P.base_single = base_single.p;
         LAUNCH(k_sweep_prepare, (size_t)K(), P, base.p, base_single.p,
                scalars.p);
+        ktab.resize((size_t)F());
+        for (int f = 0; f < F(); ++f) {
+            int nv = ktab_values(f);
+            if (!with_ktab && (size_t)nv * K() > ((size_t)1 << 18)) nv = 0;
+            P.ktab[f] = nullptr;
+            P.ktab_nv[f] = 0;
+            if (!nv) continue;
+            const size_t n = (size_t)K() * nv;
+            ktab[f].reserve(grow_capacity(n), 0);
+            LAUNCH(k_build_ktab, n, feats[f]->view(), ktab[f].p, nv, K());
+            P.ktab[f] = ktab[f].p;
+            P.ktab_nv[f] = nv;
+        }
     }
 
     struct SampleLaunch {
@@ -773,12 +807,17 @@ struct Gibbs {
 
     int vs_nvals() const {
         const dist_shared_t & sh = feats[0]->sh;
-        return sh.kind == DIST_BB ? 2 : sh.dim;
+        if (sh.kind == DIST_BB) return 2;
+        if (sh.kind == DIST_GP)   // counts beyond the table: generic kernel
+            return (int)std::min<uint32_t>(max_value[0] + 1, 256);
+        return sh.dim;
     }
     bool use_value_sorted(size_t rows) const {
         if (value_sorted_mode == 0 || F() != 1) return false;
         const int kind = feats[0]->sh.kind;
-        if (kind != DIST_DD && kind != DIST_DPD && kind != DIST_BB) return false;
+        if (kind != DIST_DD && kind != DIST_DPD && kind != DIST_BB
+            && kind != DIST_GP)
+            return false;
         if (value_sorted_mode == 2) return true;
         return rows >= (size_t)64 * vs_nvals() && rows >= 4096;
     }
@@ -793,15 +832,19 @@ struct Gibbs {
         const uint32_t nv = (uint32_t)vs_nvals();
         DeviceBuf<uint32_t> hist;
         hist.reserve(nv + 1, 0);   // zero-filled
-        LAUNCH(k_vs_hist, n, values[0], r0, n, nv, hist.p);
+        const dim3 sort_grid((unsigned)((n + kVsSortRows - 1) / kVsSortRows));
+        hipLaunchKernelGGL(k_vs_hist, sort_grid, dim3(kBlock), 0, stream(),
+                           values[0], r0, n, nv, hist.p);
+        HIP_CHECK(hipGetLastError());
         std::vector<uint32_t> h(nv + 1), start(nv + 2, 0);
         hist.download(h.data(), nv + 1);
         for (uint32_t x = 0; x <= nv; ++x) start[x + 1] = start[x] + h[x];
         DeviceBuf<uint32_t> cursor;
         cursor.upload(start.data(), nv + 1);
         c->sorted_rows.reserve(std::max<size_t>(n, 1), 0);
-        LAUNCH(k_vs_scatter, n, values[0], r0, n, nv, cursor.p,
-               c->sorted_rows.p);
+        hipLaunchKernelGGL(k_vs_scatter, sort_grid, dim3(kBlock), 0, stream(),
+                           values[0], r0, n, nv, cursor.p, c->sorted_rows.p);
+        HIP_CHECK(hipGetLastError());
         std::vector<VsTile> tiles;
         for (uint32_t x = 0; x < nv; ++x)
             for (uint32_t off = 0; off < h[x]; off += 64 * kVsR)
@@ -869,7 +912,9 @@ struct Gibbs {
         vsArg.reserve(nv, 0);
         deferred.reserve(std::max<size_t>(n, 1), 0);
         deferred_count.reserve(1, 0);
-        prepare(P);   // base[], base_single[] and the scalars
+        // base[], base_single[] and the scalars; the few handed-over rows
+        // do not pay for a gather table
+        prepare(P, false);
         if (c.n_other)
             HIP_CHECK(hipMemcpyAsync(deferred.p, c.other_rows.p,
                                      4 * (size_t)c.n_other,
@@ -879,6 +924,7 @@ struct Gibbs {
         switch (feats[0]->sh.kind) {
         case DIST_DD: L.go<DIST_DD>(); break;
         case DIST_DPD: L.go<DIST_DPD>(); break;
+        case DIST_GP: L.go<DIST_GP>(); break;
         default: L.go<DIST_BB>(); break;
         }
         // the handed-over rows, by the generic kernel in list mode
@@ -989,6 +1035,7 @@ struct Gibbs {
             VsCache & c = vs_get(batch_begin, batch_end);
             const bool sort = lds_sort <= 60 * 1024;
             const bool bb = feats[0]->sh.kind == DIST_BB;
+            const bool gp = feats[0]->sh.kind == DIST_GP;
             const dim3 grid(c.n_chunks), block(kBlock);
 #define VS_APPLY(KIND, SORT, LDS)                                            \
             hipLaunchKernelGGL((k_vs_apply<KIND, SORT>), grid, block, LDS,   \
@@ -996,6 +1043,8 @@ struct Gibbs {
                                c.sorted_rows.p, d_p2g.p, assign)
             if (bb && sort) VS_APPLY(DIST_BB, true, lds_sort);
             else if (bb) VS_APPLY(DIST_BB, false, lds_plain);
+            else if (gp && sort) VS_APPLY(DIST_GP, true, lds_sort);
+            else if (gp) VS_APPLY(DIST_GP, false, lds_plain);
             else if (sort) VS_APPLY(DIST_DD, true, lds_sort);
             else VS_APPLY(DIST_DD, false, lds_plain);
 #undef VS_APPLY

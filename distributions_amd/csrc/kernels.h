@@ -221,7 +221,12 @@ struct SweepParams {
     const float * base_single; // the same for a row that was alone in its
                                // group: empty slots score with one non-empty
                                // group fewer (clustering.hpp:221-230)
-    const float * table0;      // unused by the kernels (kept for layout)
+    // per feature, optional k-major gather table [K][nv] rebuilt per batch:
+    //   GP:      the whole additive term for value v at group k
+    //   DD/DPD:  S[v][k] transposed (lanes of a wave then gather inside one
+    //            short row instead of striding over the value-major cache)
+    const float * ktab[kMaxF];
+    int ktab_nv[kMaxF];
     const SweepScalars * scalars;
     int K;
     int n_empty;
@@ -300,6 +305,21 @@ __global__ void k_sweep_prepare(SweepParams P, float * __restrict__ base,
     base_single[i] = (P.counts[i] == 0 ? empty_single : P.shifted[i]) + shift;
 }
 
+// k-major gather table of one feature (see SweepParams::ktab)
+__global__ void k_build_ktab(SlaveView v, float * __restrict__ tab, int nv,
+                             int K) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)K * nv) return;
+    const int k = (int)(i / nv);
+    const uint32_t x = (uint32_t)(i % nv);
+    if (is_cat(v.kind)) {
+        tab[i] = v.S[(size_t)x * v.cap + k];
+    } else {   // GP: gp.cc:62-65, the term added to the accumulator
+        const Entry e = {v.c0[k], v.c1[k], v.c2[k], v.c3[k]};
+        tab[i] = score_group(v.kind, e, x, fast_log_factorial(x));
+    }
+}
+
 // Scores of one row in batch semantics: state at batch entry minus the row.
 //   count(g) >= 2: group order unchanged; slot g scored from (stats - row).
 //   count(g) == 1: the group vanishes as MixtureDriver::remove_value does it
@@ -354,8 +374,29 @@ struct RowScorer {
 #pragma unroll kUnroll
         for (int f = 0; f < nf(); ++f) {
             const int kind = kind_of(f);
-            s = accumulate(kind, s, entry_at(P.feat[f], kind, k, x[f]), x[f],
-                           lf[f]);
+            const float * tab = P.ktab[f];
+            const int nv = P.ktab_nv[f];
+            if (tab != nullptr && kind == DIST_GP) {
+                // acc += term (gp.cc:62-65); values beyond the table compute it
+                const float term =
+                    x[f] < (uint32_t)nv
+                        ? tab[(size_t)k * nv + x[f]]
+                        : score_group(kind,
+                                      entry_at(P.feat[f], kind, k, x[f]),
+                                      x[f], lf[f]);
+                s = s + term;
+            } else if (tab != nullptr && is_cat(kind)
+                       && x[f] < (uint32_t)nv) {
+                Entry e;
+                e.c0 = as_uniform(P.feat[f].c0)[k];
+                e.c1 = tab[(size_t)k * nv + x[f]];
+                e.c2 = 0.f;
+                e.c3 = 0.f;
+                s = accumulate(kind, s, e, x[f], lf[f]);
+            } else {
+                s = accumulate(kind, s, entry_at(P.feat[f], kind, k, x[f]),
+                               x[f], lf[f]);
+            }
         }
         return s;
     }
@@ -552,10 +593,13 @@ __device__ __forceinline__ float vs_own_score(const SweepParams & P,
     return accumulate(v.kind, s, entry_after_remove(v, g, x), x, lf);
 }
 
-// does group g hold at least one row with value x?
+// could group g hold a row with value x?  (only then is the own-slot score of
+// (x, g) meaningful; a false positive is harmless: no lane uses the result)
 __device__ __forceinline__ bool vs_group_has_value(const SlaveView & v, int g,
                                                    uint32_t x) {
     if (is_cat(v.kind)) return v.cnt[(size_t)g * v.dim + x] >= 1;
+    if (v.kind == DIST_GP)
+        return (uint32_t)v.i0[g] >= 1u && (uint32_t)v.i1[g] >= x;
     return (x ? v.i0[g] : v.i1[g]) >= 1;   // BB: heads / tails
 }
 
@@ -571,7 +615,7 @@ __global__ __launch_bounds__(kBlock) void k_vs_prepare(
     SlaveView v = P.feat[0];
     v.kind = KIND;
     const int K = P.K;
-    const float lf = 0.f;
+    const float lf = KIND == DIST_GP ? fast_log_factorial(x) : 0.f;
     float * la = T.LA + (size_t)x * T.Kpad;
     float * lb = T.LB + (size_t)x * T.Kpad;
     // pass 1: scores, local (max, first arg-max, max of the rest)
@@ -745,6 +789,7 @@ __global__ __launch_bounds__(kBlock) void k_vs_sample(
     const int amax = T.argmax[x];
     const float ea = u2f(g_tables_dev.exp_ab[0]);
     const float eb = u2f(g_tables_dev.exp_ab[1]);
+    const float lf = KIND == DIST_GP ? fast_log_factorial(x) : 0.f;
 
     bool valid[kVsR], inA[kVsR], inB[kVsR];
     size_t row[kVsR];
@@ -769,7 +814,7 @@ __global__ __launch_bounds__(kBlock) void k_vs_sample(
             float s_own = 0.f;
             bool defer = (n_g == 1);
             if (!defer) {
-                s_own = vs_own_score(P, v, g[r], n_g, x, 0.f, shift);
+                s_own = vs_own_score(P, v, g[r], n_g, x, lf, shift);
                 defer = !classB && s_own > M;   // table rounding lifted it
             }
             if (defer) {
@@ -866,6 +911,9 @@ __global__ __launch_bounds__(kBlock) void k_vs_apply(
         atomicAdd(&img.counts[k], dlt);
         if (KIND == DIST_BB) {
             atomicAdd(x ? &img.i0[0][k] : &img.i1[0][k], dlt);
+        } else if (KIND == DIST_GP) {
+            atomicAdd(&img.i0[0][k], dlt);                    // count
+            atomicAdd(&img.i1[0][k], dlt * (int32_t)x);       // sum
         } else {
             atomicAdd(&img.i0[0][k], dlt);
             atomicAdd(&img.cnt[0][(size_t)k * dim + x], dlt);
@@ -899,23 +947,73 @@ __global__ __launch_bounds__(kBlock) void k_vs_apply(
     }
 }
 
-// counting sort of a batch's rows by value (one-time per batch range)
-__global__ void k_vs_hist(const uint32_t * __restrict__ values,
-                          size_t row_begin, size_t n, uint32_t nvals,
-                          uint32_t * __restrict__ hist) {
+__global__ void k_max_value(const uint32_t * __restrict__ values, size_t n,
+                            uint32_t * out) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t x = values[row_begin + i];
-    atomicAdd(&hist[x < nvals ? x : nvals], 1u);   // last bin: OTHER
+    uint32_t v = i < n ? values[i] : 0u;
+    for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, v);
 }
-__global__ void k_vs_scatter(const uint32_t * __restrict__ values,
-                             size_t row_begin, size_t n, uint32_t nvals,
-                             uint32_t * __restrict__ cursor,
-                             uint32_t * __restrict__ sorted_rows) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t x = values[row_begin + i];
-    sorted_rows[atomicAdd(&cursor[x < nvals ? x : nvals], 1u)] = (uint32_t)i;
+
+// counting sort of a batch's rows by value (one-time per batch range).  A
+// workgroup counts its rows in LDS first, so a small value domain does not
+// serialise on a handful of global counters.
+constexpr int kVsSortBins = 4096;   // LDS bins; larger domains go global
+constexpr int kVsSortRows = 4096;   // rows per workgroup
+
+__global__ __launch_bounds__(kBlock) void k_vs_hist(
+        const uint32_t * __restrict__ values, size_t row_begin, size_t n,
+        uint32_t nvals, uint32_t * __restrict__ hist) {
+    __shared__ uint32_t bins[kVsSortBins];
+    const bool local = nvals + 1 <= kVsSortBins;
+    if (local) {
+        for (uint32_t i = threadIdx.x; i <= nvals; i += kBlock) bins[i] = 0;
+        __syncthreads();
+    }
+    const size_t lo = (size_t)blockIdx.x * kVsSortRows;
+    const size_t hi = lo + kVsSortRows < n ? lo + kVsSortRows : n;
+    for (size_t i = lo + threadIdx.x; i < hi; i += kBlock) {
+        const uint32_t x = values[row_begin + i];
+        const uint32_t b = x < nvals ? x : nvals;   // last bin: outside the table
+        if (local) atomicAdd(&bins[b], 1u); else atomicAdd(&hist[b], 1u);
+    }
+    if (local) {
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i <= nvals; i += kBlock)
+            if (bins[i]) atomicAdd(&hist[i], bins[i]);
+    }
+}
+__global__ __launch_bounds__(kBlock) void k_vs_scatter(
+        const uint32_t * __restrict__ values, size_t row_begin, size_t n,
+        uint32_t nvals, uint32_t * __restrict__ cursor,
+        uint32_t * __restrict__ sorted_rows) {
+    __shared__ uint32_t bins[kVsSortBins];
+    const bool local = nvals + 1 <= kVsSortBins;
+    const size_t lo = (size_t)blockIdx.x * kVsSortRows;
+    const size_t hi = lo + kVsSortRows < n ? lo + kVsSortRows : n;
+    if (!local) {
+        for (size_t i = lo + threadIdx.x; i < hi; i += kBlock) {
+            const uint32_t x = values[row_begin + i];
+            sorted_rows[atomicAdd(&cursor[x < nvals ? x : nvals], 1u)] =
+                (uint32_t)i;
+        }
+        return;
+    }
+    // count, reserve one range per value for the whole workgroup, then place
+    for (uint32_t i = threadIdx.x; i <= nvals; i += kBlock) bins[i] = 0;
+    __syncthreads();
+    for (size_t i = lo + threadIdx.x; i < hi; i += kBlock) {
+        const uint32_t x = values[row_begin + i];
+        atomicAdd(&bins[x < nvals ? x : nvals], 1u);
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i <= nvals; i += kBlock)
+        bins[i] = bins[i] ? atomicAdd(&cursor[i], bins[i]) : 0u;
+    __syncthreads();
+    for (size_t i = lo + threadIdx.x; i < hi; i += kBlock) {
+        const uint32_t x = values[row_begin + i];
+        sorted_rows[atomicAdd(&bins[x < nvals ? x : nvals], 1u)] = (uint32_t)i;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1065,6 +1163,18 @@ __global__ __launch_bounds__(64) void k_replay_sorted(
             x = values[row_begin + (e >> 1)];
         }
         const int cnt = (int)min(64u, hi - base);
+        if (s.kind == DIST_GP) {
+            // only log_prod is order-dependent (gp.hpp:115,134): the terms are
+            // looked up by all lanes at once, the running sum stays in order
+            const float term = fast_log_factorial(x);
+            for (int j = 0; j < cnt; ++j) {
+                const uint32_t ej = __builtin_amdgcn_readlane((int)e, j);
+                const float tj = u2f((uint32_t)__builtin_amdgcn_readlane(
+                    (int)f2u(term), j));
+                if (ej & 1u) fl.f0 += tj; else fl.f0 -= tj;
+            }
+            continue;
+        }
         for (int j = 0; j < cnt; ++j) {
             const uint32_t ej = __builtin_amdgcn_readlane((int)e, j);
             const uint32_t xj = __builtin_amdgcn_readlane((int)x, j);

@@ -10,7 +10,7 @@ import workloads
 pytestmark = pytest.mark.gpu
 
 
-VS_ELIGIBLE = ("dd", "dd_skew", "bb", "dpd", "dpd_other")
+VS_ELIGIBLE = ("dd", "dd_skew", "bb", "dpd", "dpd_other", "gp")
 
 
 def both(config, n, k, alpha, d, empty=1, dim=None, seed=workloads.SEED,
@@ -89,7 +89,8 @@ def test_batch_sweeps_bit_exact(config, batch, mode):
 
 
 @pytest.mark.parametrize("config,dim,k", [("dd", 256, 64), ("dd_skew", 64, 16),
-                                          ("dpd_other", 300, 24), ("bb", None, 8)])
+                                          ("dpd_other", 300, 24), ("bb", None, 8),
+                                          ("gp", None, 12)])
 def test_value_sorted_larger_batches(config, dim, k):
     """default mode picks the value-sorted kernel for large batches; groups of
     very different sizes make rows sit in the arg-max group (class B)."""
@@ -118,7 +119,7 @@ def test_sequential_chain_bit_exact(config):
 
 
 @pytest.mark.parametrize("config,mode", [("dd", 0), ("dd", 2), ("gp_nich", 0),
-                                         ("bb", 2)])
+                                         ("bb", 2), ("gp", 2)])
 @pytest.mark.parametrize("empty", [1, 3])
 def test_group_creation_and_removal(config, mode, empty):
     """Many groups, few rows, large alpha: rows are alone in their group,
