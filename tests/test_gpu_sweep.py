@@ -136,3 +136,61 @@ def test_group_creation_and_removal(config, mode, empty):
     st2 = orc.gibbs_sequential(0, n, st)
     assert gpu.sweep_sequential(0, n, st) == st2
     assert_same_state(orc, gpu, "dynamic sequential")
+
+
+def test_randomised_configurations():
+    """random feature lists, group counts, hyper-parameters, batch sizes and
+    seeds: every sweep bit-exact against the oracle"""
+    from distributions_amd import engine
+    rng = np.random.default_rng(31337)
+    L = ol.oracle()
+    for trial in range(24):
+        n = int(rng.integers(200, 9000))
+        k = int(rng.integers(1, 40))
+        empty = int(rng.integers(1, 4))
+        alpha = float(rng.choice([0.1, 1.0, 7.5]))
+        d = float(rng.choice([0.0, 0.2, 0.7]))
+        feats_o, feats_g, vals = [], [], []
+        for _ in range(int(rng.integers(1, 4))):
+            kind = rng.choice(["dd", "bb", "gp", "nich"])
+            if kind == "dd":
+                dim = int(rng.integers(2, 40))
+                alphas = [float(a) for a in rng.uniform(0.2, 3.0, dim)]
+                feats_o.append(ol.make_shared(ol.DD, alphas=alphas))
+                feats_g.append(engine.dd_shared(alphas))
+                vals.append(rng.integers(0, dim, n).astype(np.uint32))
+            elif kind == "bb":
+                a, b = float(rng.uniform(0.3, 4)), float(rng.uniform(0.3, 4))
+                feats_o.append(ol.make_shared(ol.BB, alpha=a, beta=b))
+                feats_g.append(engine.bb_shared(a, b))
+                vals.append((rng.random(n) < 0.4).astype(np.uint32))
+            elif kind == "gp":
+                a = float(rng.integers(1, 5))   # integer alpha: see DESIGN 6
+                ib = float(rng.uniform(0.3, 3))
+                feats_o.append(ol.make_shared(ol.GP, alpha=a, inv_beta=ib))
+                feats_g.append(engine.gp_shared(a, ib))
+                vals.append(rng.poisson(float(rng.uniform(0.5, 30)), n).astype(
+                    np.uint32))
+            else:
+                p = [float(rng.normal()), float(rng.uniform(0.3, 3)),
+                     float(rng.uniform(0.3, 3)), float(rng.uniform(0.5, 5))]
+                feats_o.append(ol.make_shared(ol.NICH, mu=p[0], kappa=p[1],
+                                              sigmasq=p[2], nu=p[3]))
+                feats_g.append(engine.nich_shared(*p))
+                vals.append((rng.normal(size=n) * 3).astype(np.float32))
+        assign = rng.integers(0, k, n).astype(np.uint32)
+        # every initial group must be non-empty
+        assign[:k] = np.arange(k)
+        orc = ol.OracleMixture(alpha, d, feats_o)
+        orc.init_from_assignments(vals, assign, k, empty)
+        gpu = engine.Gibbs(alpha, d, feats_g)
+        gpu.set_option("value_sorted", int(rng.choice([0, 1, 2])))
+        gpu.load_rows(vals, assign, k, empty)
+        seed = int(rng.integers(1, 2 ** 31))
+        st = L.orc_rng_seed(seed)
+        batch = int(rng.choice([64, 777, 4096, n]))
+        for sweep in range(2):
+            for b in range(0, n, batch):
+                orc.gibbs_batch(b, min(n, b + batch), st, sweep * n)
+            gpu.sweep(0, n, batch, seed, draw_base=sweep * n)
+            assert_same_state(orc, gpu, "trial %d sweep %d" % (trial, sweep))
