@@ -1069,47 +1069,7 @@ __global__ void k_add_words(int32_t * __restrict__ dst,
 
 // Float statistics (NICH count/mean/ctv, GP log_prod) depend on update order
 // (nich.hpp:125-165 is a running Welford update), so they are replayed per
-// group in row order: one wave per group walks the batch 64 rows at a time
-// and applies "remove from old, then add to new" for the rows that touch its
-// group -- the order the sequential chain would apply them in.
-// old_packed == nullptr means rows are only added (initial load).
-__global__ __launch_bounds__(64) void k_replay_floats(
-        SlaveView s, const uint32_t * __restrict__ values,
-        const uint32_t * __restrict__ old_packed,
-        const uint32_t * __restrict__ new_packed, size_t row_begin,
-        size_t n_rows) {
-    const int k = blockIdx.x;
-    const int lane = threadIdx.x;
-    Stats st = load_stats(s, k);
-    const bool ints_too = (s.kind == DIST_NICH);
-    Stats fl = st;   // running copy whose float members are authoritative
-    for (size_t base = 0; base < n_rows; base += 64) {
-        const size_t b = base + lane;
-        uint32_t go = 0xFFFFFFFFu, gn = 0xFFFFFFFFu, x = 0;
-        if (b < n_rows) {
-            gn = new_packed[b];
-            go = old_packed ? old_packed[b] : 0xFFFFFFFFu;
-            x = values[row_begin + b];
-        }
-        unsigned long long touched =
-            __ballot(go == (uint32_t)k || gn == (uint32_t)k);
-        while (touched) {
-            const int j = __ffsll((long long)touched) - 1;
-            touched &= touched - 1;
-            const uint32_t xj = __shfl(x, j);
-            const uint32_t goj = __shfl(go, j);
-            const uint32_t gnj = __shfl(gn, j);
-            if (goj == (uint32_t)k) stats_remove(s.kind, fl, xj);
-            if (gnj == (uint32_t)k) stats_add(s.kind, fl, xj);
-        }
-    }
-    if (lane == 0) {
-        s.f0[k] = fl.f0;
-        s.f1[k] = fl.f1;
-        if (ints_too) s.i0[k] = fl.i0;
-    }
-}
-
+// group in row order -- the order the sequential chain would apply them in.
 // ---- ordered replay through a stable sort of the events by group ----------
 // events of batch row b: 2b = "remove from old[b]", 2b+1 = "add to new[b]";
 // sorted stably by group they are, per group, in row order with the removal
