@@ -41,7 +41,7 @@ def parse():
                     help="rows per GPU")
     ap.add_argument("--groups", type=int, default=1024)
     ap.add_argument("--dim", type=int, default=256)
-    ap.add_argument("--batch", type=int, default=1 << 20,
+    ap.add_argument("--batch", type=int, default=1_000_000,
                     help="rows per frozen sub-sweep (per GPU)")
     ap.add_argument("--alpha", type=float, default=1.0)
     ap.add_argument("--d", type=float, default=0.2)

@@ -750,7 +750,7 @@ struct Gibbs {
         size_t nv = 0;
         if (sh.kind == DIST_GP) nv = std::min<size_t>(max_value[f] + 1, 64);
         if (is_cat(sh.kind)) nv = (size_t)sh.dim;
-        if (nv * (size_t)K() > ((size_t)64 << 20)) return 0;   // > 256 MiB
+        if (nv * (size_t)K() > ((size_t)256 << 20)) return 0;   // > 1 GiB
         return (int)nv;
     }
     // with_ktab = false: only tables that cost next to nothing are built
@@ -819,7 +819,7 @@ struct Gibbs {
             && kind != DIST_GP)
             return false;
         if (value_sorted_mode == 2) return true;
-        return rows >= (size_t)64 * vs_nvals() && rows >= 4096;
+        return rows >= (size_t)16 * vs_nvals() && rows >= 4096;
     }
 
     VsCache & vs_get(size_t r0, size_t r1) {
@@ -890,11 +890,19 @@ struct Gibbs {
                                c->n_other);
             HIP_CHECK(hipGetLastError());
             HIP_CHECK(hipEventRecord(self->ev0, stream()));
-            hipLaunchKernelGGL((k_vs_sample<KIND>),
-                               dim3((c->n_tiles + 3) / 4), dim3(kBlock), 0,
-                               stream(), *P, T, c->tiles.p, c->n_tiles,
-                               c->sorted_rows.p, self->deferred.p,
-                               self->deferred_count.p);
+            // likelihood tables beyond a few MiB stream from HBM: vector loads
+            const bool vec = (size_t)nv * T.Kpad * 4 > ((size_t)4 << 20);
+            const dim3 grid((c->n_tiles + 3) / 4), block(kBlock);
+            if (vec)
+                hipLaunchKernelGGL((k_vs_sample<KIND, true>), grid, block, 0,
+                                   stream(), *P, T, c->tiles.p, c->n_tiles,
+                                   c->sorted_rows.p, self->deferred.p,
+                                   self->deferred_count.p);
+            else
+                hipLaunchKernelGGL((k_vs_sample<KIND, false>), grid, block, 0,
+                                   stream(), *P, T, c->tiles.p, c->n_tiles,
+                                   c->sorted_rows.p, self->deferred.p,
+                                   self->deferred_count.p);
             HIP_CHECK(hipGetLastError());
             HIP_CHECK(hipEventRecord(self->ev1, stream()));
         }
