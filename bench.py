@@ -14,8 +14,10 @@ are sharded, weak scaling (N rows per GPU), one all-reduce of the integer
 statistic deltas per sub-sweep.
 
 Prints ONE JSON line (rank 0).  `roofline` prices the score+sample kernel
-(k_sweep_sample) by ALGORITHMIC bytes: (12*K + 12) B per row over
-its HIP-event duration on the launch stream.  `cpu_baseline` times the
+(k_vs_sample, or k_sweep_sample when the value-sorted kernel does not apply)
+by ALGORITHMIC bytes: (12*K + 12) B per row over its HIP-event
+duration on the launch stream; `traffic` is the HBM byte count per launch from
+the committed rocprofv3 PMC passes (profiles/).  `cpu_baseline` times the
 oracle's sequential chain (the reference loop restated, oracle/oracle.c) on a
 bounded row sample of the same workload, one host thread.
 """
@@ -56,6 +58,20 @@ def parse():
     ap.add_argument("--value-sorted", type=int, default=1,
                     help="0 generic kernel only, 1 auto, 2 force")
     return ap.parse_args()
+
+
+def measured_traffic(kernel, rows_per_launch):
+    """HBM bytes per launch of `kernel` from the committed PMC passes
+    (profiles/r1_traffic.json: FETCH_SIZE + WRITE_SIZE, separate rocprofv3
+    --pmc runs of this same command), scaled to this run's rows per launch.
+    None when no measurement is on file for the kernel."""
+    path = os.path.join(ROOT, "profiles", "r1_traffic.json")
+    try:
+        rec = json.load(open(path))[kernel]
+    except (OSError, KeyError, ValueError):
+        return None
+    kb = rec["fetch_kb_per_launch"] + rec["write_kb_per_launch"]
+    return kb * 1024.0 * rows_per_launch / rec["rows_per_launch"]
 
 
 def cpu_baseline(args):
@@ -220,7 +236,7 @@ def main():
                 "unit": "GB/s",
                 "frac": (bytes_per_row * rows) / (1e-3 * ms) / 1e9
                         / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": measured_traffic(kernel, rows / max(launches, 1)),
                 "algorithmic_bytes_per_row": bytes_per_row,
                 "rows_per_launch": rows / max(launches, 1),
                 "avg_launch_ms": ms / max(launches, 1),
