@@ -17,6 +17,16 @@ if not _os.path.exists(_os.path.join(_here, "libdistributions_hip.so")):
         "distributions_amd/libdistributions_hip.so is missing: run "
         "`python __graft_entry__.py` (hipcc, gfx950) first")
 
+# PyTorch-ROCm wheels bundle their own libamdhip64.so.7 / libhsa-runtime64.
+# Two HIP runtimes in one process cannot both own the GPU, so whichever is
+# loaded first must serve both: load torch's first when torch is installed
+# (libdistributions_hip then binds to it by SONAME); without torch the
+# system runtime under /opt/rocm is used.
+try:  # noqa: E402
+    import torch as _torch  # noqa: F401
+except ImportError:  # pragma: no cover
+    _torch = None
+
 from . import _core  # noqa: E402,F401
 
 __version__ = "0.1.0"

@@ -120,7 +120,8 @@ class ShardedGibbs(object):
     gloo.
     """
 
-    def __init__(self, backend, n_local, row_offset, group=None, device=None):
+    def __init__(self, backend, n_local, row_offset, group=None, device=None,
+                 force_collective=False):
         import torch.distributed as dist
         self.dist = dist
         self.backend = backend
@@ -129,16 +130,20 @@ class ShardedGibbs(object):
         self.group = group
         self.device = device
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # force_collective: take the delta + all-reduce path even with one
+        # rank (what N > 1 runs, exercised on a single GPU)
+        self.collective = self.world > 1 or (force_collective
+                                             and dist.is_initialized())
 
     def _all_reduce(self, tensor):
-        if self.world > 1:
+        if self.collective:
             self.dist.all_reduce(tensor, op=self.dist.ReduceOp.SUM,
                                  group=self.group)
 
     def sync_initial_stats(self):
         """After every rank loaded ITS rows: make the statistics global."""
         import torch
-        if self.world == 1:
+        if not self.collective:
             return
         n = self.backend.stat_words()
         t = torch.zeros(n, dtype=torch.int32, device=self.device)
@@ -151,7 +156,7 @@ class ShardedGibbs(object):
         sub-sweeps (shards are equal up to one batch of padding)."""
         import torch
         n_batches = (self.n_local + batch_rows - 1) // batch_rows
-        if self.world > 1:
+        if self.collective:
             nb = torch.tensor([n_batches], dtype=torch.int64,
                               device=self.device)
             self.dist.all_reduce(nb, op=self.dist.ReduceOp.MAX,
@@ -161,7 +166,7 @@ class ShardedGibbs(object):
             r0 = min(self.n_local, b * batch_rows)
             r1 = min(self.n_local, r0 + batch_rows)
             self.backend.batch_sample(r0, r1, seed_state, draw_base)
-            if self.world == 1:
+            if not self.collective:
                 self.backend.batch_apply_local()
             else:
                 n = self.backend.stat_words()

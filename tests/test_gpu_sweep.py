@@ -194,3 +194,48 @@ def test_randomised_configurations():
                 orc.gibbs_batch(b, min(n, b + batch), st, sweep * n)
             gpu.sweep(0, n, batch, seed, draw_base=sweep * n)
             assert_same_state(orc, gpu, "trial %d sweep %d" % (trial, sweep))
+
+
+@pytest.mark.parametrize("config", ["dd", "bb", "gp", "dd_bb_gp"])
+def test_delta_all_reduce_path_single_rank_nccl(config):
+    """the multi-GPU code path (integer statistic deltas, RCCL all-reduce,
+    apply, lock-step normalisation) driven with ONE rank on the real backend:
+    must equal the direct path bit for bit"""
+    import os
+    import torch
+    import torch.distributed as dist
+    from distributions_amd import engine, _core
+    n, k = 20000, 20
+    osh, gsh, vals, assign = workloads.make(config, n, k)
+    orc = ol.OracleMixture(1.0, 0.2, osh)
+    orc.init_from_assignments(vals, assign, k, 2)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        dev = torch.device("cuda", 0)
+        cols = [torch.from_numpy(ol.value_words(s.kind, v).view(np.int32)).to(dev)
+                for s, v in zip(osh, vals)]
+        a = torch.from_numpy(assign.view(np.int32)).to(dev)
+        gpu = engine.Gibbs(1.0, 0.2, gsh)
+        gpu.load_rows_torch(cols, a, k, 2)
+        sharded = engine.ShardedGibbs(gpu.core, n, 0, device=dev,
+                                      force_collective=True)
+        sharded.sync_initial_stats()
+        st = ol.oracle().orc_rng_seed(5)
+        for sweep in range(2):
+            for b in range(0, n, 6000):
+                orc.gibbs_batch(b, min(n, b + 6000), st, sweep * n)
+            sharded.sweep(6000, _core.rng_seed(5), draw_base=sweep * n)
+            torch.cuda.synchronize()
+            if config == "gp":
+                # log_prod is replayed from local rows; ints + assignments
+                np.testing.assert_array_equal(gpu.counts(), orc.counts())
+                np.testing.assert_array_equal(gpu.assignments(), orc.assign)
+            else:
+                assert_same_state(orc, gpu, "%s delta sweep %d" % (config, sweep))
+    finally:
+        if created:
+            dist.destroy_process_group()
