@@ -53,6 +53,7 @@ cdef extern from "distributions_hip.h" nogil:
     int dist_log_sum_exp(size_t, const float *, float *)
     int dist_py_score_add_value(float, float, int, int, int, int, float *)
     int dist_py_score_remove_value(float, float, int, int, int, int, float *)
+    int dist_py_score_counts(float, float, const int *, size_t, float *)
 
     ctypedef struct dist_py_mixture_t:
         pass
@@ -66,6 +67,8 @@ cdef extern from "distributions_hip.h" nogil:
                                      int *)
     int dist_py_mixture_score_value(const dist_py_mixture_t *, float, float,
                                     float *, size_t)
+    int dist_py_mixture_score_data(const dist_py_mixture_t *, float, float,
+                                   float *)
     size_t dist_py_mixture_size(const dist_py_mixture_t *)
     size_t dist_py_mixture_sample_size(const dist_py_mixture_t *)
     int dist_py_mixture_counts(const dist_py_mixture_t *, int *)
@@ -89,12 +92,14 @@ cdef extern from "distributions_hip.h" nogil:
                                        uint32_t, float *)
     int dist_mixture_score_value(const dist_mixture_t *, uint32_t, float *,
                                  size_t)
+    int dist_mixture_score_data(const dist_mixture_t *, float *)
 
     int dist_group_init(const dist_shared_t *, uint32_t *)
     int dist_group_add_value(const dist_shared_t *, uint32_t *, uint32_t)
     int dist_group_remove_value(const dist_shared_t *, uint32_t *, uint32_t)
     int dist_group_score_value(const dist_shared_t *, const uint32_t *,
                                uint32_t, float *)
+    int dist_group_score_data(const dist_shared_t *, const uint32_t *, float *)
 
     ctypedef struct dist_id_tracker_t:
         pass
@@ -258,6 +263,12 @@ cdef class SharedParams:
         return out
 
 
+    def group_score_data(self, cnp.ndarray[cnp.uint32_t, ndim=1] g):
+        cdef float out = 0
+        check(dist_group_score_data(&self.c, <const uint32_t *> g.data, &out))
+        return out
+
+
 # ---------------------------------------------------------------------------
 # entropy and sampling
 
@@ -381,6 +392,15 @@ def py_score_remove_value(float alpha, float d, int group_size,
     return out
 
 
+def py_score_counts(float alpha, float d, counts):
+    cdef cnp.ndarray[cnp.int32_t, ndim=1] c = np.ascontiguousarray(
+        counts, dtype=np.int32)
+    cdef float out = 0
+    check(dist_py_score_counts(alpha, d, <const int *> c.data, c.shape[0],
+                               &out))
+    return out
+
+
 # ---------------------------------------------------------------------------
 # PitmanYor::Mixture
 
@@ -421,6 +441,11 @@ cdef class PyMixture:
         check(dist_py_mixture_score_value(self.ptr, alpha, d,
                                           <float *> scores.data,
                                           scores.shape[0]))
+
+    def score_data(self, float alpha, float d):
+        cdef float out = 0
+        check(dist_py_mixture_score_data(self.ptr, alpha, d, &out))
+        return out
 
     def sample_size(self):
         return dist_py_mixture_sample_size(self.ptr)
@@ -500,6 +525,11 @@ cdef class SlaveMixture:
         check(dist_mixture_score_value(self.ptr, value,
                                        <float *> scores_accum.data,
                                        scores_accum.shape[0]))
+
+    def score_data(self):
+        cdef float out = 0
+        check(dist_mixture_score_data(self.ptr, &out))
+        return out
 
 
 # ---------------------------------------------------------------------------

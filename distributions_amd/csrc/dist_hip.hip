@@ -128,10 +128,23 @@ struct Slave {
     DeviceBuf<int32_t> i0, i1, cnt;
     DeviceBuf<float> f0, f1, c0, c1, c2, c3, S, prior, other;
     float other_host = 0.f;
+    float gp_lut[12] = {0};   // see gp_lgamma (models.h)
 
     explicit Slave(const dist_shared_t & shared) : sh(shared) {
         check_shared(sh);
         ensure_device_ready();
+        if (sh.kind == DIST_GP) {
+            // every float (alpha + s) + x with s + x <= 2, and glibc's lgammaf
+            // of it (the call the reference makes, special.hpp:121-123)
+            int n = 0;
+            for (int s = 0; s <= 2; ++s)
+                for (int x = 0; s + x <= 2; ++x) {
+                    const float y = (sh.p[0] + (float)s) + (float)x;
+                    gp_lut[n] = y;
+                    gp_lut[6 + n] = ::lgammaf(y);
+                    n += 1;
+                }
+        }
         if (sh.kind == DIST_DD) {
             // dd.hpp:403-406: alpha_sum_ accumulates in index order
             alpha_sum = 0.f;
@@ -159,6 +172,7 @@ struct Slave {
         v.kind = sh.kind;
         v.dim = sh.dim;
         for (int i = 0; i < 4; ++i) v.p[i] = sh.p[i];
+        for (int i = 0; i < 12; ++i) v.p[4 + i] = gp_lut[i];
         v.alpha_sum = alpha_sum;
         v.other = other_host;
         v.K = K;
@@ -318,6 +332,17 @@ struct Slave {
         float out;
         sc.f.download(&out, 1);
         return out;
+    }
+    float score_data() const {                // mixture.hpp:427-431
+        if (!K) return 0.f;
+        DeviceBuf<double> out;
+        out.reserve(1, 0);   // zero-filled
+        const size_t width = is_cat(sh.kind) ? sh.dim : 1;
+        SlaveView v = view();
+        LAUNCH(k_score_data, (size_t)K * width, v, out.p);
+        double total = 0.0;
+        out.download(&total, 1);
+        return (float)total;
     }
     void score_value(uint32_t value, float * acc, size_t size) const {
         DIST_REQUIRE(size == (size_t)K, "scores_accum != len(mixture)");
@@ -1305,6 +1330,32 @@ int dist_log_sum_exp(size_t n, const float * scores, float * out_value) {
     });
 }
 
+// PitmanYor::score_counts (src/clustering.cc:152-183) on device: the integer
+// prefixes are formed on the host, the float terms on the GPU
+static float py_score_counts(float alpha, float d, const int * counts,
+                             size_t n) {
+    ensure_device_ready();
+    if (!n) return 0.f;
+    std::vector<unsigned long long> before(2 * n);
+    unsigned long long ne = 0, rows = 0;
+    for (size_t k = 0; k < n; ++k) {
+        DIST_REQUIRE(counts[k] >= 0, "negative group size");
+        before[2 * k] = ne;
+        before[2 * k + 1] = rows;
+        if (counts[k]) { ne += 1; rows += (unsigned long long)counts[k]; }
+    }
+    DeviceBuf<int32_t> c;
+    DeviceBuf<unsigned long long> b;
+    DeviceBuf<double> out;
+    c.upload(counts, n);
+    b.upload(before.data(), 2 * n);
+    out.reserve(1, 0);
+    LAUNCH(k_py_score_counts, n, c.p, b.p, (int)n, alpha, d, out.p);
+    double total = 0.0;
+    out.download(&total, 1);
+    return (float)total;
+}
+
 // ---- PitmanYor --------------------------------------------------------------
 int dist_py_score_add_value(float alpha, float d, int group_size,
                             int nonempty, int sample_size, int empty,
@@ -1329,6 +1380,18 @@ int dist_py_score_remove_value(float alpha, float d, int group_size,
                                      sample_size, empty, out);
     if (rc == 0) *out = -*out;
     return rc;
+}
+
+int dist_py_score_counts(float alpha, float d, const int * counts, size_t n,
+                         float * out) {
+    return guarded([&] { *out = py_score_counts(alpha, d, counts, n); });
+}
+int dist_py_mixture_score_data(const dist_py_mixture_t * m, float alpha,
+                               float d, float * out) {
+    return guarded([&] {
+        *out = py_score_counts(alpha, d, m->impl.counts.data(),
+                               m->impl.counts.size());
+    });
 }
 
 dist_py_mixture_t * dist_py_mixture_create(void) {
@@ -1429,6 +1492,10 @@ int dist_mixture_score_value(const dist_mixture_t * m, uint32_t value,
     return guarded([&] { m->impl->score_value(value, scores_accum, size); });
 }
 
+int dist_mixture_score_data(const dist_mixture_t * m, float * out) {
+    return guarded([&] { *out = m->impl->score_data(); });
+}
+
 // ---- Model::Group (host scalars over the same inline model code) -----------
 int dist_group_init(const dist_shared_t * shared, uint32_t * group) {
     return guarded([&] {
@@ -1499,7 +1566,37 @@ int dist_group_score_value(const dist_shared_t * sh, const uint32_t * group,
         const Stats st = group_to_stats(*sh, group);
         const Entry e = scorer_init(sh->kind, sh->p, st);
         const float lf = sh->kind == DIST_GP ? fast_log_factorial(value) : 0.f;
-        *out = score_group(sh->kind, e, value, lf);
+        *out = score_group(sh->kind, e, value, lf, sh->p);
+    });
+}
+
+int dist_group_score_data(const dist_shared_t * sh, const uint32_t * group,
+                          float * out) {
+    return guarded([&] {
+        ensure_host_tables();
+        check_shared(*sh);
+        if (is_cat(sh->kind)) {   // dd.hpp:160-177, dpd.hpp:234-250
+            const float alpha_sum = [&] {
+                if (sh->kind == DIST_DPD) return sh->p[0];
+                float a = 0.f;
+                for (int v = 0; v < sh->dim; ++v) a += sh->alphas[v];
+                return a;
+            }();
+            float score = 0.f;
+            for (int v = 0; v < sh->dim; ++v) {
+                const float prior = sh->kind == DIST_DD
+                    ? sh->alphas[v] : sh->p[0] * sh->betas[v];
+                const int32_t c = (int32_t)group[1 + v];
+                if (sh->kind == DIST_DPD && c == 0) continue;   // sparse counts
+                score += fast_lgamma(prior + (float)c) - fast_lgamma(prior);
+            }
+            score += fast_lgamma(alpha_sum)
+                   - fast_lgamma(alpha_sum + (float)(int32_t)group[0]);
+            *out = score;
+            return;
+        }
+        *out = scalar_group_score_data(sh->kind, sh->p,
+                                       group_to_stats(*sh, group));
     });
 }
 

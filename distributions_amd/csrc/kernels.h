@@ -194,12 +194,64 @@ __global__ void k_slave_score_value(SlaveView s, uint32_t value,
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= K) return;
     const float lf = s.kind == DIST_GP ? fast_log_factorial(value) : 0.f;
-    acc[k] = accumulate(s.kind, acc[k], load_entry(s, k, value), value, lf);
+    acc[k] = accumulate(s.kind, acc[k], load_entry(s, k, value), value, lf,
+                        s.p);
 }
 __global__ void k_slave_score_group(SlaveView s, int k, uint32_t value,
                                     float * out) {
     const float lf = s.kind == DIST_GP ? fast_log_factorial(value) : 0.f;
-    *out = score_group(s.kind, load_entry(s, k, value), value, lf);
+    *out = score_group(s.kind, load_entry(s, k, value), value, lf, s.p);
+}
+
+// ---------------------------------------------------------------------------
+// MixtureDataScorer::score_data (dd.hpp:250-256,287-318; dpd.hpp:344-374;
+// bb.hpp:207-229; gp.hpp:220-241; nich.hpp:262-288): every float term is the
+// reference's; the terms are summed in binary64 (the reference accumulates in
+// float, DD through the re-associated vector_sum) -- stated tolerance 1e-5
+// relative against a float restatement of the reference's loops.
+
+__device__ __forceinline__ void block_sum_to(double v, double * out) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if ((threadIdx.x & 63) == 0 && v != 0.0) atomicAdd(out, v);
+}
+
+__global__ void k_score_data(SlaveView s, double * out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    double acc = 0.0;
+    if (is_cat(s.kind)) {
+        const size_t n = (size_t)s.K * s.dim;
+        if (i < n) {
+            const int k = (int)(i / s.dim);
+            const int v = (int)(i % s.dim);
+            if (s.i0[k] != 0) {
+                const float prior = s.prior[v];
+                acc += (double)(fast_lgamma(
+                                    prior + (float)s.cnt[(size_t)k * s.dim + v])
+                                - fast_lgamma(prior));
+                if (v == 0)
+                    acc += (double)(fast_lgamma(s.alpha_sum)
+                                    - fast_lgamma(s.alpha_sum + (float)s.i0[k]));
+            }
+        }
+    } else if (i < (size_t)s.K) {
+        float t[4];
+        const int nt = scalar_mixture_score_terms(s.kind, s.p,
+                                                  load_stats(s, (int)i), t);
+        for (int j = 0; j < nt; ++j) acc += (double)t[j];
+    }
+    block_sum_to(acc, out);
+}
+
+// PitmanYor::score_counts: before[k] = (non-empty groups, rows) ahead of k
+__global__ void k_py_score_counts(const int32_t * __restrict__ counts,
+                                  const unsigned long long * __restrict__ before,
+                                  int K, float alpha, float d, double * out) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    double acc = 0.0;
+    if (k < K && counts[k] > 0)
+        acc = py_score_counts_term(alpha, d, counts[k], before[2 * k],
+                                   before[2 * k + 1]);
+    block_sum_to(acc, out);
 }
 
 // ---------------------------------------------------------------------------
@@ -316,7 +368,7 @@ __global__ void k_build_ktab(SlaveView v, float * __restrict__ tab, int nv,
         tab[i] = v.S[(size_t)x * v.cap + k];
     } else {   // GP: gp.cc:62-65, the term added to the accumulator
         const Entry e = {v.c0[k], v.c1[k], v.c2[k], v.c3[k]};
-        tab[i] = score_group(v.kind, e, x, fast_log_factorial(x));
+        tab[i] = score_group(v.kind, e, x, fast_log_factorial(x), v.p);
     }
 }
 
@@ -383,7 +435,7 @@ struct RowScorer {
                         ? tab[(size_t)k * nv + x[f]]
                         : score_group(kind,
                                       entry_at(P.feat[f], kind, k, x[f]),
-                                      x[f], lf[f]);
+                                      x[f], lf[f], P.feat[f].p);
                 s = s + term;
             } else if (tab != nullptr && is_cat(kind)
                        && x[f] < (uint32_t)nv) {
@@ -392,10 +444,10 @@ struct RowScorer {
                 e.c1 = tab[(size_t)k * nv + x[f]];
                 e.c2 = 0.f;
                 e.c3 = 0.f;
-                s = accumulate(kind, s, e, x[f], lf[f]);
+                s = accumulate(kind, s, e, x[f], lf[f], P.feat[f].p);
             } else {
                 s = accumulate(kind, s, entry_at(P.feat[f], kind, k, x[f]),
-                               x[f], lf[f]);
+                               x[f], lf[f], P.feat[f].p);
             }
         }
         return s;
@@ -420,7 +472,7 @@ struct RowScorer {
                 SlaveView v = P.feat[f];
                 v.kind = kind_of(f);
                 s = accumulate(v.kind, s, entry_after_remove(v, g, x[f]),
-                               x[f], lf[f]);
+                               x[f], lf[f], v.p);
             }
             s_own = s;
         } else {
@@ -432,7 +484,7 @@ struct RowScorer {
                 SlaveView v = P.feat[f];
                 v.kind = kind_of(f);
                 s = accumulate(v.kind, s, load_entry(v, src, x[f]), x[f],
-                               lf[f]);
+                               lf[f], v.p);
             }
             s_own = s;
         }
@@ -545,7 +597,7 @@ __global__ void k_score_rows(SweepParams P, float * __restrict__ out,
         const SlaveView & v = P.feat[f];
         const uint32_t x = P.values[f][row];
         const float lf = v.kind == DIST_GP ? fast_log_factorial(x) : 0.f;
-        s = accumulate(v.kind, s, load_entry(v, k, x), x, lf);
+        s = accumulate(v.kind, s, load_entry(v, k, x), x, lf, v.p);
     }
     out[r * ld + k] = s;
 }
@@ -590,7 +642,7 @@ __device__ __forceinline__ float vs_own_score(const SweepParams & P,
                                               int n_g, uint32_t x, float lf,
                                               float shift) {
     const float s = py_nonempty_score(n_g - 1, P.d) + shift;
-    return accumulate(v.kind, s, entry_after_remove(v, g, x), x, lf);
+    return accumulate(v.kind, s, entry_after_remove(v, g, x), x, lf, v.p);
 }
 
 // could group g hold a row with value x?  (only then is the own-slot score of
@@ -622,7 +674,8 @@ __global__ __launch_bounds__(kBlock) void k_vs_prepare(
     float m1 = -INFINITY, m2 = -INFINITY;
     int i1 = 0x7fffffff;
     for (int k = threadIdx.x; k < K; k += kBlock) {
-        const float s = accumulate(KIND, P.base[k], load_entry(v, k, x), x, lf);
+        const float s =
+            accumulate(KIND, P.base[k], load_entry(v, k, x), x, lf, v.p);
         la[k] = s;
         if (s > m1) { m2 = m1; m1 = s; i1 = k; }
         else if (s > m2) m2 = s;

@@ -24,7 +24,10 @@ namespace dist {
 struct SlaveView {
     int kind;
     int dim;          // categorical kinds: number of values
-    float p[4];       // hyper-parameters (dist_shared_t::p)
+    float p[16];      // [0..3] hyper-parameters (dist_shared_t::p);
+                      // GP: [4..9] the arguments below 2.5 that fast_lgamma
+                      // can see ((alpha + s) + x, s + x <= 2) and [10..15]
+                      // glibc's lgammaf of each (see gp_lgamma)
     float alpha_sum;  // DD: sum of alphas (dd.hpp:403-406); DPD: alpha
     float other;      // DPD: fast_log(alpha * beta0), score of OTHER
     int K;            // groups
@@ -120,6 +123,24 @@ DIST_HD void stats_remove(int kind, Stats & s, uint32_t value) {
     }
 }
 
+// fast_lgamma as GammaPoisson calls it.  Below 2.5 the reference calls
+// glibc's lgammaf (special.hpp:121-123).  With alpha fixed, only a handful of
+// arguments below 2.5 exist -- (alpha + s) + x with s + x <= 2 -- so the host
+// evaluates glibc's lgammaf on exactly those floats once and the device looks
+// the result up: bit-identical to the reference for every alpha.
+DIST_HD float gp_lgamma(float y, const float * p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (y < 2.5f) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+            if (y == p[4 + i]) return p[10 + i];
+    }
+#else
+    (void)p;
+#endif
+    return fast_lgamma(y);
+}
+
 // Model::Scorer::init over Shared::plus_group for the non-categorical kinds
 // (bb.hpp:189-197; gp.hpp:56-61,198-207; nich.hpp:58-69,239-250)
 DIST_HD Entry scorer_init(int kind, const float * p, const Stats & s) {
@@ -136,7 +157,7 @@ DIST_HD Entry scorer_init(int kind, const float * p, const Stats & s) {
         const float post_alpha = p[0] + (float)(uint32_t)s.i1;
         const float post_inv_beta = p[1] + (float)(uint32_t)s.i0;
         const float score_coeff = -fast_log(1.f + post_inv_beta);
-        e.c0 = -fast_lgamma(post_alpha)
+        e.c0 = -gp_lgamma(post_alpha, p)
              + post_alpha * (fast_log(post_inv_beta) + score_coeff);
         e.c1 = post_alpha;
         e.c2 = score_coeff;
@@ -172,8 +193,10 @@ DIST_HD Entry scorer_init(int kind, const float * p, const Stats & s) {
 //   GP      acc + (((score + lgamma(a+v)) - logfact(v)) + coeff*v)   gp.cc:57-66
 //   NICH    acc + (score + log_coeff*log(1 + prec*(v-mean)^2))     nich.cc:60-66
 // `lf` = fast_log_factorial(value) for GP (hoisted like gp.cc:56).
+// `p` = the feature's parameter block (SlaveView::p; GP reads its lgamma
+// table from it, see gp_lgamma).
 DIST_HD float accumulate(int kind, float acc, const Entry & e, uint32_t value,
-                         float lf) {
+                         float lf, const float * p) {
     switch (kind) {
     case DIST_DD:
     case DIST_DPD:
@@ -182,7 +205,7 @@ DIST_HD float accumulate(int kind, float acc, const Entry & e, uint32_t value,
         return acc + (value ? e.c0 : e.c1);
     case DIST_GP: {
         const float fv = (float)value;
-        return acc + (e.c0 + fast_lgamma(e.c1 + fv) - lf + e.c2 * fv);
+        return acc + (e.c0 + gp_lgamma(e.c1 + fv, p) - lf + e.c2 * fv);
     }
     default: {  // DIST_NICH
         const float x = u2f(value);
@@ -195,7 +218,8 @@ DIST_HD float accumulate(int kind, float acc, const Entry & e, uint32_t value,
 
 // score_value_group (dd.hpp:423-431, bb.hpp:293-301, gp.hpp:300-310,
 // nich.hpp:351-360, dpd.hpp:499-515)
-DIST_HD float score_group(int kind, const Entry & e, uint32_t value, float lf) {
+DIST_HD float score_group(int kind, const Entry & e, uint32_t value, float lf,
+                          const float * p) {
     switch (kind) {
     case DIST_DD:
     case DIST_DPD:
@@ -204,7 +228,7 @@ DIST_HD float score_group(int kind, const Entry & e, uint32_t value, float lf) {
         return value ? e.c0 : e.c1;
     case DIST_GP: {
         const float fv = (float)value;
-        return e.c0 + fast_lgamma(e.c1 + fv) - lf + e.c2 * fv;
+        return e.c0 + gp_lgamma(e.c1 + fv, p) - lf + e.c2 * fv;
     }
     default: {
         const float x = u2f(value);
@@ -285,6 +309,122 @@ DIST_HD void refresh_scalar_entry(const SlaveView & s, int k) {
     s.c1[k] = e.c1;
     s.c2[k] = e.c2;
     s.c3[k] = e.c3;
+}
+
+// Shared::plus_group for NICH (nich.hpp:58-69), returning post kappa, mu, nu,
+// sigmasq
+DIST_HD void nich_plus_group(const float * p, const Stats & s, float & pk,
+                             float & pmu, float & pnu, float & psig) {
+    const float mu = p[0], kappa = p[1], sigmasq = p[2], nu = p[3];
+    const float count = (float)s.i0, mean = s.f0, ctv = s.f1;
+    const float mu_1 = mu - mean;
+    pk = kappa + count;
+    pmu = (kappa * mu + mean * count) / pk;
+    pnu = nu + count;
+    psig = 1.f / pnu * (nu * sigmasq + ctv + (count * kappa * mu_1 * mu_1) / pk);
+}
+
+// Group::score_data for the scalar kinds (bb.hpp:141-151, gp.hpp:155-164,
+// nich.hpp:190-202): log marginal likelihood of the group's data
+DIST_HD float scalar_group_score_data(int kind, const float * p,
+                                      const Stats & s) {
+    switch (kind) {
+    case DIST_BB: {
+        const float alpha = p[0] + (float)s.i0;
+        const float beta = p[1] + (float)s.i1;
+        float score = 0.f;
+        score += fast_lgamma(alpha) - fast_lgamma(p[0]);
+        score += fast_lgamma(beta) - fast_lgamma(p[1]);
+        score += fast_lgamma(p[0] + p[1]) - fast_lgamma(alpha + beta);
+        return score;
+    }
+    case DIST_GP: {
+        const float post_alpha = p[0] + (float)(uint32_t)s.i1;
+        const float post_inv_beta = p[1] + (float)(uint32_t)s.i0;
+        float score = fast_lgamma(post_alpha) - fast_lgamma(p[0]);
+        score += p[0] * fast_log(p[1]) - post_alpha * fast_log(post_inv_beta);
+        score += -s.f0;
+        return score;
+    }
+    default: {  // DIST_NICH
+        float pk, pmu, pnu, psig;
+        nich_plus_group(p, s, pk, pmu, pnu, psig);
+        const float log_pi = 1.1447298858493991f;
+        float score = fast_lgamma(0.5f * pnu) - fast_lgamma(0.5f * p[3]);
+        score += 0.5f * fast_log(p[1] / pk);
+        score += 0.5f * p[3] * (fast_log(p[3] * p[2]))
+               - 0.5f * pnu * fast_log(pnu * psig);
+        score += -0.5f * (float)s.i0 * log_pi;
+        return score;
+    }
+    }
+}
+
+// One group's contribution to MixtureDataScorer::score_data for the scalar
+// kinds (bb.hpp:207-229, gp.hpp:220-241, nich.hpp:262-288), as the separate
+// float terms the reference adds to its accumulator; returns how many.
+DIST_HD int scalar_mixture_score_terms(int kind, const float * p,
+                                       const Stats & s, float (&t)[4]) {
+    switch (kind) {
+    case DIST_BB: {   // every group, empty ones included
+        const float shared_part =
+            + fast_lgamma(p[0] + p[1]) - fast_lgamma(p[0]) - fast_lgamma(p[1]);
+        const float alpha = p[0] + (float)s.i0;
+        const float beta = p[1] + (float)s.i1;
+        const float group_part =
+            + fast_lgamma(alpha) + fast_lgamma(beta) - fast_lgamma(alpha + beta);
+        t[0] = shared_part + group_part;
+        return 1;
+    }
+    case DIST_GP: {
+        if (s.i0 == 0) return 0;
+        const float alpha_part = fast_lgamma(p[0]);
+        const float beta_part = p[0] * fast_log(p[1]);
+        const float post_alpha = p[0] + (float)(uint32_t)s.i1;
+        const float post_inv_beta = p[1] + (float)(uint32_t)s.i0;
+        t[0] = fast_lgamma(post_alpha) - alpha_part;
+        t[1] = beta_part - post_alpha * fast_log(post_inv_beta);
+        t[2] = -s.f0;
+        return 3;
+    }
+    default: {  // DIST_NICH
+        if (s.i0 == 0) return 0;
+        const float nu_part = fast_lgamma(0.5f * p[3]);
+        const float kappa_part = 0.5f * fast_log(p[1]);
+        const float sigmasq_part = 0.5f * p[3] * fast_log(p[3] * p[2]);
+        const float log_pi = 1.1447298858493991f;
+        float pk, pmu, pnu, psig;
+        nich_plus_group(p, s, pk, pmu, pnu, psig);
+        t[0] = fast_lgamma(0.5f * pnu) - nu_part;
+        t[1] = kappa_part - 0.5f * fast_log(pk);
+        t[2] = sigmasq_part - 0.5f * pnu * fast_log(pnu * psig);
+        t[3] = -0.5f * log_pi * (float)s.i0;
+        return 4;
+    }
+    }
+}
+
+// PitmanYor::score_counts (src/clustering.cc:152-183): the term of one
+// non-empty group given how many non-empty groups and rows precede it
+DIST_HD double py_score_counts_term(float alpha, float d, int count,
+                                    unsigned long long nonempty_before,
+                                    unsigned long long rows_before) {
+    const float ne = (float)nonempty_before;
+    const float ss = (float)rows_before;
+    if (count == 1) {
+        return fast_log((alpha + d * ne) / (alpha + ss));
+    }
+    if (count == 2) {
+        return fast_log(((alpha + d * ne) * (1 - d))
+                        / ((alpha + ss) * (alpha + ss + 1)));
+    }
+    double score = 0.0;
+    score += fast_log(alpha + d * ne);
+    score += fast_lgamma((1 - d) + (float)(unsigned long long)(count - 1))
+           - fast_lgamma(1 - d);
+    score -= fast_lgamma((alpha + ss) + (float)(unsigned long long)count)
+           - fast_lgamma(alpha + ss);
+    return score;
 }
 
 // Clustering<int>::PitmanYor cached scores (clustering.hpp:215-230)

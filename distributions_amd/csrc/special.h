@@ -113,7 +113,13 @@ DIST_HD float fast_exp_nonpos(float x, const uint32_t * exp_table, float a,
 // calls glibc's lgammaf there (special.hpp:121-123); this evaluates lgamma in
 // binary64 and rounds once, which is exact for y = 1, 2 and within 1 ulp of
 // glibc elsewhere (DESIGN.md "Known numeric gaps").
-DIST_HD float libm_lgammaf(float y) { return (float)::lgamma((double)y); }
+DIST_HD float libm_lgammaf(float y) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (float)::lgamma((double)y);
+#else
+    return ::lgammaf(y);   // host side: the very libm call of the reference
+#endif
+}
 
 // special.hpp:114-171
 DIST_HD float fast_lgamma(float y) {

@@ -46,6 +46,9 @@ class PitmanYorMixture(object):
     def counts(self):
         return self._core.counts()
 
+    def score_data(self, model):
+        return self._core.score_data(model.alpha, model.d)
+
 
 class PitmanYor(object):
     EXAMPLES = [
@@ -107,5 +110,4 @@ class PitmanYor(object):
             "path (SURVEY 8f rank 3)")
 
     def score_counts(self, counts):
-        raise NotImplementedError(
-            "score_counts is hyper-parameter scoring (SURVEY 8f rank 1)")
+        return _core.py_score_counts(self.alpha, self.d, list(counts))

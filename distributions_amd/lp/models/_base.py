@@ -103,8 +103,7 @@ class GroupBase(object):
                                                self._word(shared, value))
 
     def score_data(self, shared):
-        raise NotImplementedError(
-            "score_data is outside the row-update path (SURVEY 8f rank 1)")
+        return shared.params.group_score_data(self.words)
 
     def sample_value(self, shared):
         raise NotImplementedError(
@@ -204,5 +203,4 @@ class MixtureBase(object):
                                          scores_accum)
 
     def score_data(self, shared):
-        raise NotImplementedError(
-            "score_data is outside the row-update path (SURVEY 8f rank 1)")
+        return self._handle(shared).score_data()

@@ -103,6 +103,10 @@ int dist_py_score_remove_value(float alpha, float d, int group_size,
                                int nonempty_group_count, int sample_size,
                                int empty_group_count, float * out);
 
+/* score_counts(counts): log probability of a partition (clustering.cc:152-183) */
+int dist_py_score_counts(float alpha, float d, const int * counts,
+                         size_t group_count, float * out);
+
 /* ---- PitmanYor::Mixture = CachedMixture (clustering.hpp:126-234) --------- */
 typedef struct dist_py_mixture dist_py_mixture_t;
 dist_py_mixture_t * dist_py_mixture_create(void);
@@ -119,6 +123,9 @@ int dist_py_mixture_remove_value(dist_py_mixture_t * m, float alpha, float d,
 /* score_value(model, scores): OVERWRITES scores[size]  clustering.hpp:195-208 */
 int dist_py_mixture_score_value(const dist_py_mixture_t * m, float alpha,
                                 float d, float * scores, size_t size);
+/* score_data(model) = model.score_counts(counts())      clustering.hpp:210-212 */
+int dist_py_mixture_score_data(const dist_py_mixture_t * m, float alpha,
+                               float d, float * out);
 size_t dist_py_mixture_size(const dist_py_mixture_t * m);           /* counts().size() */
 size_t dist_py_mixture_sample_size(const dist_py_mixture_t * m);    /* sample_size()   */
 int dist_py_mixture_counts(const dist_py_mixture_t * m, int * out); /* counts()        */
@@ -148,6 +155,10 @@ int dist_mixture_score_value_group(const dist_mixture_t * m, size_t groupid,
 int dist_mixture_score_value(const dist_mixture_t * m, uint32_t value,
                              float * scores_accum, size_t size);
 
+/* score_data: log marginal likelihood of all groups' data    mixture.hpp:427-431
+ * (float terms of the reference, summed in binary64; 1e-5 relative) */
+int dist_mixture_score_data(const dist_mixture_t * m, float * out);
+
 /* ---- Model::Group scalar API (host side, O(1); dd.hpp:113-199 etc.) ------ */
 int dist_group_init(const dist_shared_t * shared, uint32_t * group);
 int dist_group_add_value(const dist_shared_t * shared, uint32_t * group,
@@ -157,6 +168,8 @@ int dist_group_remove_value(const dist_shared_t * shared, uint32_t * group,
 int dist_group_score_value(const dist_shared_t * shared,
                            const uint32_t * group, uint32_t value,
                            float * out);
+int dist_group_score_data(const dist_shared_t * shared, const uint32_t * group,
+                          float * out);
 
 /* ---- MixtureIdTracker (mixture.hpp:460-521) ------------------------------ */
 typedef struct dist_id_tracker dist_id_tracker_t;

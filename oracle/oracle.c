@@ -860,6 +860,181 @@ float orc_group_score_value(const orc_shared * sh, const uint32_t * group,
 }
 
 /* ------------------------------------------------------------------------ */
+/* score_data                                            */
+
+/* Group::score_data (dd.hpp:160-177, bb.hpp:141-151, gp.hpp:155-164,
+ * nich.hpp:190-202, dpd.hpp:234-250); `group` as orc_mix_slave_get_group */
+float orc_group_score_data(const orc_shared * sh, const uint32_t * group) {
+    unsigned saved = orc_ftz_enable();
+    float score = 0;
+    if (sh->kind == ORC_DD || sh->kind == ORC_DPD) {
+        float alpha_sum = 0;
+        if (sh->kind == ORC_DPD) alpha_sum = sh->p[0];
+        for (int v = 0; v < sh->dim; ++v) {
+            float alpha = sh->kind == ORC_DD ? sh->alphas[v]
+                                             : sh->p[0] * sh->betas[v];
+            if (sh->kind == ORC_DD) alpha_sum += alpha;
+            int32_t c = (int32_t)group[1 + v];
+            if (sh->kind == ORC_DPD && c == 0) continue; /* sparse counter */
+            score += orc_fast_lgamma(alpha + (float)c) - orc_fast_lgamma(alpha);
+        }
+        score += orc_fast_lgamma(alpha_sum)
+               - orc_fast_lgamma(alpha_sum + (float)(int32_t)group[0]);
+    } else if (sh->kind == ORC_BB) {
+        float alpha = sh->p[0] + (float)(int32_t)group[0];
+        float beta = sh->p[1] + (float)(int32_t)group[1];
+        score += orc_fast_lgamma(alpha) - orc_fast_lgamma(sh->p[0]);
+        score += orc_fast_lgamma(beta) - orc_fast_lgamma(sh->p[1]);
+        score += orc_fast_lgamma(sh->p[0] + sh->p[1])
+               - orc_fast_lgamma(alpha + beta);
+    } else if (sh->kind == ORC_GP) {
+        float post_alpha = sh->p[0] + (float)group[1];
+        float post_inv_beta = sh->p[1] + (float)group[0];
+        score = orc_fast_lgamma(post_alpha) - orc_fast_lgamma(sh->p[0]);
+        score += sh->p[0] * orc_fast_log(sh->p[1])
+               - post_alpha * orc_fast_log(post_inv_beta);
+        score += -u2f(group[2]);
+    } else {
+        float mu = sh->p[0], kappa = sh->p[1], sigmasq = sh->p[2],
+              nu = sh->p[3];
+        float count = (float)(int32_t)group[0], mean = u2f(group[1]),
+              ctv = u2f(group[2]);
+        float mu_1 = mu - mean;
+        float pk = kappa + count;
+        float pnu = nu + count;
+        float psig = 1.f / pnu * (
+            nu * sigmasq + ctv + (count * kappa * mu_1 * mu_1) / pk);
+        float log_pi = 1.1447298858493991f;
+        score = orc_fast_lgamma(0.5f * pnu) - orc_fast_lgamma(0.5f * nu);
+        score += 0.5f * orc_fast_log(kappa / pk);
+        score += 0.5f * nu * (orc_fast_log(nu * sigmasq))
+               - 0.5f * pnu * orc_fast_log(pnu * psig);
+        score += -0.5f * count * log_pi;
+    }
+    orc_ftz_restore(saved);
+    return score;
+}
+
+/* MixtureDataScorer::score_data (dd.hpp:250-256,287-318; bb.hpp:207-229;
+ * gp.hpp:220-241; nich.hpp:262-288; dpd.hpp:344-374), float accumulation in
+ * the reference's loop order (DD's final vector_sum taken in index order) */
+float orc_mix_slave_score_data(const orc_mix * m, int fi) {
+    unsigned saved = orc_ftz_enable();
+    const feat * f = &m->f[fi];
+    const orc_shared * sh = &f->sh;
+    float result = 0;
+    if (sh->kind == ORC_DD) {
+        int dim = sh->dim;
+        float * scores = calloc(dim + 1, sizeof(float));
+        float * shared_part = calloc(dim + 1, sizeof(float));
+        float alpha_sum = 0;
+        for (int i = 0; i < dim; ++i) {
+            alpha_sum += sh->alphas[i];
+            shared_part[i] = orc_fast_lgamma(sh->alphas[i]);
+        }
+        shared_part[dim] = orc_fast_lgamma(alpha_sum);
+        for (int k = 0; k < f->K; ++k) {
+            if (!f->i0[k]) continue;
+            for (int i = 0; i < dim; ++i)
+                scores[i] += orc_fast_lgamma(
+                    sh->alphas[i] + (float)f->cnt[(size_t)k * dim + i])
+                           - shared_part[i];
+            scores[dim] += shared_part[dim]
+                         - orc_fast_lgamma(alpha_sum + (float)f->i0[k]);
+        }
+        for (int i = 0; i <= dim; ++i) result += scores[i];
+        free(scores); free(shared_part);
+    } else if (sh->kind == ORC_DPD) {
+        float alpha = sh->p[0];
+        float shared_total = orc_fast_lgamma(alpha);
+        for (int k = 0; k < f->K; ++k) {
+            if (!f->i0[k]) continue;
+            for (int v = 0; v < sh->dim; ++v) {
+                int32_t c = f->cnt[(size_t)k * sh->dim + v];
+                if (!c) continue;
+                float prior_i = f->betas[v] * alpha;
+                result += orc_fast_lgamma(prior_i + (float)c)
+                        - orc_fast_lgamma(alpha * f->betas[v]);
+            }
+            result += shared_total - orc_fast_lgamma(alpha + (float)f->i0[k]);
+        }
+    } else if (sh->kind == ORC_BB) {
+        float shared_part = + orc_fast_lgamma(sh->p[0] + sh->p[1])
+                            - orc_fast_lgamma(sh->p[0])
+                            - orc_fast_lgamma(sh->p[1]);
+        for (int k = 0; k < f->K; ++k) {
+            float alpha = sh->p[0] + (float)f->i0[k];
+            float beta = sh->p[1] + (float)f->i1[k];
+            float group_part = + orc_fast_lgamma(alpha) + orc_fast_lgamma(beta)
+                               - orc_fast_lgamma(alpha + beta);
+            result += shared_part + group_part;
+        }
+    } else if (sh->kind == ORC_GP) {
+        float alpha_part = orc_fast_lgamma(sh->p[0]);
+        float beta_part = sh->p[0] * orc_fast_log(sh->p[1]);
+        for (int k = 0; k < f->K; ++k) {
+            if (!f->i0[k]) continue;
+            float post_alpha = sh->p[0] + (float)(uint32_t)f->i1[k];
+            float post_inv_beta = sh->p[1] + (float)(uint32_t)f->i0[k];
+            result += orc_fast_lgamma(post_alpha) - alpha_part;
+            result += beta_part - post_alpha * orc_fast_log(post_inv_beta);
+            result += -f->f0[k];
+        }
+    } else {
+        float kappa = sh->p[1], sigmasq = sh->p[2], nu = sh->p[3],
+              mu = sh->p[0];
+        float nu_part = orc_fast_lgamma(0.5f * nu);
+        float kappa_part = 0.5f * orc_fast_log(kappa);
+        float sigmasq_part = 0.5f * nu * orc_fast_log(nu * sigmasq);
+        float log_pi = 1.1447298858493991f;
+        for (int k = 0; k < f->K; ++k) {
+            if (!f->i0[k]) continue;
+            float count = (float)f->i0[k], mean = f->f0[k], ctv = f->f1[k];
+            float mu_1 = mu - mean;
+            float pk = kappa + count;
+            float pnu = nu + count;
+            float psig = 1.f / pnu * (
+                nu * sigmasq + ctv + (count * kappa * mu_1 * mu_1) / pk);
+            result += orc_fast_lgamma(0.5f * pnu) - nu_part;
+            result += kappa_part - 0.5f * orc_fast_log(pk);
+            result += sigmasq_part - 0.5f * pnu * orc_fast_log(pnu * psig);
+            result += -0.5f * log_pi * (float)f->i0[k];
+        }
+    }
+    orc_ftz_restore(saved);
+    return result;
+}
+
+/* PitmanYor::score_counts (src/clustering.cc:144-183) */
+float orc_py_score_counts(float alpha, float d, const int * counts, size_t n) {
+    unsigned saved = orc_ftz_enable();
+    double score = 0.0;
+    size_t sample_size = 0, nonempty_group_count = 0;
+    for (size_t i = 0; i < n; ++i) {
+        size_t count = (size_t)counts[i];
+        if (!count) continue;
+        if (count == 1) {
+            score += orc_fast_log((alpha + d * nonempty_group_count)
+                                  / (alpha + sample_size));
+        } else if (count == 2) {
+            score += orc_fast_log(
+                ((alpha + d * nonempty_group_count) * (1 - d))
+                / ((alpha + sample_size) * (alpha + sample_size + 1)));
+        } else {
+            score += orc_fast_log(alpha + d * nonempty_group_count);
+            score += orc_fast_lgamma((1 - d) + (count - 1))
+                   - orc_fast_lgamma(1 - d);
+            score -= orc_fast_lgamma((alpha + sample_size) + count)
+                   - orc_fast_lgamma(alpha + sample_size);
+        }
+        nonempty_group_count += 1;
+        sample_size += count;
+    }
+    orc_ftz_restore(saved);
+    return (float)score;
+}
+
+/* ------------------------------------------------------------------------ */
 /* whole-path drivers                                                       */
 
 void orc_mix_init_from_assignments(orc_mix * m, size_t n_rows,

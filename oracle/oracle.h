@@ -139,6 +139,12 @@ void orc_mix_slave_get_group(const orc_mix * m, int f, int groupid,
 float orc_group_score_value(const orc_shared * shared, const uint32_t * group,
                             uint32_t value);
 
+/* score_data: Group::score_data, MixtureDataScorer::
+ * score_data, PitmanYor::score_counts (clustering.cc:152-183) */
+float orc_group_score_data(const orc_shared * shared, const uint32_t * group);
+float orc_mix_slave_score_data(const orc_mix * m, int f);
+float orc_py_score_counts(float alpha, float d, const int * counts, size_t n);
+
 /* id tracker (mixture.hpp:460-521) */
 void orc_mix_tracker_init(orc_mix * m, int group_count);
 void orc_mix_tracker_add_group(orc_mix * m);

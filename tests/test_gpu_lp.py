@@ -294,3 +294,62 @@ def test_prob_from_scores():
         assert 0 <= sample < size
         prob2 = lprandom.prob_from_scores(sample, scores)
         assert_close(prob1, prob2)
+
+
+@pytest.mark.parametrize("module,EXAMPLE", examples())
+def test_mixture_score_data(module, EXAMPLE):
+    """check_score_data of distributions/tests/test_models.py:559-562 on the
+    GPU, plus the oracle within the stated 1e-5 (terms are the reference's,
+    the device sums them in binary64)"""
+    L = ol.oracle()
+    shared = module.Shared.from_dict(EXAMPLE['shared'])
+    values = EXAMPLE['values']
+    groups = [module.Group.from_values(shared, [value]) for value in values]
+    mixture = module.Mixture()
+    for group in groups:
+        mixture.append(group)
+    mixture.init(shared)
+    osh = oracle_twin(module, shared)
+    orc = ol.OracleMixture(1.0, 0.0, [osh])
+    word = lambda v: module.Group._word(shared, v)   # noqa: E731
+    for g, value in enumerate(values):
+        L.orc_mix_slave_append_empty(orc.h, 0)
+        L.orc_mix_slave_group_add_value(orc.h, 0, g, word(value))
+    L.orc_mix_slave_init(orc.h, 0)
+
+    def check():
+        expected = sum(group.score_data(shared) for group in groups)
+        actual = mixture.score_data(shared)
+        assert_close(actual, expected, msg='score_data')
+        want = L.orc_mix_slave_score_data(orc.h, 0)
+        assert abs(actual - want) <= 1e-5 * (1 + abs(want)), (actual, want)
+        for g, group in enumerate(groups):
+            wg = L.orc_group_score_data(ctypes.byref(osh), orc.get_group(0, g))
+            assert np.float32(group.score_data(shared)) == np.float32(wg)
+
+    check()
+    for i, value in enumerate(values):
+        g = (3 * i + 1) % len(groups)
+        groups[g].add_value(shared, value)
+        mixture.add_value(shared, g, value)
+        L.orc_mix_slave_add_value(orc.h, 0, g, word(value))
+        check()
+
+
+def test_py_score_counts_and_mixture_score_data():
+    from distributions_amd.lp.clustering import PitmanYor
+    L = ol.oracle()
+    model = PitmanYor(alpha=1.0, d=0.2)
+    got = model.score_counts([5, 3, 1, 0])
+    assert abs(got - (-9.18923473)) < 5e-7         # SURVEY 8c(5)
+    rng = np.random.default_rng(12)
+    for ex in PitmanYor.EXAMPLES:
+        model = PitmanYor(**ex)
+        counts = [int(c) for c in rng.integers(0, 50, 300)] + [0]
+        want = L.orc_py_score_counts(model.alpha, model.d,
+                                     np.array(counts, np.int32), len(counts))
+        got = model.score_counts(counts)
+        assert abs(got - want) <= 1e-6 * (1 + abs(want))
+        mixture = PitmanYor.Mixture()
+        mixture.init(model, counts)
+        assert abs(mixture.score_data(model) - want) <= 1e-6 * (1 + abs(want))

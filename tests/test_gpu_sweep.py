@@ -165,7 +165,7 @@ def test_randomised_configurations():
                 feats_g.append(engine.bb_shared(a, b))
                 vals.append((rng.random(n) < 0.4).astype(np.uint32))
             elif kind == "gp":
-                a = float(rng.integers(1, 5))   # integer alpha: see DESIGN 6
+                a = float(rng.choice([0.3, 0.5, 1.0, 1.7, 2.4, 4.0]))
                 ib = float(rng.uniform(0.3, 3))
                 feats_o.append(ol.make_shared(ol.GP, alpha=a, inv_beta=ib))
                 feats_g.append(engine.gp_shared(a, ib))
@@ -239,3 +239,35 @@ def test_delta_all_reduce_path_single_rank_nccl(config):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("alpha", [0.3, 0.5, 1.25, 2.2])
+def test_gamma_poisson_small_arguments_use_libm_values(alpha):
+    """fast_lgamma(y < 2.5) is glibc's lgammaf in the reference
+    (special.hpp:121-123); with a non-integer alpha and near-empty groups the
+    device must reproduce those values (gp_lgamma's lookup), not an
+    approximation: scores and assignments stay bit-exact."""
+    from distributions_amd import engine
+    rng = np.random.default_rng(3)
+    n, k = 600, 150
+    vals = [rng.integers(0, 3, n).astype(np.uint32)]
+    assign = (np.arange(n) % k).astype(np.uint32)
+    osh = [ol.make_shared(ol.GP, alpha=alpha, inv_beta=0.7)]
+    orc = ol.OracleMixture(2.0, 0.3, osh)
+    orc.init_from_assignments(vals, assign, k, 2)
+    for mode in (0, 2):
+        gpu = engine.Gibbs(2.0, 0.3, [engine.gp_shared(alpha, 0.7)])
+        gpu.set_option("value_sorted", mode)
+        gpu.load_rows(vals, assign, k, 2)
+        for row in [0, 7, 599]:
+            g = int(ol.oracle().orc_mix_global_to_packed(orc.h,
+                                                        int(orc.assign[row])))
+            want = orc.row_scores(row, g)
+            got = gpu.row_scores(row)
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    st = ol.oracle().orc_rng_seed(11)
+    for sweep in range(3):
+        for b in range(0, n, 200):
+            orc.gibbs_batch(b, b + 200, st, sweep * n)
+        gpu.sweep(0, n, 200, 11, draw_base=sweep * n)
+        assert_same_state(orc, gpu, "gp alpha=%g sweep %d" % (alpha, sweep))

@@ -291,3 +291,62 @@ def test_fast_exp_flushes_like_the_reference_build():
     s = np.array([0.0, -100.0, -88.0, -50.0], np.float32)
     total = L.orc_scores_to_likelihoods(4, s)
     assert s[0] == 1.0 and s[1] == 0.0 and s[2] == 0.0 and total >= 1.0
+
+
+# ---------------------------------------------------------------------------
+# score_data / score_counts
+
+@pytest.mark.parametrize("name,kind,kw,values", EXAMPLES)
+def test_score_data_chain_rule_and_float64(name, kind, kw, values):
+    """distributions/tests/test_models.py:241-251: the sequential predictive
+    scores of a group's values sum to its score_data; and both agree with the
+    float64 marginal likelihood."""
+    L = ol.oracle()
+    sh = ol.make_shared(kind, **kw)
+    m = ol.OracleMixture(1.0, 0.0, [sh])
+    L.orc_mix_slave_append_empty(m.h, 0)
+    L.orc_mix_slave_init(m.h, 0)
+    chain = 0.0
+    f64 = 0.0
+    for i, v in enumerate(values):
+        chain += L.orc_group_score_value(ctypes.byref(sh), m.get_group(0, 0),
+                                         words(kind, v))
+        f64 += float64_score(kind, kw, values[:i], v)
+        L.orc_mix_slave_add_value(m.h, 0, 0, words(kind, v))
+    total = L.orc_group_score_data(ctypes.byref(sh), m.get_group(0, 0))
+    assert_close(total, chain, tol=2e-3, msg=name + " chain rule")
+    assert_close(total, f64, tol=2e-3, msg=name + " float64")
+    # Mixture.score_data == sum of Group.score_data (test_models.py:559-562)
+    for v in values[:3]:
+        L.orc_mix_slave_add_group(m.h, 0)
+        L.orc_mix_slave_add_value(m.h, 0, L.orc_mix_slave_size(m.h, 0) - 1,
+                                  words(kind, v))
+    expected = sum(L.orc_group_score_data(ctypes.byref(sh), m.get_group(0, g))
+                   for g in range(L.orc_mix_slave_size(m.h, 0)))
+    assert_close(L.orc_mix_slave_score_data(m.h, 0), expected,
+                 msg=name + " mixture score_data")
+
+
+def test_score_counts_recorded_probe_and_consistency():
+    """SURVEY 8c(5), recorded from the compiled reference:
+    PitmanYor(alpha=1, d=.2).score_counts({5,3,1,0}) = -9.18923473; and
+    test_clustering.py:201-239: score_add_value == difference of
+    score_counts."""
+    L = ol.oracle()
+    got = L.orc_py_score_counts(1.0, 0.2, np.array([5, 3, 1, 0], np.int32), 4)
+    assert abs(got - (-9.18923473)) < 5e-7
+    rng = np.random.default_rng(8)
+    for alpha, d in PY_EXAMPLES:
+        counts = [int(c) for c in rng.integers(1, 20, 6)]
+        base = L.orc_py_score_counts(alpha, d, np.array(counts, np.int32),
+                                     len(counts))
+        n = sum(counts)
+        for g in range(len(counts) + 1):
+            bumped = list(counts) + [0]
+            bumped[g] += 1
+            after = L.orc_py_score_counts(alpha, d,
+                                          np.array(bumped, np.int32),
+                                          len(bumped))
+            size = counts[g] if g < len(counts) else 0
+            add = L.orc_py_score_add_value(alpha, d, size, len(counts), n, 1)
+            assert_close(after - base, add, tol=5e-3)
