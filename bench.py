@@ -57,6 +57,9 @@ def parse():
                          "DESIGN.md's table (not the bench line of record)")
     ap.add_argument("--value-sorted", type=int, default=1,
                     help="0 generic kernel only, 1 auto, 2 force")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="diagnostic: run the N>1 code path (statistic "
+                         "deltas + RCCL all-reduce) with a single rank")
     return ap.parse_args()
 
 
@@ -109,7 +112,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    if world > 1 or args.force_collective:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
         dist.init_process_group("nccl", rank=rank, world_size=world)
     torch.cuda.set_device(local_rank)
     _core.set_device(local_rank)
@@ -162,7 +167,8 @@ def main():
     g = engine.Gibbs(args.alpha, args.d, shareds)
     g.set_option("value_sorted", args.value_sorted)
     g.load_rows_torch(columns, assign, k, 1, row_offset=row_offset)
-    sharded = engine.ShardedGibbs(g.core, n, row_offset, device=dev)
+    sharded = engine.ShardedGibbs(g.core, n, row_offset, device=dev,
+                                  force_collective=args.force_collective)
     sharded.sync_initial_stats()
     seed_state = _core.rng_seed(args.seed)
 
@@ -245,8 +251,16 @@ def main():
         }
         if world == 1 and args.cpu_rows > 0 and args.config == "dd":
             out["cpu_baseline"] = cpu_baseline(args)
+        # RCCL prints its version banner through C stdio; push that out first
+        # so that the JSON line is the last thing on stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        sys.stdout.flush()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or args.force_collective:
         dist.destroy_process_group()
 
 

@@ -1105,15 +1105,24 @@ struct Gibbs {
     void batch_apply_delta(const int32_t * delta_dev) {
         DIST_REQUIRE(batch_open, "no open batch");
         StatImage a = live_image();
-        StatImage b = word_image(const_cast<int32_t *>(delta_dev));
         const size_t k = (size_t)K();
-        LAUNCH(k_add_words, k, a.counts, b.counts, k);
+        WordSegments seg;
+        memset(&seg, 0, sizeof(seg));
+        size_t off = 0;
+        auto push = [&](int32_t * dst, size_t n) {
+            if (!n) return;
+            off += n;
+            seg.dst[seg.n] = dst;
+            seg.end[seg.n] = off;
+            seg.n += 1;
+        };
+        push(a.counts, k);
         for (int f = 0; f < F(); ++f) {
-            LAUNCH(k_add_words, k, a.i0[f], b.i0[f], k);
-            LAUNCH(k_add_words, k, a.i1[f], b.i1[f], k);
-            const size_t nc = k * feats[f]->dim();
-            if (nc) LAUNCH(k_add_words, nc, a.cnt[f], b.cnt[f], nc);
+            push(a.i0[f], k);
+            push(a.i1[f], k);
+            push(a.cnt[f], k * feats[f]->dim());
         }
+        LAUNCH(k_add_words, off, seg, delta_dev, off);
         // GP log_prod never enters score_value (gp.hpp:198-217); it is
         // replayed from the local rows only
         replay_floats();
@@ -1690,7 +1699,9 @@ int dist_gibbs_batch_sample(dist_gibbs_t * g, size_t row_begin, size_t row_end,
     });
 }
 int dist_gibbs_batch_delta_dev(dist_gibbs_t * g, int32_t * delta_dev) {
-    return guarded([&] { g->impl->batch_delta(delta_dev); sync(); });
+    // no host sync: the collective is ordered after these kernels on the
+    // same (default) stream
+    return guarded([&] { g->impl->batch_delta(delta_dev); });
 }
 int dist_gibbs_batch_apply_delta_dev(dist_gibbs_t * g,
                                      const int32_t * delta_dev) {

@@ -1130,11 +1130,21 @@ __global__ void k_apply_moves(SweepParams P, StatImage img,
     }
 }
 
-// stats += delta (after the all-reduce), elementwise over the stat words
-__global__ void k_add_words(int32_t * __restrict__ dst,
-                            const int32_t * __restrict__ src, size_t n) {
+// stats += delta (after the all-reduce): the delta image is contiguous, the
+// live statistics are separate arrays; one launch walks all segments
+struct WordSegments {
+    int n;
+    int32_t * dst[1 + 3 * kMaxF];
+    unsigned long long end[1 + 3 * kMaxF];   // running end offset in the image
+};
+__global__ void k_add_words(WordSegments seg,
+                            const int32_t * __restrict__ src, size_t total) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) dst[i] += src[i];
+    if (i >= total) return;
+    int j = 0;
+    while (i >= seg.end[j]) ++j;
+    const size_t begin = j ? seg.end[j - 1] : 0;
+    seg.dst[j][i - begin] += src[i];
 }
 
 // Float statistics (NICH count/mean/ctv, GP log_prod) depend on update order
