@@ -78,20 +78,40 @@ def measured_traffic(kernel, rows_per_launch):
 
 
 def cpu_baseline(args):
-    """Oracle (port of the reference loop) on a bounded sample, 1 thread."""
+    """Oracle (port of the reference loop) on a bounded sample.  The figure of
+    record is ONE thread (the reference is single-threaded); `all_cores` adds
+    what the host reaches with one independent chain per core."""
+    import threading
     import numpy as np
     import oracle_lib as ol
+
+    def chain(n, seed):
+        rng = np.random.default_rng(seed)
+        values = rng.integers(0, args.dim, n).astype(np.uint32)
+        assign = (np.arange(n) % args.groups).astype(np.uint32)
+        orc = ol.OracleMixture(args.alpha, args.d, [
+            ol.make_shared(ol.DD, alphas=[0.5] * args.dim)])
+        orc.init_from_assignments([values], assign, args.groups, 1)
+        return orc
+
     n = min(args.cpu_rows, args.rows)
-    rng = np.random.default_rng(args.seed)
-    values = rng.integers(0, args.dim, n).astype(np.uint32)
-    assign = (np.arange(n) % args.groups).astype(np.uint32)
-    orc = ol.OracleMixture(args.alpha, args.d,
-                           [ol.make_shared(ol.DD, alphas=[0.5] * args.dim)])
-    orc.init_from_assignments([values], assign, args.groups, 1)
+    orc = chain(n, args.seed)
     st = ol.oracle().orc_rng_seed(args.seed)
     t0 = time.perf_counter()
     orc.gibbs_sequential(0, n, st)
     dt = time.perf_counter() - t0
+
+    cores = os.cpu_count() or 1
+    n_par = max(10000, n // 8)
+    chains = [chain(n_par, args.seed + 1 + i) for i in range(cores)]
+    threads = [threading.Thread(target=c.gibbs_sequential, args=(0, n_par, st))
+               for c in chains]          # ctypes releases the GIL
+    t1 = time.perf_counter()
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    dt_par = time.perf_counter() - t1
     return {
         "value": n / dt,
         "unit": "row-updates/s",
@@ -100,6 +120,9 @@ def cpu_baseline(args):
         "sample": "one sequential sweep over the first %d rows of the "
                   "workload (K=%d, dim=%d), oracle/oracle.c -O3, %.1f s"
                   % (n, args.groups, args.dim, dt),
+        "all_cores": {"value": cores * n_par / dt_par, "cores": cores,
+                      "sample": "%d independent chains of %d rows, %.1f s"
+                                % (cores, n_par, dt_par)},
     }
 
 

@@ -54,6 +54,7 @@ cdef extern from "distributions_hip.h" nogil:
     int dist_py_score_add_value(float, float, int, int, int, int, float *)
     int dist_py_score_remove_value(float, float, int, int, int, int, float *)
     int dist_py_score_counts(float, float, const int *, size_t, float *)
+    int dist_py_sample_assignments(float, float, int, uint32_t *, int *)
 
     ctypedef struct dist_py_mixture_t:
         pass
@@ -390,6 +391,15 @@ def py_score_remove_value(float alpha, float d, int group_size,
                                      nonempty_group_count, sample_size,
                                      empty_group_count, &out))
     return out
+
+
+def py_sample_assignments(float alpha, float d, int size, uint32_t state):
+    """-> (assignments, new rng state)"""
+    cdef cnp.ndarray[cnp.int32_t, ndim=1] out = np.zeros(max(size, 1),
+                                                         np.int32)
+    cdef uint32_t s = state
+    check(dist_py_sample_assignments(alpha, d, size, &s, <int *> out.data))
+    return out[:size], s
 
 
 def py_score_counts(float alpha, float d, counts):

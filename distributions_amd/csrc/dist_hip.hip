@@ -1391,6 +1391,46 @@ int dist_py_score_remove_value(float alpha, float d, int group_size,
     return rc;
 }
 
+// PitmanYor::sample_assignments (src/clustering.cc:67-142): an inherently
+// sequential draw (each row sees the tables of the rows before it) made of
+// float adds/compares and engine steps only -- host code, like the reference
+int dist_py_sample_assignments(float alpha, float d, int size,
+                               uint32_t * rng_state, int * assignments) {
+    return guarded([&] {
+        DIST_REQUIRE(size >= 0, "negative size");
+        DIST_REQUIRE((float)size + 1.f > (float)size, "underflow expected");
+        ensure_host_tables();
+        std::vector<float> likelihoods;
+        likelihoods.reserve(100);
+        int table_count = 0;
+        const float py_likelihood_new = 1 - d;
+        likelihoods.push_back(alpha);
+        if (size) {
+            assignments[0] = 0;
+            table_count = 1;
+            likelihoods.push_back(alpha + d * table_count);
+            likelihoods[0] = py_likelihood_new;
+        }
+        for (int i = 1; i < size; ++i) {
+            const float total = i + alpha;
+            // sample_from_likelihoods (random.hpp:316-333)
+            float t = total * lcg_unif01(dist_rng_next(rng_state));
+            int assign = (int)likelihoods.size() - 1;
+            for (size_t k = 0; k < likelihoods.size(); ++k) {
+                t -= likelihoods[k];
+                if (t <= 0) { assign = (int)k; break; }
+            }
+            assignments[i] = assign;
+            if (assign == table_count) {
+                table_count += 1;
+                likelihoods.push_back(alpha + d * table_count);
+                likelihoods[assign] = py_likelihood_new;
+            } else {
+                likelihoods[assign] += 1.0f;
+            }
+        }
+    });
+}
 int dist_py_score_counts(float alpha, float d, const int * counts, size_t n,
                          float * out) {
     return guarded([&] { *out = py_score_counts(alpha, d, counts, n); });

@@ -105,9 +105,11 @@ class PitmanYor(object):
                                            empty_group_count)
 
     def sample_assignments(self, size):
-        raise NotImplementedError(
-            "sample_assignments is initialisation, outside the row-update "
-            "path (SURVEY 8f rank 3)")
+        from .random import get_rng
+        rng = get_rng()
+        out, rng.state = _core.py_sample_assignments(self.alpha, self.d,
+                                                     int(size), rng.state)
+        return [int(a) for a in out]
 
     def score_counts(self, counts):
         return _core.py_score_counts(self.alpha, self.d, list(counts))

@@ -103,6 +103,10 @@ int dist_py_score_remove_value(float alpha, float d, int group_size,
                                int nonempty_group_count, int sample_size,
                                int empty_group_count, float * out);
 
+/* sample_assignments(size, rng): sequential CRP/Pitman-Yor draw of `size`
+ * group ids (clustering.cc:67-142); host-side like the reference */
+int dist_py_sample_assignments(float alpha, float d, int size,
+                               uint32_t * rng_state, int * assignments_out);
 /* score_counts(counts): log probability of a partition (clustering.cc:152-183) */
 int dist_py_score_counts(float alpha, float d, const int * counts,
                          size_t group_count, float * out);

@@ -859,6 +859,40 @@ float orc_group_score_value(const orc_shared * sh, const uint32_t * group,
     return noncat_term(sh->kind, s, value, lf);
 }
 
+/* PitmanYor::sample_assignments (src/clustering.cc:67-142): sequential CRP
+ * draw over a growing likelihood vector; one engine step per row after the
+ * first */
+void orc_py_sample_assignments(float alpha, float d, int size,
+                               uint32_t * rng_state, int * assignments) {
+    unsigned saved = orc_ftz_enable();
+    float * likelihoods = malloc(sizeof(float) * (size_t)(size + 2));
+    int n_like = 0;
+    int table_count = 0;
+    const float py_likelihood_new = 1 - d;
+    likelihoods[n_like++] = alpha;
+    if (size) {
+        assignments[0] = 0;
+        table_count = 1;
+        likelihoods[n_like++] = alpha + d * table_count;
+        likelihoods[0] = py_likelihood_new;
+    }
+    for (int i = 1; i < size; ++i) {
+        float total = i + alpha;
+        int assign = (int)orc_sample_from_likelihoods(rng_state, n_like,
+                                                      likelihoods, total);
+        assignments[i] = assign;
+        if (assign == table_count) {
+            table_count += 1;
+            likelihoods[n_like++] = alpha + d * table_count;
+            likelihoods[assign] = py_likelihood_new;
+        } else {
+            likelihoods[assign] += 1.0f;
+        }
+    }
+    free(likelihoods);
+    orc_ftz_restore(saved);
+}
+
 /* ------------------------------------------------------------------------ */
 /* score_data                                            */
 

@@ -144,6 +144,9 @@ float orc_group_score_value(const orc_shared * shared, const uint32_t * group,
 float orc_group_score_data(const orc_shared * shared, const uint32_t * group);
 float orc_mix_slave_score_data(const orc_mix * m, int f);
 float orc_py_score_counts(float alpha, float d, const int * counts, size_t n);
+/* PitmanYor::sample_assignments (clustering.cc:67-142) */
+void orc_py_sample_assignments(float alpha, float d, int size,
+                               uint32_t * rng_state, int * assignments);
 
 /* id tracker (mixture.hpp:460-521) */
 void orc_mix_tracker_init(orc_mix * m, int group_count);

@@ -135,6 +135,7 @@ def oracle():
     sig("orc_group_score_data", f32, ctypes.POINTER(Shared), c_u32p)
     sig("orc_mix_slave_score_data", f32, vp, ci)
     sig("orc_py_score_counts", f32, f32, f32, c_i32p, sz)
+    sig("orc_py_sample_assignments", None, f32, f32, ci, u32ptr, c_i32p)
     sig("orc_mix_tracker_init", None, vp, ci)
     sig("orc_mix_tracker_add_group", None, vp)
     sig("orc_mix_tracker_remove_group", None, vp, u32)

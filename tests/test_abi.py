@@ -81,3 +81,31 @@ def test_product_never_touches_the_oracle():
     needed = subprocess.run(["ldd", LIB], capture_output=True,
                             text=True).stdout
     assert "liboracle" not in needed and "libref" not in needed
+
+
+def test_sample_assignments_is_host_logic_and_matches_the_probe():
+    """PitmanYor::sample_assignments (clustering.cc:67-142) needs no GPU; the
+    recorded output of the compiled reference and the oracle"""
+    import numpy as np
+    import oracle_lib as ol
+    lib = ctypes.CDLL(LIB)
+    out = (ctypes.c_int * 20)()
+    st = ctypes.c_uint32(1)
+    rc = lib.dist_py_sample_assignments(ctypes.c_float(1.0),
+                                        ctypes.c_float(0.2), 20,
+                                        ctypes.byref(st), out)
+    assert rc == 0
+    assert list(out) == [0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 2, 0, 0, 2, 0, 0, 0, 0,
+                         0, 0]
+    L = ol.oracle()
+    for alpha, d, n, seed in [(1.0, 0.0, 500, 3), (10.0, 0.1, 2000, 9),
+                              (0.1, 0.9, 300, 77)]:
+        a = (ctypes.c_int * n)()
+        st = ctypes.c_uint32(L.orc_rng_seed(seed))
+        lib.dist_py_sample_assignments(ctypes.c_float(alpha),
+                                       ctypes.c_float(d), n,
+                                       ctypes.byref(st), a)
+        b = np.zeros(n, np.int32)
+        st2 = ctypes.c_uint32(L.orc_rng_seed(seed))
+        L.orc_py_sample_assignments(alpha, d, n, ctypes.byref(st2), b)
+        assert list(a) == list(b) and st.value == st2.value

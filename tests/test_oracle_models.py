@@ -350,3 +350,14 @@ def test_score_counts_recorded_probe_and_consistency():
             size = counts[g] if g < len(counts) else 0
             add = L.orc_py_score_add_value(alpha, d, size, len(counts), n, 1)
             assert_close(after - base, add, tol=5e-3)
+
+
+def test_sample_assignments_recorded_probe():
+    """SURVEY 8c(5), recorded from the compiled reference: alpha=1, d=.2,
+    n=20, default-seeded engine -> 0 0 0 1 0 0 0 0 0 0 2 0 0 2 0 0 0 0 0 0"""
+    L = ol.oracle()
+    st = ctypes.c_uint32(L.orc_rng_seed(1))
+    out = np.zeros(20, np.int32)
+    L.orc_py_sample_assignments(1.0, 0.2, 20, ctypes.byref(st), out)
+    assert list(out) == [0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 2, 0, 0, 2, 0, 0, 0, 0,
+                         0, 0]
