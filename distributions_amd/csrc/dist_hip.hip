@@ -505,6 +505,7 @@ struct Gibbs {
     bool maps_dirty = true;
 
     DeviceBuf<uint32_t> old_packed, new_packed;
+    DeviceBuf<uint32_t> old_row, new_row;   // row-ordered copies (see replay)
     // ordered replay of float statistics: events sorted stably by group
     DeviceBuf<uint32_t> ev_keys, ev_vals, ev_keys_sorted, ev_vals_sorted;
     DeviceBuf<uint32_t> seg_begin, seg_end;
@@ -534,9 +535,24 @@ struct Gibbs {
         uint32_t n_tiles = 0;
         DeviceBuf<VsTile> chunks;          // apply work items, one value each
         uint32_t n_chunks = 0;
-        DeviceBuf<uint32_t> other_rows;   // rows the tiles do not cover
+        DeviceBuf<uint32_t> other_pos;    // positions the tiles do not cover
         uint32_t n_other = 0;
+        // the rows' current assignment (global ids) in sorted-position
+        // order; while `dirty`, assign[] (row order) is stale for this range
+        DeviceBuf<uint32_t> assign_pos;
+        bool dirty = false;
     };
+    // value-sorted batches keep assignments by position; anything that reads
+    // assign[] in row order calls this first
+    void flush_assign_pos() {
+        for (auto & c : vs_cache) {
+            if (!c->dirty) continue;
+            const size_t n = c->r1 - c->r0;
+            LAUNCH(k_pos_scatter, n, c->assign_pos.p, c->sorted_rows.p,
+                   assign + c->r0, n);
+            c->dirty = false;
+        }
+    }
     std::vector<std::unique_ptr<VsCache>> vs_cache;
     DeviceBuf<float> vsLA, vsLB, vsM, vsmB;
     DeviceBuf<int> vsArg;
@@ -886,18 +902,23 @@ struct Gibbs {
                                                            h[x] - off)});
         c->n_chunks = (uint32_t)chunks.size();
         c->chunks.upload(chunks.data(), chunks.size());
-        // rows whose value is outside the table (DPD OTHER): generic kernel
+        // rows whose value is outside the table: generic kernel, by position
         c->n_other = h[nv];
         if (c->n_other) {
             std::vector<uint32_t> idx(c->n_other);
-            sync();
-            HIP_CHECK(hipMemcpy(idx.data(), c->sorted_rows.p + start[nv],
-                                4 * (size_t)c->n_other, hipMemcpyDeviceToHost));
-            for (auto & i : idx) i += (uint32_t)r0;
-            c->other_rows.upload(idx.data(), idx.size());
+            for (uint32_t i = 0; i < c->n_other; ++i) idx[i] = start[nv] + i;
+            c->other_pos.upload(idx.data(), idx.size());
         }
+        // current assignments in position order
+        flush_assign_pos();
+        c->assign_pos.reserve(std::max<size_t>(n, 1), 0);
+        LAUNCH(k_pos_gather, n, assign + r0, c->sorted_rows.p,
+               c->assign_pos.p, n);
         sync();
-        if (vs_cache.size() >= 64) vs_cache.erase(vs_cache.begin());
+        if (vs_cache.size() >= 64) {
+            flush_assign_pos();
+            vs_cache.erase(vs_cache.begin());
+        }
         vs_cache.push_back(std::move(c));
         return *vs_cache.back();
     }
@@ -949,9 +970,11 @@ struct Gibbs {
         // do not pay for a gather table
         prepare(P, false);
         if (c.n_other)
-            HIP_CHECK(hipMemcpyAsync(deferred.p, c.other_rows.p,
+            HIP_CHECK(hipMemcpyAsync(deferred.p, c.other_pos.p,
                                      4 * (size_t)c.n_other,
                                      hipMemcpyDeviceToDevice, stream()));
+        P.sorted_rows = c.sorted_rows.p;
+        P.assign_pos = c.assign_pos.p;
         VsLaunch L{this, &P, &c,
                    VsTables{vsLA.p, vsLB.p, vsM.p, vsmB.p, vsArg.p, Kpad}};
         switch (feats[0]->sh.kind) {
@@ -988,6 +1011,7 @@ struct Gibbs {
         upload_maps();
         SweepParams P = params(r0, r1, seed, draw_base);
         batch_value_sorted = use_value_sorted(r1 - r0);
+        if (!batch_value_sorted) flush_assign_pos();
         if (batch_value_sorted) {
             sample_value_sorted(P);
             vs_batches += 1;
@@ -1052,7 +1076,11 @@ struct Gibbs {
         }
     }
     void replay_floats() {
-        replay_sorted(old_packed.p, new_packed.p, batch_begin,
+        // value-sorted batches hold the moves by position; apply_ints left a
+        // row-ordered copy for the replay
+        const bool by_pos = batch_value_sorted;
+        replay_sorted(by_pos ? old_row.p : old_packed.p,
+                      by_pos ? new_row.p : new_packed.p, batch_begin,
                       batch_end - batch_begin);
     }
 
@@ -1070,10 +1098,21 @@ struct Gibbs {
             const bool bb = feats[0]->sh.kind == DIST_BB;
             const bool gp = feats[0]->sh.kind == DIST_GP;
             const dim3 grid(c.n_chunks), block(kBlock);
+            // float statistics replay in ROW order: un-sort the moves first
+            // (before the kernel below permutes sorted_rows)
+            if (any_float_stats()) {
+                old_row.reserve(std::max<size_t>(n, 1), 0);
+                new_row.reserve(std::max<size_t>(n, 1), 0);
+                LAUNCH(k_pos_scatter, n, old_packed.p, c.sorted_rows.p,
+                       old_row.p, n);
+                LAUNCH(k_pos_scatter, n, new_packed.p, c.sorted_rows.p,
+                       new_row.p, n);
+            }
+            c.dirty = true;
 #define VS_APPLY(KIND, SORT, LDS)                                            \
             hipLaunchKernelGGL((k_vs_apply<KIND, SORT>), grid, block, LDS,   \
                                stream(), P, img, c.chunks.p,                 \
-                               c.sorted_rows.p, d_p2g.p, assign)
+                               c.sorted_rows.p, d_p2g.p, c.assign_pos.p)
             if (bb && sort) VS_APPLY(DIST_BB, true, lds_sort);
             else if (bb) VS_APPLY(DIST_BB, false, lds_plain);
             else if (gp && sort) VS_APPLY(DIST_GP, true, lds_sort);
@@ -1082,6 +1121,21 @@ struct Gibbs {
             else VS_APPLY(DIST_DD, false, lds_plain);
 #undef VS_APPLY
             HIP_CHECK(hipGetLastError());
+        } else if (batch_value_sorted) {
+            // group count too large for the LDS-aggregated kernel: un-sort
+            // the moves and take the direct-atomics kernel
+            VsCache & c = vs_get(batch_begin, batch_end);
+            flush_assign_pos();
+            old_row.reserve(std::max<size_t>(n, 1), 0);
+            new_row.reserve(std::max<size_t>(n, 1), 0);
+            LAUNCH(k_pos_scatter, n, old_packed.p, c.sorted_rows.p, old_row.p, n);
+            LAUNCH(k_pos_scatter, n, new_packed.p, c.sorted_rows.p, new_row.p, n);
+            P.old_packed = old_row.p;
+            P.new_packed = new_row.p;
+            LAUNCH(k_apply_moves, n, P, img, d_p2g.p, assign);
+            // assign[] is now current: refresh the position copy
+            LAUNCH(k_pos_gather, n, assign + batch_begin, c.sorted_rows.p,
+                   c.assign_pos.p, n);
         } else {
             LAUNCH(k_apply_moves, n, P, img, d_p2g.p, assign);
         }
@@ -1193,6 +1247,7 @@ struct Gibbs {
     void get_row_scores(size_t row, float * out, size_t * size_out) {
         DIST_REQUIRE(row < n_rows, "bad row");
         DIST_REQUIRE(!batch_open, "batch open");
+        flush_assign_pos();
         upload_maps();
         row_scores.reserve(grow_capacity((size_t)K()), 0);
         row_size.reserve(1, 0);
@@ -1209,6 +1264,7 @@ struct Gibbs {
         DIST_REQUIRE(r0 <= r1 && r1 <= n_rows && ld >= (size_t)K(),
                      "bad row range or leading dimension");
         if (r0 == r1) return;
+        flush_assign_pos();
         SweepParams P = params(r0, r1, 0, 0);
         prepare(P);
         LAUNCH(k_score_rows, (r1 - r0) * (size_t)K(), P, out_dev, ld);
@@ -1777,6 +1833,7 @@ int dist_gibbs_counts(const dist_gibbs_t * g, int * out) {
 }
 int dist_gibbs_assignments(const dist_gibbs_t * g, uint32_t * global_out) {
     return guarded([&] {
+        g->impl->flush_assign_pos();
         sync();
         if (g->impl->n_rows)
             HIP_CHECK(hipMemcpy(global_out, g->impl->assign,

@@ -298,10 +298,16 @@ struct SweepParams {
     uint32_t seed_batch;
     const uint32_t * pow_lo;   // [4096]  16807^i
     const uint32_t * pow_hi;   // [..]    16807^(4096 i)
-    // when set, the generic kernel scores rows row_list[0 .. *row_list_count)
-    // (rows the value-sorted kernel handed over) instead of the whole range
+    // when set, the generic kernel scores the listed items instead of the
+    // whole range: the rows the value-sorted kernel handed over, as POSITIONS
+    // in the batch's value-sorted order (row = row_begin + sorted_rows[pos])
     const uint32_t * row_list;
     const uint32_t * row_list_count;
+    // value-sorted batches keep their per-row arrays in sorted-position order
+    // (coalesced for the kernels that walk tiles): the current assignment as
+    // global id, and old_packed / new_packed of the open batch
+    const uint32_t * sorted_rows;
+    const uint32_t * assign_pos;
 };
 
 // Integer statistics are exact under atomics.  `stats` is either the live
@@ -453,10 +459,11 @@ struct RowScorer {
         return s;
     }
 
-    __device__ __forceinline__ RowScorer(const SweepParams & P_, size_t row)
+    __device__ __forceinline__ RowScorer(const SweepParams & P_, size_t row,
+                                         uint32_t global_id)
         : P(P_) {
         const float shift = P.scalars->shift;
-        g = P.g2p[P.assign[row]];
+        g = P.g2p[global_id];
         const int n_g = P.counts[g];
         singleton = (n_g == 1);
         Kl = P.K - singleton;
@@ -525,10 +532,19 @@ __global__ __launch_bounds__(kBlock) void k_sweep_sample(SweepParams P) {
     for (size_t item = (size_t)blockIdx.x * kBlock + threadIdx.x;
          item < n_round; item += stride) {
         const bool live = item < n_items;
-        const size_t row = !live ? P.row_begin
-                           : P.row_list ? (size_t)P.row_list[item]
-                                        : P.row_begin + item;
-        const RowScorer<KIND0, KIND1, NF> rs(P, row);
+        // where the row's results go: batch-relative row index, or (list
+        // mode) its position in the value-sorted order
+        size_t out = live ? item : 0;
+        size_t row = P.row_begin + out;
+        uint32_t global_id;
+        if (P.row_list) {
+            out = live ? (size_t)P.row_list[item] : 0;
+            row = P.row_begin + P.sorted_rows[out];
+            global_id = P.assign_pos[out];
+        } else {
+            global_id = P.assign[row];
+        }
+        const RowScorer<KIND0, KIND1, NF> rs(P, row, global_id);
         const int Kl = rs.Kl;
 
         // vector_max (vector_math.cc:74-83)
@@ -566,9 +582,8 @@ __global__ __launch_bounds__(kBlock) void k_sweep_sample(SweepParams P) {
         int g2 = steps < Kl - 1 ? steps : Kl - 1;
         if (rs.singleton && g2 == rs.g) g2 = K - 1;   // slot g held group K-1
         if (live) {
-            const size_t b = row - P.row_begin;
-            P.old_packed[b] = (uint32_t)rs.g;
-            P.new_packed[b] = (uint32_t)g2;
+            P.old_packed[out] = (uint32_t)rs.g;
+            P.new_packed[out] = (uint32_t)g2;
         }
     }
 }
@@ -578,7 +593,7 @@ template <int KIND0, int KIND1, int NF>
 __global__ void k_row_scores(SweepParams P, size_t row, float * out,
                              int * size_out) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const RowScorer<KIND0, KIND1, NF> rs(P, row);
+    const RowScorer<KIND0, KIND1, NF> rs(P, row, P.assign[row]);
     for (int k = 0; k < rs.Kl; ++k) out[k] = rs.at(k);
     *size_out = rs.Kl;
 }
@@ -876,8 +891,9 @@ __global__ __launch_bounds__(kBlock) void k_vs_sample(
         u[r] = 0.f;
         bool classB = false;
         if (valid[r]) {
-            row[r] = P.row_begin + sorted_rows[pos + lane + 64 * r];
-            g[r] = P.g2p[P.assign[row[r]]];
+            const uint32_t at = pos + lane + 64 * r;
+            row[r] = P.row_begin + sorted_rows[at];
+            g[r] = P.g2p[P.assign_pos[at]];
             const int n_g = P.counts[g[r]];
             classB = (g[r] == amax);
             const float m = classB ? mB : M;
@@ -888,7 +904,7 @@ __global__ __launch_bounds__(kBlock) void k_vs_sample(
                 defer = !classB && s_own > M;   // table rounding lifted it
             }
             if (defer) {
-                deferred[atomicAdd(deferred_count, 1u)] = (uint32_t)row[r];
+                deferred[atomicAdd(deferred_count, 1u)] = pos + lane + 64 * r;
                 valid[r] = false;
             } else {
                 l_own[r] = fast_exp_nonpos(s_own - m, g_tables_dev.exp_table,
@@ -918,9 +934,9 @@ __global__ __launch_bounds__(kBlock) void k_vs_sample(
 #pragma unroll
     for (int r = 0; r < kVsR; ++r) {
         if (valid[r]) {
-            const size_t bidx = row[r] - P.row_begin;
-            P.old_packed[bidx] = (uint32_t)g[r];
-            P.new_packed[bidx] = (uint32_t)g2[r];
+            const uint32_t at = pos + lane + 64 * r;
+            P.old_packed[at] = (uint32_t)g[r];
+            P.new_packed[at] = (uint32_t)g2[r];
         }
     }
 }
@@ -943,7 +959,7 @@ template <int KIND, bool SORT>
 __global__ __launch_bounds__(kBlock) void k_vs_apply(
         SweepParams P, StatImage img, const VsTile * __restrict__ chunks,
         uint32_t * __restrict__ sorted_rows,
-        const uint32_t * __restrict__ p2g, uint32_t * __restrict__ assign) {
+        const uint32_t * __restrict__ p2g, uint32_t * __restrict__ assign_pos) {
     extern __shared__ int vs_lds[];
     const int K = P.K;
     int * delta = vs_lds;                 // [K]
@@ -960,17 +976,17 @@ __global__ __launch_bounds__(kBlock) void k_vs_apply(
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < n; i += kBlock) {
-        const uint32_t b = sorted_rows[pos + i];
-        const uint32_t go = P.old_packed[b], gn = P.new_packed[b];
-        if (assign) assign[P.row_begin + b] = p2g[gn];
+        const uint32_t go = P.old_packed[pos + i], gn = P.new_packed[pos + i];
         if (go != gn) {
             atomicAdd(&delta[go], -1);
             atomicAdd(&delta[gn], 1);
         }
         if (SORT) {
-            rows_l[i] = b;
+            rows_l[i] = sorted_rows[pos + i];
             gn_l[i] = gn;
             atomicAdd(&hist[gn], 1);
+        } else {
+            assign_pos[pos + i] = p2g[gn];
         }
     }
     __syncthreads();
@@ -1014,6 +1030,7 @@ __global__ __launch_bounds__(kBlock) void k_vs_apply(
     for (uint32_t i = threadIdx.x; i < n; i += kBlock) {
         const int p = atomicAdd(&hist[gn_l[i]], 1);
         sorted_rows[pos + p] = rows_l[i];
+        assign_pos[pos + p] = p2g[gn_l[i]];
     }
 }
 
@@ -1023,6 +1040,20 @@ __global__ void k_max_value(const uint32_t * __restrict__ values, size_t n,
     uint32_t v = i < n ? values[i] : 0u;
     for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off));
     if ((threadIdx.x & 63) == 0) atomicMax(out, v);
+}
+
+// row order <-> value-sorted position order
+__global__ void k_pos_gather(const uint32_t * __restrict__ by_row,
+                             const uint32_t * __restrict__ sorted_rows,
+                             uint32_t * __restrict__ by_pos, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) by_pos[i] = by_row[sorted_rows[i]];
+}
+__global__ void k_pos_scatter(const uint32_t * __restrict__ by_pos,
+                              const uint32_t * __restrict__ sorted_rows,
+                              uint32_t * __restrict__ by_row, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) by_row[sorted_rows[i]] = by_pos[i];
 }
 
 // counting sort of a batch's rows by value (one-time per batch range).  A
