@@ -506,6 +506,7 @@ struct Gibbs {
 
     DeviceBuf<uint32_t> old_packed, new_packed;
     DeviceBuf<uint32_t> old_row, new_row;   // row-ordered copies (see replay)
+    DeviceBuf<int2> struct_moves;           // {dst, src} slot copies
     // ordered replay of float statistics: events sorted stably by group
     DeviceBuf<uint32_t> ev_keys, ev_vals, ev_keys_sorted, ev_vals_sorted;
     DeviceBuf<uint32_t> seg_begin, seg_end;
@@ -1197,25 +1198,49 @@ struct Gibbs {
         for (int k = 0; k < K0; ++k)
             if (snap[k] == 0 && py.counts[k] > 0) created += 1;
         bool structural = created > 0;
+        // swap-removals in descending slot order, simulated on the host:
+        // content[i] = original slot of the group that ends up in slot i
+        std::vector<int> content((size_t)K0);
+        for (int k = 0; k < K0; ++k) content[k] = k;
+        int size = K0;
         for (int k = K0 - 1; k >= 0; --k) {
             if (snap[k] > 0 && py.counts[k] == 0) {
                 structural = true;
-                const int last = K() - 1;
+                const int last = size - 1;
                 if (k != last) {
+                    content[k] = content[last];
                     py.counts[k] = py.counts[last];
-                    LAUNCH1(k_py_move, py.d_counts.p, py.d_shifted.p, k, last);
                 }
+                size -= 1;
                 py.counts.pop_back();
-                for (auto & s : feats) s->remove_group((size_t)k);
                 tracker.remove_group((uint32_t)k);
             }
         }
-        for (int c = 0; c < created; ++c) {
-            py.counts.push_back(0);
+        std::vector<int2> moves;
+        for (int i = 0; i < size; ++i)
+            if (content[i] != i) moves.push_back(int2{i, content[i]});
+        if (!moves.empty()) {
+            // sources lie in [size, K0), destinations in [0, size): one
+            // launch per object copies them all
+            struct_moves.upload(moves.data(), moves.size());
+            const int nm = (int)moves.size();
+            LAUNCH(k_py_move_groups, (size_t)nm, py.d_counts.p, py.d_shifted.p,
+                   struct_moves.p, nm);
+            for (auto & s : feats) {
+                const size_t width = std::max(1, s->dim());
+                LAUNCH(k_slave_move_groups, (size_t)nm * width, s->view(),
+                       struct_moves.p, nm);
+            }
+        }
+        for (auto & s : feats) s->K = size;
+        if (created) {
+            const int k0 = size;
+            py.counts.resize((size_t)(size + created), 0);
             py.reserve(K());
-            LAUNCH1(k_py_set_count, py.d_counts.p, py.d_shifted.p, K() - 1, 0, d);
-            for (auto & s : feats) s->append_zero(1);
-            tracker.add_group();
+            LAUNCH(k_py_zero_range, (size_t)created, py.d_counts.p, k0,
+                   k0 + created);
+            for (auto & s : feats) s->append_zero(created);
+            for (int c = 0; c < created; ++c) tracker.add_group();
         }
         if (structural) maps_dirty = true;
         rebuild_caches();

@@ -188,6 +188,40 @@ __global__ void k_slave_move_group(SlaveView s, int dst, int src) {
     }
 }
 
+// Many packed_remove steps at once: after a batch the host works out which
+// original group ends up in which slot (sources lie beyond the new end,
+// destinations inside it, so the copies are independent) and one launch per
+// object performs them.  moves[i] = {dst, src}.
+__global__ void k_slave_move_groups(SlaveView s, const int2 * __restrict__ moves,
+                                    int n_moves) {
+    const int width = is_cat(s.kind) ? s.dim : 1;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)n_moves * width) return;
+    const int dst = moves[i / width].x, src = moves[i / width].y;
+    const int v = (int)(i % width);
+    if (is_cat(s.kind)) {
+        s.cnt[(size_t)dst * s.dim + v] = s.cnt[(size_t)src * s.dim + v];
+        s.S[(size_t)v * s.cap + dst] = s.S[(size_t)v * s.cap + src];
+    }
+    if (v == 0) {
+        s.i0[dst] = s.i0[src]; s.i1[dst] = s.i1[src];
+        s.f0[dst] = s.f0[src]; s.f1[dst] = s.f1[src];
+        s.c0[dst] = s.c0[src]; s.c1[dst] = s.c1[src];
+        s.c2[dst] = s.c2[src]; s.c3[dst] = s.c3[src];
+    }
+}
+__global__ void k_py_move_groups(int32_t * counts, float * shifted,
+                                 const int2 * __restrict__ moves, int n_moves) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_moves) return;
+    counts[moves[i].x] = counts[moves[i].y];
+    shifted[moves[i].x] = shifted[moves[i].y];
+}
+__global__ void k_py_zero_range(int32_t * counts, int k0, int k1) {
+    const int k = k0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < k1) counts[k] = 0;
+}
+
 // MixtureSlave::score_value (accumulates) and score_value_group
 __global__ void k_slave_score_value(SlaveView s, uint32_t value,
                                     float * __restrict__ acc, int K) {
