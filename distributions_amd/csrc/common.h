@@ -4,6 +4,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
+#include <cstdlib>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -78,6 +80,9 @@ struct DeviceBuf {
     // grows to at least n elements, keeping the first `keep` elements
     void reserve(size_t n, size_t keep) {
         if (n <= cap) return;
+        if (getenv("DIST_TRACE_ALLOC"))
+            fprintf(stderr, "[dist] device buffer grows %zu -> %zu elements of %zu B\n",
+                    cap, n, sizeof(T));
         T * q = nullptr;
         HIP_CHECK(hipMalloc(&q, n * sizeof(T)));
         HIP_CHECK(hipMemsetAsync(q, 0, n * sizeof(T), stream()));

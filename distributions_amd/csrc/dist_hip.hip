@@ -960,8 +960,9 @@ struct Gibbs {
         const size_t n = P.row_end - P.row_begin;
         const uint32_t nv = (uint32_t)vs_nvals();
         const int Kpad = (K() + kVsUnroll - 1) / kVsUnroll * kVsUnroll;
-        vsLA.reserve((size_t)nv * Kpad, 0);
-        vsLB.reserve((size_t)nv * Kpad, 0);
+        // (headroom: K creeps up by a group per batch; no realloc per step)
+        vsLA.reserve(grow_capacity((size_t)nv * Kpad), 0);
+        vsLB.reserve(grow_capacity((size_t)nv * Kpad), 0);
         vsM.reserve(nv, 0);
         vsmB.reserve(nv, 0);
         vsArg.reserve(nv, 0);
@@ -988,8 +989,13 @@ struct Gibbs {
         SweepParams Q = P;
         Q.row_list = deferred.p;
         Q.row_list_count = deferred_count.p;
-        DeferredLaunch D{&Q};
-        dispatch(D);
+        if (wave_rows_fit()) {
+            WaveRowsLaunch D{&Q, K(), 1024};
+            dispatch(D);
+        } else {
+            DeferredLaunch D{&Q};
+            dispatch(D);
+        }
     }
     struct DeferredLaunch {
         SweepParams * P;
@@ -1000,6 +1006,24 @@ struct Gibbs {
             HIP_CHECK(hipGetLastError());
         }
     };
+    // one wave per row (list mode or a small range)
+    struct WaveRowsLaunch {
+        SweepParams * P;
+        int K;
+        unsigned blocks;
+        template <int A, int B, int NF>
+        void run() {
+            hipLaunchKernelGGL((k_rows_wave<A, B, NF>), dim3(blocks),
+                               dim3(kBlock),
+                               (size_t)(kBlock / 64) * K * sizeof(float),
+                               stream(), *P);
+            HIP_CHECK(hipGetLastError());
+        }
+    };
+    // the wave-per-row kernel keeps K floats per wave in LDS
+    bool wave_rows_fit() const {
+        return (size_t)(kBlock / 64) * K() * sizeof(float) <= 60 * 1024;
+    }
 
     void batch_sample(size_t r0, size_t r1, uint32_t seed, uint64_t draw_base) {
         DIST_REQUIRE(!batch_open, "previous batch not finished");
@@ -1016,6 +1040,16 @@ struct Gibbs {
         if (batch_value_sorted) {
             sample_value_sorted(P);
             vs_batches += 1;
+        } else if (r1 - r0 <= 2048 && wave_rows_fit()) {
+            // a handful of rows (the sequential chain is one): a wave each
+            prepare(P, false);
+            HIP_CHECK(hipEventRecord(ev0, stream()));
+            WaveRowsLaunch L{&P, K(),
+                             (unsigned)((r1 - r0 + kBlock / 64 - 1)
+                                        / (kBlock / 64))};
+            dispatch(L);
+            HIP_CHECK(hipEventRecord(ev1, stream()));
+            generic_batches += 1;
         } else {
             prepare(P);
             SampleLaunch L{this, &P};

@@ -537,6 +537,20 @@ struct RowScorer {
         const float s = cached(k);
         return k == g ? s_own : s;
     }
+
+    // the same score with a per-lane slot index (lanes of a wave score 64
+    // slots of ONE row at once): plain loads, identical arithmetic
+    __device__ __forceinline__ float at_lane(int k) const {
+        float s = singleton ? P.base_single[k] : P.base[k];
+#pragma unroll kUnroll
+        for (int f = 0; f < nf(); ++f) {
+            SlaveView v = P.feat[f];
+            v.kind = kind_of(f);
+            s = accumulate(v.kind, s, load_entry(v, k, x[f]), x[f], lf[f],
+                           v.p);
+        }
+        return k == g ? s_own : s;
+    }
 };
 
 // One lane = one row: three passes over the groups in index order, exactly
@@ -619,6 +633,80 @@ __global__ __launch_bounds__(kBlock) void k_sweep_sample(SweepParams P) {
             P.old_packed[out] = (uint32_t)rs.g;
             P.new_packed[out] = (uint32_t)g2;
         }
+    }
+}
+
+// One WAVE per row, for the rows that come one at a time: the hand-overs of
+// the value-sorted kernel, tiny batches, the sequential chain.  Lanes score 64
+// slots at once (coalesced cache reads) and exponentiate them in parallel into
+// the wave's LDS strip; only the two order-sensitive recurrences run serially
+// (every lane computes the same sum over LDS broadcasts).  Same float
+// operations as the lane-per-row kernel, a row's latency drops from ~3K
+// dependent gather round trips to ~2K LDS-fed adds.
+template <int KIND0, int KIND1, int NF>
+__global__ __launch_bounds__(kBlock) void k_rows_wave(SweepParams P) {
+    extern __shared__ float wave_lds[];
+    __shared__ uint32_t s_exp[1024];
+    for (int i = threadIdx.x; i < 1024; i += kBlock)
+        s_exp[i] = g_tables_dev.exp_table[i];
+    __syncthreads();
+    const float ea = u2f(g_tables_dev.exp_ab[0]);
+    const float eb = u2f(g_tables_dev.exp_ab[1]);
+    const int K = P.K;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    float * sl = wave_lds + (size_t)wave * K;
+
+    const size_t n_items = P.row_list ? (size_t)*P.row_list_count
+                                      : P.row_end - P.row_begin;
+    const size_t stride = (size_t)gridDim.x * (kBlock / 64);
+    for (size_t item = (size_t)blockIdx.x * (kBlock / 64) + wave;
+         item < n_items; item += stride) {
+        size_t out = item;
+        size_t row = P.row_begin + item;
+        uint32_t global_id;
+        if (P.row_list) {
+            out = (size_t)P.row_list[item];
+            row = P.row_begin + P.sorted_rows[out];
+            global_id = P.assign_pos[out];
+        } else {
+            global_id = P.assign[row];
+        }
+        const RowScorer<KIND0, KIND1, NF> rs(P, row, global_id);
+        const int Kl = rs.Kl;
+        // scores and vector_max (vector_math.cc:74-83; max is order-free)
+        float m = -INFINITY;
+        for (int k = lane; k < Kl; k += 64) {
+            const float s = rs.at_lane(k);
+            sl[k] = s;
+            m = s > m ? s : m;
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            const float o = __shfl_xor(m, off);
+            m = o > m ? o : m;
+        }
+        // scores_to_likelihoods: the exponentials in parallel ...
+        for (int k = lane; k < Kl; k += 64)
+            sl[k] = fast_exp_nonpos(sl[k] - m, s_exp, ea, eb);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ... their total in index order (random.cc:100-103)
+        float total = 0.f;
+        for (int k = 0; k < Kl; ++k) total += sl[k];
+        // sample_from_likelihoods (random.hpp:316-333)
+        float t = total * batch_row_unif01(P, row);
+        int g2 = Kl - 1;
+        for (int k = 0; k < Kl; ++k) {
+            t -= sl[k];
+            if (t <= 0.f) { g2 = k; break; }
+        }
+        if (rs.singleton && g2 == rs.g) g2 = K - 1;   // slot g held group K-1
+        if (lane == 0) {
+            P.old_packed[out] = (uint32_t)rs.g;
+            P.new_packed[out] = (uint32_t)g2;
+        }
+        __builtin_amdgcn_wave_barrier();   // before the strip is reused
     }
 }
 
