@@ -189,9 +189,11 @@ def main():
         bytes_per_row = 32 * k + 16       # (1+3+4)*4K + 16
     g = engine.Gibbs(args.alpha, args.d, shareds)
     g.set_option("value_sorted", args.value_sorted)
+    initial = assign.clone()   # the engine keeps updating `assign` in place
     g.load_rows_torch(columns, assign, k, 1, row_offset=row_offset)
     sharded = engine.ShardedGibbs(g.core, n, row_offset, device=dev,
-                                  force_collective=args.force_collective)
+                                  force_collective=args.force_collective,
+                                  columns=columns, assign_packed=initial)
     sharded.sync_initial_stats()
     seed_state = _core.rng_seed(args.seed)
 

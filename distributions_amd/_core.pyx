@@ -135,6 +135,11 @@ cdef extern from "distributions_hip.h" nogil:
                                 uint64_t)
     int dist_gibbs_batch_delta_dev(dist_gibbs_t *, int32_t *)
     int dist_gibbs_batch_apply_delta_dev(dist_gibbs_t *, const int32_t *)
+    int dist_gibbs_ordered_features(const dist_gibbs_t *, int *)
+    int dist_gibbs_batch_moves_dev(dist_gibbs_t *, uint32_t *, uint32_t *)
+    int dist_gibbs_replay_ordered_dev(dist_gibbs_t *, const uint32_t *,
+                                      const uint32_t *,
+                                      const uint32_t * const *, size_t, int)
     int dist_gibbs_batch_apply_local(dist_gibbs_t *)
     int dist_gibbs_batch_finish(dist_gibbs_t *)
     int dist_gibbs_row_scores(dist_gibbs_t *, size_t, float *, size_t *)
@@ -703,6 +708,36 @@ cdef class GibbsEngine:
 
     def batch_apply_local(self):
         check(dist_gibbs_batch_apply_local(self.ptr))
+
+    def ordered_features(self):
+        """number of features with order-dependent statistics (NICH, GP)"""
+        cdef int n = 0
+        check(dist_gibbs_ordered_features(self.ptr, &n))
+        return n
+
+    def feature_is_ordered(self, int feature):
+        cdef SharedParams s = self.shareds[feature]
+        return s.c.kind == DIST_GP or s.c.kind == DIST_NICH
+
+    def batch_moves_dev(self, size_t old_ptr, size_t new_ptr):
+        check(dist_gibbs_batch_moves_dev(self.ptr, <uint32_t *> old_ptr,
+                                         <uint32_t *> new_ptr))
+
+    def replay_ordered_dev(self, size_t old_ptr, size_t new_ptr, value_ptrs,
+                           size_t n_rows, bint reset):
+        """value_ptrs: per feature a device address or 0"""
+        cdef int n = len(value_ptrs)
+        cdef const uint32_t ** ptrs = <const uint32_t **> malloc(
+            max(n, 1) * sizeof(void *))
+        cdef size_t addr
+        for i in range(n):
+            addr = value_ptrs[i]
+            ptrs[i] = <const uint32_t *> addr
+        cdef int rc = dist_gibbs_replay_ordered_dev(
+            self.ptr, <const uint32_t *> old_ptr, <const uint32_t *> new_ptr,
+            ptrs, n_rows, reset)
+        free(ptrs)
+        check(rc)
 
     def batch_finish(self):
         check(dist_gibbs_batch_finish(self.ptr))

@@ -523,6 +523,7 @@ struct Gibbs {
     size_t batch_begin = 0, batch_end = 0;   // rows of the open batch
     bool batch_open = false;
     bool batch_value_sorted = false;
+    bool moves_in_row_order = false;   // old_row/new_row hold the open batch
     bool timing_pending = false;
     int * pinned_counts = nullptr;
     size_t pinned_cap = 0;
@@ -1032,6 +1033,7 @@ struct Gibbs {
         batch_end = r1;
         batch_open = true;
         batch_value_sorted = false;
+        moves_in_row_order = false;
         if (r0 == r1) return;
         upload_maps();
         SweepParams P = params(r0, r1, seed, draw_base);
@@ -1081,34 +1083,69 @@ struct Gibbs {
     // are sorted stably by group, then one wave per group walks its segment.
     // old_dev == nullptr: rows are only added (initial load).
     void replay_sorted(const uint32_t * old_dev, const uint32_t * new_dev,
-                       size_t row_begin, size_t n_rows) {
+                       size_t row_begin, size_t n_rows,
+                       const uint32_t * const * vals = nullptr) {
         if (!any_float_stats() || !n_rows) return;
+        if (!vals) vals = values.data();
         const size_t n_ev = old_dev ? 2 * n_rows : n_rows;
         const size_t Kn = (size_t)K();
-        int bits = 1;
-        while ((1ull << bits) < Kn) bits += 1;
+        int bits = 1;   // keys 0..Kn (Kn = padding)
+        while ((1ull << bits) < Kn + 1) bits += 1;
         ev_keys.reserve(n_ev, 0); ev_vals.reserve(n_ev, 0);
         ev_keys_sorted.reserve(n_ev, 0); ev_vals_sorted.reserve(n_ev, 0);
-        seg_begin.reserve(grow_capacity(Kn), 0);
-        seg_end.reserve(grow_capacity(Kn), 0);
+        seg_begin.reserve(grow_capacity(Kn + 1), 0);
+        seg_end.reserve(grow_capacity(Kn + 1), 0);
         const size_t tb = sort_pairs_temp_bytes(n_ev, bits);
         sort_temp.reserve(tb + 256, 0);
-        LAUNCH(k_replay_events, n_rows, old_dev, new_dev, n_rows, ev_keys.p,
-               ev_vals.p);
+        LAUNCH(k_replay_events, n_rows, old_dev, new_dev, n_rows,
+               (uint32_t)Kn, ev_keys.p, ev_vals.p);
         sort_pairs(sort_temp.p, tb, ev_keys.p, ev_keys_sorted.p, ev_vals.p,
                    ev_vals_sorted.p, n_ev, bits, stream());
-        HIP_CHECK(hipMemsetAsync(seg_begin.p, 0, Kn * 4, stream()));
-        HIP_CHECK(hipMemsetAsync(seg_end.p, 0, Kn * 4, stream()));
+        HIP_CHECK(hipMemsetAsync(seg_begin.p, 0, (Kn + 1) * 4, stream()));
+        HIP_CHECK(hipMemsetAsync(seg_end.p, 0, (Kn + 1) * 4, stream()));
         LAUNCH(k_replay_bounds, n_ev, ev_keys_sorted.p, n_ev, seg_begin.p,
                seg_end.p);
         for (int f = 0; f < F(); ++f) {
             if (!has_float_stats(feats[f]->sh.kind)) continue;
+            DIST_REQUIRE(vals[f], "replay: no values for an ordered feature");
             hipLaunchKernelGGL(k_replay_sorted, dim3((unsigned)Kn), dim3(64),
-                               0, stream(), feats[f]->view(), values[f],
+                               0, stream(), feats[f]->view(), vals[f],
                                row_begin, ev_vals_sorted.p, seg_begin.p,
                                seg_end.p);
             HIP_CHECK(hipGetLastError());
         }
+    }
+    // Multi-rank exchange of the order-dependent statistics: the moves of the
+    // open batch in row order (slot indices of the batch snapshot) ...
+    void batch_moves(uint32_t * old_dev, uint32_t * new_dev) {
+        DIST_REQUIRE(batch_open, "no open batch");
+        const size_t n = batch_end - batch_begin;
+        if (!n) return;
+        const uint32_t * o = old_packed.p, * w = new_packed.p;
+        if (batch_value_sorted) {
+            DIST_REQUIRE(any_float_stats() && moves_in_row_order,
+                         "batch_moves: call after batch_delta, on a mixture "
+                         "with order-dependent statistics");
+            o = old_row.p; w = new_row.p;
+        }
+        HIP_CHECK(hipMemcpyAsync(old_dev, o, n * 4, hipMemcpyDeviceToDevice,
+                                 stream()));
+        HIP_CHECK(hipMemcpyAsync(new_dev, w, n * 4, hipMemcpyDeviceToDevice,
+                                 stream()));
+    }
+    // ... and the replay of an event list gathered from all ranks in rank
+    // (= global row) order.  old_dev == nullptr: additions only.
+    void replay_ordered(const uint32_t * old_dev, const uint32_t * new_dev,
+                        const uint32_t * const * vals, size_t n, bool reset) {
+        if (reset) {
+            for (int f = 0; f < F(); ++f) {
+                if (!has_float_stats(feats[f]->sh.kind)) continue;
+                LAUNCH(k_zero_ordered_stats, (size_t)K(), feats[f]->view(),
+                       K());
+            }
+        }
+        replay_sorted(old_dev, new_dev, 0, n, vals);
+        if (reset && !batch_open) rebuild_caches();
     }
     void replay_floats() {
         // value-sorted batches hold the moves by position; apply_ints left a
@@ -1142,6 +1179,7 @@ struct Gibbs {
                        old_row.p, n);
                 LAUNCH(k_pos_scatter, n, new_packed.p, c.sorted_rows.p,
                        new_row.p, n);
+                moves_in_row_order = true;
             }
             c.dirty = true;
 #define VS_APPLY(KIND, SORT, LDS)                                            \
@@ -1165,6 +1203,7 @@ struct Gibbs {
             new_row.reserve(std::max<size_t>(n, 1), 0);
             LAUNCH(k_pos_scatter, n, old_packed.p, c.sorted_rows.p, old_row.p, n);
             LAUNCH(k_pos_scatter, n, new_packed.p, c.sorted_rows.p, new_row.p, n);
+            moves_in_row_order = true;
             P.old_packed = old_row.p;
             P.new_packed = new_row.p;
             LAUNCH(k_apply_moves, n, P, img, d_p2g.p, assign);
@@ -1183,10 +1222,6 @@ struct Gibbs {
     }
     void batch_delta(int32_t * delta_dev) {
         DIST_REQUIRE(batch_open, "no open batch");
-        for (auto & s : feats)
-            DIST_REQUIRE(s->sh.kind != DIST_NICH,
-                         "NormalInverseChiSq statistics are order-dependent: "
-                         "no integer delta (single-GPU only in this round)");
         HIP_CHECK(hipMemsetAsync(delta_dev, 0, stat_words() * 4, stream()));
         if (batch_end == batch_begin) return;
         apply_ints(word_image(delta_dev));
@@ -1212,9 +1247,8 @@ struct Gibbs {
             push(a.cnt[f], k * feats[f]->dim());
         }
         LAUNCH(k_add_words, off, seg, delta_dev, off);
-        // GP log_prod never enters score_value (gp.hpp:198-217); it is
-        // replayed from the local rows only
-        replay_floats();
+        // the order-dependent statistics (NICH, GP log_prod) are not in the
+        // image: the caller gathers the moves and calls replay_ordered
     }
 
     // Normalise the group set after a batch (DESIGN.md "Batch semantics"):
@@ -1864,6 +1898,28 @@ int dist_gibbs_batch_apply_delta_dev(dist_gibbs_t * g,
 }
 int dist_gibbs_batch_apply_local(dist_gibbs_t * g) {
     return guarded([&] { g->impl->batch_apply_local(); });
+}
+int dist_gibbs_ordered_features(const dist_gibbs_t * g, int * count_out) {
+    return guarded([&] {
+        int n = 0;
+        for (auto & f : g->impl->feats)
+            if (has_float_stats(f->sh.kind)) n += 1;
+        *count_out = n;
+    });
+}
+int dist_gibbs_batch_moves_dev(dist_gibbs_t * g, uint32_t * old_slot_dev,
+                               uint32_t * new_slot_dev) {
+    return guarded([&] { g->impl->batch_moves(old_slot_dev, new_slot_dev); });
+}
+int dist_gibbs_replay_ordered_dev(dist_gibbs_t * g,
+                                  const uint32_t * old_slot_dev,
+                                  const uint32_t * new_slot_dev,
+                                  const uint32_t * const * values_dev,
+                                  size_t n_rows, int reset) {
+    return guarded([&] {
+        g->impl->replay_ordered(old_slot_dev, new_slot_dev, values_dev,
+                                n_rows, reset != 0);
+    });
 }
 int dist_gibbs_batch_finish(dist_gibbs_t * g) {
     return guarded([&] { g->impl->batch_finish(); });

@@ -1307,21 +1307,35 @@ __global__ void k_add_words(WordSegments seg,
 // events of batch row b: 2b = "remove from old[b]", 2b+1 = "add to new[b]";
 // sorted stably by group they are, per group, in row order with the removal
 // of a row ahead of its own addition.
+// A slot of 0xFFFFFFFF marks padding (ragged gathers of the multi-rank
+// exchange): its events get key `n_groups`, a segment nobody replays.
 __global__ void k_replay_events(const uint32_t * __restrict__ old_packed,
                                 const uint32_t * __restrict__ new_packed,
-                                size_t n_rows, uint32_t * __restrict__ keys,
+                                size_t n_rows, uint32_t n_groups,
+                                uint32_t * __restrict__ keys,
                                 uint32_t * __restrict__ vals) {
     const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= n_rows) return;
+    const uint32_t g2 = new_packed[b];
+    const bool pad = g2 == 0xFFFFFFFFu;
     if (old_packed) {
-        keys[2 * b] = old_packed[b];
+        keys[2 * b] = pad ? n_groups : old_packed[b];
         vals[2 * b] = (uint32_t)(2 * b);
-        keys[2 * b + 1] = new_packed[b];
+        keys[2 * b + 1] = pad ? n_groups : g2;
         vals[2 * b + 1] = (uint32_t)(2 * b + 1);
     } else {   // initial load: additions only
-        keys[b] = new_packed[b];
+        keys[b] = pad ? n_groups : g2;
         vals[b] = (uint32_t)(2 * b + 1);
     }
+}
+
+// the order-dependent statistics back to Group::init (before a replay of
+// the whole data set): all of NICH's, GP's log_prod
+__global__ void k_zero_ordered_stats(SlaveView s, int K) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    s.f0[k] = 0.f;
+    if (s.kind == DIST_NICH) { s.i0[k] = 0; s.f1[k] = 0.f; }
 }
 
 // first/one-past-last position of every group's events in the sorted list

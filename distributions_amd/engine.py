@@ -121,7 +121,12 @@ class ShardedGibbs(object):
     """
 
     def __init__(self, backend, n_local, row_offset, group=None, device=None,
-                 force_collective=False):
+                 force_collective=False, columns=None, assign_packed=None):
+        """columns: the local value columns (per feature a 4-byte-per-row
+        tensor, as given to load_rows); assign_packed: the local initial
+        assignment.  Both are needed only when a feature has order-dependent
+        statistics (NormalInverseChiSq, GammaPoisson's log_prod): those are
+        exchanged as rows, not as sums."""
         import torch.distributed as dist
         self.dist = dist
         self.backend = backend
@@ -134,6 +139,52 @@ class ShardedGibbs(object):
         # rank (what N > 1 runs, exercised on a single GPU)
         self.collective = self.world > 1 or (force_collective
                                              and dist.is_initialized())
+        self.ordered = self.collective and backend.ordered_features() > 0
+        self.columns = columns
+        self.assign_packed = assign_packed
+        if self.ordered and columns is None:
+            raise ValueError("features with order-dependent statistics need "
+                             "the local value columns (columns=...)")
+
+    def _gather_rows(self, arrays, n_pad):
+        """arrays: list of (tensor-or-None, n valid) with 4-byte elements ->
+        per array the concatenation over ranks (rank order) of the tensors
+        padded to n_pad with 0xFFFFFFFF; ONE all-gather."""
+        import torch
+        pack = torch.full((len(arrays), n_pad), -1, dtype=torch.int32,
+                          device=self.device)
+        for i, t in enumerate(arrays):
+            if t is not None and t.numel():
+                pack[i, :t.numel()] = t.view(torch.int32)
+        if self.world == 1:
+            return [pack[i] for i in range(len(arrays))]
+        out = torch.empty((self.world,) + tuple(pack.shape), dtype=torch.int32,
+                          device=self.device)
+        self.dist.all_gather(list(out.unbind(0)), pack, group=self.group)
+        return [out[:, i, :].reshape(-1).contiguous()
+                for i in range(len(arrays))]
+
+    def _replay(self, old, new, cols, n_pad, reset):
+        """cols: per feature the local slice (or None)"""
+        arrays = [new] + ([old] if old is not None else []) + [
+            c for c in cols if c is not None]
+        got = self._gather_rows(arrays, n_pad)
+        new_all = got[0]
+        old_all = got[1] if old is not None else None
+        rest = got[2:] if old is not None else got[1:]
+        ptrs, j = [], 0
+        for c in cols:
+            if c is None:
+                ptrs.append(0)
+            else:
+                ptrs.append(int(rest[j].data_ptr()))
+                j += 1
+        self.backend.replay_ordered_dev(
+            int(old_all.data_ptr()) if old_all is not None else 0,
+            int(new_all.data_ptr()), ptrs, int(new_all.numel()), bool(reset))
+
+    def _is_ordered(self, f):
+        return self.backend.feature_is_ordered(f)
 
     def _all_reduce(self, tensor):
         if self.collective:
@@ -150,6 +201,19 @@ class ShardedGibbs(object):
         self.backend.export_stats_dev(int(t.data_ptr()))
         self._all_reduce(t)
         self.backend.import_stats_dev(int(t.data_ptr()))
+        if self.ordered:
+            # order-dependent statistics: every replica replays ALL rows in
+            # global order (Group::add_value per row, in row order)
+            if self.assign_packed is None:
+                raise ValueError("sync_initial_stats needs assign_packed")
+            nmax = torch.tensor([self.n_local], dtype=torch.int64,
+                                device=self.device)
+            self.dist.all_reduce(nmax, op=self.dist.ReduceOp.MAX,
+                                 group=self.group)
+            cols = [c if self._is_ordered(f) else None
+                    for f, c in enumerate(self.columns)]
+            self._replay(None, self.assign_packed, cols, int(nmax.item()),
+                         reset=True)
 
     def sweep(self, batch_rows, seed_state, draw_base=0):
         """One pass over the local shard; all ranks take the same number of
@@ -174,4 +238,15 @@ class ShardedGibbs(object):
                 self.backend.batch_delta_dev(int(delta.data_ptr()))
                 self._all_reduce(delta)
                 self.backend.batch_apply_delta_dev(int(delta.data_ptr()))
+                if self.ordered:
+                    nb_rows = r1 - r0
+                    old = torch.empty(nb_rows, dtype=torch.int32,
+                                      device=self.device)
+                    new = torch.empty(nb_rows, dtype=torch.int32,
+                                      device=self.device)
+                    self.backend.batch_moves_dev(int(old.data_ptr()),
+                                                 int(new.data_ptr()))
+                    cols = [c[r0:r1] if self._is_ordered(f) else None
+                            for f, c in enumerate(self.columns)]
+                    self._replay(old, new, cols, batch_rows, reset=False)
             self.backend.batch_finish()

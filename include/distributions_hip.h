@@ -233,8 +233,11 @@ int dist_gibbs_sweep(dist_gibbs_t * g, size_t row_begin, size_t row_end,
 int dist_gibbs_sweep_sequential(dist_gibbs_t * g, size_t row_begin,
                                 size_t row_end, uint32_t * rng_state);
 /* the same pass in phases, for callers that exchange statistics between
- * GPUs: sample -> moves_to_delta -> [all-reduce delta] -> apply_delta ->
- * finish.  delta is dist_gibbs_stat_words() int32 words of device memory. */
+ * GPUs: sample -> delta -> [all-reduce delta] -> apply_delta ->
+ * (ordered statistics: moves -> [all-gather] -> replay_ordered) -> finish.
+ * delta is dist_gibbs_stat_words() int32 words of device memory and carries
+ * the statistics that add over ranks (group sizes, DD/DPD/BB counts, GP count
+ * and sum). */
 int dist_gibbs_batch_sample(dist_gibbs_t * g, size_t row_begin, size_t row_end,
                             uint32_t seed_state, uint64_t draw_base);
 int dist_gibbs_batch_delta_dev(dist_gibbs_t * g, int32_t * delta_dev);
@@ -242,6 +245,25 @@ int dist_gibbs_batch_apply_delta_dev(dist_gibbs_t * g,
                                      const int32_t * delta_dev);
 int dist_gibbs_batch_apply_local(dist_gibbs_t * g);
 int dist_gibbs_batch_finish(dist_gibbs_t * g);
+/* Order-dependent statistics -- all of NormalInverseChiSq's (Welford updates,
+ * nich.hpp:125-165) and GammaPoisson's log_prod (gp.hpp:115,134) -- do not add
+ * over ranks: they are replayed in global row order on every replica.
+ * ordered_features: how many features carry such statistics.
+ * batch_moves_dev: the open batch's moves in row order (slot indices of the
+ * batch snapshot, identical on every replica); call after batch_delta_dev.
+ * replay_ordered_dev: row i of the gathered list (rank order) leaves slot
+ * old_slot[i] (NULL: additions only) and joins new_slot[i]; 0xFFFFFFFF in
+ * new_slot marks padding; values_dev[f] -> n_rows words for every ordered
+ * feature f (other entries may be NULL).  reset != 0 returns those statistics
+ * to Group::init first (replay of the whole data set after load_rows). */
+int dist_gibbs_ordered_features(const dist_gibbs_t * g, int * count_out);
+int dist_gibbs_batch_moves_dev(dist_gibbs_t * g, uint32_t * old_slot_dev,
+                               uint32_t * new_slot_dev);
+int dist_gibbs_replay_ordered_dev(dist_gibbs_t * g,
+                                  const uint32_t * old_slot_dev,
+                                  const uint32_t * new_slot_dev,
+                                  const uint32_t * const * values_dev,
+                                  size_t n_rows, int reset);
 
 /* batch-semantics scores of one resident row (length written to *size_out;
  * scores_out needs dist_gibbs_group_count() floats) */

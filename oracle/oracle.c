@@ -1234,20 +1234,86 @@ void orc_mix_batch_sample(const orc_mix * m, size_t row_begin, size_t row_end,
     orc_ftz_restore(saved);
 }
 
+/* The statistics split in two parts for the multi-rank exchange: integers
+ * that sum over ranks (group sizes, DD/DPD/BB counts, GP count and sum) and
+ * the order-dependent ones, which are replayed in global row order (all of
+ * NICH's count/mean/count_times_variance, nich.hpp:125-165; GP's log_prod,
+ * gp.hpp:115,134). */
+static void group_apply_part(feat * f, int k, uint32_t value, int add,
+                             int part) {
+    const int kind = f->sh.kind;
+    if (kind == ORC_NICH) {
+        if (!(part & ORC_PART_ORDERED)) return;
+        if (add) group_add(f, k, value); else group_remove(f, k, value);
+        return;
+    }
+    if (kind == ORC_GP) {
+        const int32_t i0 = f->i0[k], i1 = f->i1[k];
+        const float f0 = f->f0[k];
+        if (add) group_add(f, k, value); else group_remove(f, k, value);
+        if (!(part & ORC_PART_SUMMED)) { f->i0[k] = i0; f->i1[k] = i1; }
+        if (!(part & ORC_PART_ORDERED)) f->f0[k] = f0;
+        return;
+    }
+    if (!(part & ORC_PART_SUMMED)) return;
+    if (add) group_add(f, k, value); else group_remove(f, k, value);
+}
+
 /* phase 2: apply the moves in row order (remove, then add, per row) */
-void orc_mix_apply_moves(orc_mix * m, size_t row_begin, size_t row_end,
-                         const uint32_t * const * values, uint32_t * assign,
-                         const uint32_t * old_p, const uint32_t * new_p) {
+void orc_mix_apply_moves_part(orc_mix * m, size_t row_begin, size_t row_end,
+                              const uint32_t * const * values,
+                              uint32_t * assign, const uint32_t * old_p,
+                              const uint32_t * new_p, int part) {
     unsigned saved = orc_ftz_enable();
     for (size_t i = row_begin; i < row_end; ++i) {
         uint32_t g = old_p[i - row_begin], g2 = new_p[i - row_begin];
-        m->counts[g] -= 1;
-        m->counts[g2] += 1;
-        for (int fi = 0; fi < m->F; ++fi) {
-            group_remove(&m->f[fi], g, values[fi][i]);
-            group_add(&m->f[fi], g2, values[fi][i]);
+        if (part & ORC_PART_SUMMED) {
+            m->counts[g] -= 1;
+            m->counts[g2] += 1;
+            assign[i] = m->p2g[g2];
         }
-        assign[i] = m->p2g[g2];
+        for (int fi = 0; fi < m->F; ++fi) {
+            group_apply_part(&m->f[fi], g, values[fi][i], 0, part);
+            group_apply_part(&m->f[fi], g2, values[fi][i], 1, part);
+        }
+    }
+    orc_ftz_restore(saved);
+}
+void orc_mix_apply_moves(orc_mix * m, size_t row_begin, size_t row_end,
+                         const uint32_t * const * values, uint32_t * assign,
+                         const uint32_t * old_p, const uint32_t * new_p) {
+    orc_mix_apply_moves_part(m, row_begin, row_end, values, assign, old_p,
+                             new_p, ORC_PART_SUMMED | ORC_PART_ORDERED);
+}
+
+/* the order-dependent statistics over an event list gathered from all ranks
+ * (rank order == global row order): row i leaves slot old_p[i] (old_p == NULL:
+ * rows are only added) and joins new_p[i]; 0xFFFFFFFF marks padding.
+ * values[fi][i] is row i's value of feature fi (only read for NICH/GP
+ * features).  reset != 0 zeroes those statistics first (initial load). */
+void orc_mix_replay_ordered(orc_mix * m, size_t n,
+                            const uint32_t * const * values,
+                            const uint32_t * old_p, const uint32_t * new_p,
+                            int reset) {
+    unsigned saved = orc_ftz_enable();
+    for (int fi = 0; fi < m->F; ++fi) {
+        feat * f = &m->f[fi];
+        const int kind = f->sh.kind;
+        if (kind != ORC_NICH && kind != ORC_GP) continue;
+        if (reset) {
+            for (int k = 0; k < m->K; ++k) {
+                f->f0[k] = 0.f;
+                if (kind == ORC_NICH) { f->i0[k] = 0; f->f1[k] = 0.f; }
+            }
+        }
+        for (size_t i = 0; i < n; ++i) {
+            if (new_p[i] == 0xFFFFFFFFu) continue;
+            if (old_p)
+                group_apply_part(f, (int)old_p[i], values[fi][i], 0,
+                                 ORC_PART_ORDERED);
+            group_apply_part(f, (int)new_p[i], values[fi][i], 1,
+                             ORC_PART_ORDERED);
+        }
     }
     orc_ftz_restore(saved);
 }

@@ -186,6 +186,16 @@ void orc_mix_apply_moves(orc_mix * m, size_t row_begin, size_t row_end,
                          const uint32_t * const * values,
                          uint32_t * assign_global, const uint32_t * old_packed,
                          const uint32_t * new_packed);
+#define ORC_PART_SUMMED 1    /* integers that add over ranks */
+#define ORC_PART_ORDERED 2   /* NICH statistics, GP log_prod: replayed in order */
+void orc_mix_apply_moves_part(orc_mix * m, size_t row_begin, size_t row_end,
+                              const uint32_t * const * values,
+                              uint32_t * assign, const uint32_t * old_p,
+                              const uint32_t * new_p, int part);
+void orc_mix_replay_ordered(orc_mix * m, size_t n,
+                            const uint32_t * const * values,
+                            const uint32_t * old_p, const uint32_t * new_p,
+                            int reset);
 size_t orc_mix_stat_words(const orc_mix * m);
 void orc_mix_export_stats(const orc_mix * m, int32_t * words);
 void orc_mix_import_stats(orc_mix * m, const int32_t * words);

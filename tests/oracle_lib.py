@@ -293,6 +293,11 @@ def _phase_sigs(L):
                                        c_u32p, c_u32p]
     L.orc_mix_apply_moves.restype = None
     L.orc_mix_apply_moves.argtypes = [vp, sz, sz, pp, c_u32p, c_u32p, c_u32p]
+    L.orc_mix_apply_moves_part.restype = None
+    L.orc_mix_apply_moves_part.argtypes = [vp, sz, sz, pp, c_u32p, c_u32p,
+                                           c_u32p, ctypes.c_int]
+    L.orc_mix_replay_ordered.restype = None
+    L.orc_mix_replay_ordered.argtypes = [vp, sz, vp, vp, vp, ctypes.c_int]
     L.orc_mix_stat_words.restype = sz
     L.orc_mix_stat_words.argtypes = [vp]
     L.orc_mix_export_stats.restype = None
@@ -355,10 +360,44 @@ class OracleBackend(object):
 
     def batch_delta_dev(self, ptr):
         before = self._snapshot()
-        self.batch_apply_local()
+        r0, r1, old, new, _ = self._open
+        self.L.orc_mix_apply_moves_part(self.m.h, r0, r1, self.m._vals,
+                                        self.m.assign, old, new, 1)
         after = self._snapshot()
         self.L.orc_mix_import_stats(self.m.h, before)   # undo: delta only
         self._view(ptr, before.size)[:] = after - before
+
+    def feature_is_ordered(self, f):
+        return self.m.shareds[f].kind in (GP, NICH)
+
+    def ordered_features(self):
+        return sum(self.feature_is_ordered(f)
+                   for f in range(len(self.m.shareds)))
+
+    def batch_moves_dev(self, old_ptr, new_ptr):
+        r0, r1, old, new, _ = self._open
+        n = r1 - r0
+        self._view(old_ptr, n)[:] = old[:n].view(np.int32)
+        self._view(new_ptr, n)[:] = new[:n].view(np.int32)
+
+    def replay_ordered_dev(self, old_ptr, new_ptr, value_ptrs, n, reset):
+        F = len(value_ptrs)
+        keep = []
+        arr = (ctypes.POINTER(ctypes.c_uint32) * F)()
+        for f, ptr in enumerate(value_ptrs):
+            if ptr:
+                v = np.ascontiguousarray(self._view(ptr, n).view(np.uint32))
+                keep.append(v)
+                arr[f] = v.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32))
+        new = np.ascontiguousarray(self._view(new_ptr, n).view(np.uint32))
+        old = (np.ascontiguousarray(self._view(old_ptr, n).view(np.uint32))
+               if old_ptr else None)
+        self.L.orc_mix_replay_ordered(
+            self.m.h, n, ctypes.cast(arr, ctypes.c_void_p),
+            old.ctypes.data if old is not None else None,
+            new.ctypes.data, int(reset))
+        if reset:
+            self.L.orc_mix_batch_finish(self.m.h, self.m.counts())
 
     def batch_apply_delta_dev(self, ptr):
         cur = self._snapshot()

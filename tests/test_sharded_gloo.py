@@ -8,6 +8,7 @@ import socket
 import sys
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -20,38 +21,57 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 N, K, BATCH, SWEEPS, SEED = 2400, 12, 300, 2, 4242
 
 
-def make_rows():
+def make_rows(config):
+    """-> (list of value columns, packed assignment)"""
     rng = np.random.default_rng(7)
-    values = rng.integers(0, 8, N).astype(np.uint32)
     assign = (np.arange(N) % K).astype(np.uint32)
-    return values, assign
+    if config == "dd":
+        return [rng.integers(0, 8, N).astype(np.uint32)], assign
+    # order-dependent statistics: GammaPoisson (log_prod) + NormalInverseChiSq
+    return [rng.poisson(5.0, N).astype(np.uint32),
+            rng.normal(0.0, 1.0, N).astype(np.float32)], assign
 
 
-def make_mix(values, assign, lo, hi):
+def make_mix(config, values, assign, lo, hi):
     import oracle_lib as ol
-    sh = [ol.make_shared(ol.DD, alphas=[0.5] * 8)]
+    if config == "dd":
+        sh = [ol.make_shared(ol.DD, alphas=[0.5] * 8)]
+    else:
+        sh = [ol.make_shared(ol.GP, alpha=1.0, inv_beta=1.0),
+              ol.make_shared(ol.NICH, mu=0.0, kappa=1.0, sigmasq=1.0, nu=1.0)]
     m = ol.OracleMixture(3.0, 0.3, sh)
-    m.init_from_assignments([values[lo:hi]], assign[lo:hi], K, 2)
+    m.init_from_assignments([v[lo:hi] for v in values], assign[lo:hi], K, 2)
     return m
 
 
-def worker(rank, world, port, out):
+def group_words(m):
+    return np.stack([np.concatenate([m.get_group(f, g)
+                                     for f in range(len(m.shareds))])
+                     for g in range(len(m))])
+
+
+def worker(rank, world, port, out, config):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import oracle_lib as ol
     from distributions_amd import engine
-    values, assign = make_rows()
+    values, assign = make_rows(config)
     lo, hi = rank * N // world, (rank + 1) * N // world
-    m = make_mix(values, assign, lo, hi)
+    m = make_mix(config, values, assign, lo, hi)
     backend = ol.OracleBackend(m, row_offset=lo)
-    sharded = engine.ShardedGibbs(backend, hi - lo, lo, device="cpu")
+    # the oracle's value words are what a caller hands to load_rows
+    columns = [torch.from_numpy(w.view(np.int32).copy()) for w in m.values]
+    packed = torch.from_numpy(assign[lo:hi].view(np.int32).copy())
+    sharded = engine.ShardedGibbs(backend, hi - lo, lo, device="cpu",
+                                  columns=columns, assign_packed=packed)
     sharded.sync_initial_stats()
     st = ol.oracle().orc_rng_seed(SEED)
     for s in range(SWEEPS):
         sharded.sweep(BATCH // world, st, draw_base=s * N)
     np.save(os.path.join(out, "assign_%d.npy" % rank), m.assign)
     np.save(os.path.join(out, "counts_%d.npy" % rank), m.counts())
+    np.save(os.path.join(out, "groups_%d.npy" % rank), group_words(m))
     dist.destroy_process_group()
 
 
@@ -63,20 +83,23 @@ def free_port():
     return port
 
 
-def test_two_ranks_equal_one_rank_with_the_same_batches(tmp_path):
+@pytest.mark.parametrize("config", ["dd", "gp_nich"])
+def test_two_ranks_equal_one_rank_with_the_same_batches(tmp_path, config):
     import oracle_lib as ol
     world = 2
-    mp.spawn(worker, args=(world, free_port(), str(tmp_path)), nprocs=world,
-             join=True)
+    mp.spawn(worker, args=(world, free_port(), str(tmp_path), config),
+             nprocs=world, join=True)
     got = np.concatenate([np.load(tmp_path / ("assign_%d.npy" % r))
                           for r in range(world)])
     counts = [np.load(tmp_path / ("counts_%d.npy" % r)) for r in range(world)]
+    groups = [np.load(tmp_path / ("groups_%d.npy" % r)) for r in range(world)]
     assert np.array_equal(counts[0], counts[1])   # replicas agree
+    assert np.array_equal(groups[0], groups[1])   # ... bit for bit
 
     # single process, same batch composition: batch b = the union over ranks
     # of local rows [b*B/2, (b+1)*B/2) of each shard
-    values, assign = make_rows()
-    m = make_mix(values, assign, 0, N)
+    values, assign = make_rows(config)
+    m = make_mix(config, values, assign, 0, N)
     L = ol.oracle()
     ol._phase_sigs(L)
     st = L.orc_rng_seed(SEED)
@@ -98,3 +121,5 @@ def test_two_ranks_equal_one_rank_with_the_same_batches(tmp_path):
             L.orc_mix_batch_finish(m.h, np.ascontiguousarray(snap, np.int32))
     assert np.array_equal(m.counts(), counts[0])
     assert np.array_equal(got, m.assign)
+    # statistics too, the order-dependent floats included
+    assert np.array_equal(group_words(m), groups[0])
