@@ -94,6 +94,8 @@ cdef extern from "distributions_hip.h" nogil:
     int dist_mixture_score_value(const dist_mixture_t *, uint32_t, float *,
                                  size_t)
     int dist_mixture_score_data(const dist_mixture_t *, float *)
+    int dist_mixture_score_data_grid(const dist_mixture_t *,
+                                     const dist_shared_t *, size_t, float *)
 
     int dist_group_init(const dist_shared_t *, uint32_t *)
     int dist_group_add_value(const dist_shared_t *, uint32_t *, uint32_t)
@@ -544,6 +546,24 @@ cdef class SlaveMixture:
     def score_data(self):
         cdef float out = 0
         check(dist_mixture_score_data(self.ptr, &out))
+        return out
+
+    def score_data_grid(self, shareds):
+        """shareds: SharedParams candidates -> float32 scores, one each"""
+        cdef size_t n = len(shareds)
+        cdef cnp.ndarray[cnp.float32_t, ndim=1] out = np.zeros(n, np.float32)
+        if n == 0:
+            return out
+        cdef dist_shared_t * arr = <dist_shared_t *> malloc(
+            n * sizeof(dist_shared_t))
+        cdef SharedParams s
+        for i in range(n):
+            s = shareds[i]
+            arr[i] = s.c
+        cdef int rc = dist_mixture_score_data_grid(self.ptr, arr, n,
+                                                   <float *> out.data)
+        free(arr)
+        check(rc)
         return out
 
 

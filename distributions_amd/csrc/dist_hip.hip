@@ -344,6 +344,66 @@ struct Slave {
         out.download(&total, 1);
         return (float)total;
     }
+    // mixture.hpp:433-438 over MixtureSlaveDataScorerMixin::score_data_grid
+    // (mixture.hpp:238-247) / DirichletDiscrete's incremental form
+    // (dd.hpp:259-284, whose alpha_sum is carried in binary64 from one
+    // candidate to the next)
+    void score_data_grid(const dist_shared_t * shareds, size_t n,
+                         float * scores_out) const {
+        if (!n) return;
+        const size_t dimc = is_cat(sh.kind) ? (size_t)sh.dim : 0;
+        std::vector<float> cp(4 * n), cprior(std::max<size_t>(1, dimc * n)),
+            csum(n, 0.f);
+        double alpha_sum_d = 0.0;
+        for (size_t c = 0; c < n; ++c) {
+            const dist_shared_t & cs = shareds[c];
+            DIST_REQUIRE(cs.kind == sh.kind, "score_data_grid: model mismatch");
+            DIST_REQUIRE(!dimc || cs.dim == sh.dim,
+                         "score_data_grid: dim mismatch");
+            check_shared(cs);
+            for (int j = 0; j < 4; ++j) cp[4 * c + j] = cs.p[j];
+            if (sh.kind == DIST_DD) {
+                if (c == 0) {
+                    float a = 0.f;   // _init: float, index order
+                    for (int v = 0; v < sh.dim; ++v) a += cs.alphas[v];
+                    alpha_sum_d = a;
+                } else {             // _update: only the changed entries
+                    for (int v = 0; v < sh.dim; ++v)
+                        if (cs.alphas[v] != shareds[c - 1].alphas[v])
+                            alpha_sum_d += (double)cs.alphas[v]
+                                         - (double)shareds[c - 1].alphas[v];
+                }
+                csum[c] = (float)alpha_sum_d;
+                for (int v = 0; v < sh.dim; ++v)
+                    cprior[c * dimc + v] = cs.alphas[v];
+            } else if (sh.kind == DIST_DPD) {
+                csum[c] = cs.p[0];
+                for (int v = 0; v < sh.dim; ++v)   // dpd.hpp:362
+                    cprior[c * dimc + v] = cs.betas[v] * cs.p[0];
+            }
+        }
+        if (!K) {
+            for (size_t c = 0; c < n; ++c) scores_out[c] = 0.f;
+            return;
+        }
+        DeviceBuf<float> dp, dprior, dsum;
+        DeviceBuf<double> out;
+        dp.upload(cp.data(), cp.size());
+        dprior.upload(cprior.data(), cprior.size());
+        dsum.upload(csum.data(), csum.size());
+        out.reserve(n, 0);   // zero-filled
+        const size_t cells = (size_t)K * (dimc ? dimc : 1);
+        SlaveView v = view();
+        hipLaunchKernelGGL(k_score_data_grid,
+                           dim3((unsigned)((cells + kBlock - 1) / kBlock),
+                                (unsigned)n),
+                           dim3(kBlock), 0, stream(), v, dp.p, dprior.p,
+                           dsum.p, out.p);
+        HIP_CHECK(hipGetLastError());
+        std::vector<double> totals(n);
+        out.download(totals.data(), n);
+        for (size_t c = 0; c < n; ++c) scores_out[c] = (float)totals[c];
+    }
     void score_value(uint32_t value, float * acc, size_t size) const {
         DIST_REQUIRE(size == (size_t)K, "scores_accum != len(mixture)");
         check_value(value);
@@ -1692,6 +1752,11 @@ int dist_mixture_score_value(const dist_mixture_t * m, uint32_t value,
 
 int dist_mixture_score_data(const dist_mixture_t * m, float * out) {
     return guarded([&] { *out = m->impl->score_data(); });
+}
+int dist_mixture_score_data_grid(const dist_mixture_t * m,
+                                 const dist_shared_t * shareds, size_t n,
+                                 float * scores_out) {
+    return guarded([&] { m->impl->score_data_grid(shareds, n, scores_out); });
 }
 
 // ---- Model::Group (host scalars over the same inline model code) -----------

@@ -249,8 +249,9 @@ __device__ __forceinline__ void block_sum_to(double v, double * out) {
     if ((threadIdx.x & 63) == 0 && v != 0.0) atomicAdd(out, v);
 }
 
-__global__ void k_score_data(SlaveView s, double * out) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+// the terms of cell i (categorical: one (group, value); scalar: one group)
+__device__ __forceinline__ double score_data_cell(const SlaveView & s,
+                                                  size_t i) {
     double acc = 0.0;
     if (is_cat(s.kind)) {
         const size_t n = (size_t)s.K * s.dim;
@@ -273,7 +274,29 @@ __global__ void k_score_data(SlaveView s, double * out) {
                                                   load_stats(s, (int)i), t);
         for (int j = 0; j < nt; ++j) acc += (double)t[j];
     }
-    block_sum_to(acc, out);
+    return acc;
+}
+
+__global__ void k_score_data(SlaveView s, double * out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    block_sum_to(score_data_cell(s, i), out);
+}
+
+// score_data_grid (mixture.hpp:238-247, dd.hpp:259-284): blockIdx.y = the
+// candidate Shared; the groups' statistics are read once per candidate, the
+// hyper-parameters come from the candidate arrays
+__global__ void k_score_data_grid(SlaveView s, const float * __restrict__ cand_p,
+                                  const float * __restrict__ cand_prior,
+                                  const float * __restrict__ cand_alpha_sum,
+                                  double * out) {
+    const int c = blockIdx.y;
+    for (int j = 0; j < 4; ++j) s.p[j] = cand_p[4 * c + j];
+    if (is_cat(s.kind)) {
+        s.prior = cand_prior + (size_t)c * s.dim;
+        s.alpha_sum = cand_alpha_sum[c];
+    }
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    block_sum_to(score_data_cell(s, i), out + c);
 }
 
 // PitmanYor::score_counts: before[k] = (non-empty groups, rows) ahead of k

@@ -204,3 +204,11 @@ class MixtureBase(object):
 
     def score_data(self, shared):
         return self._handle(shared).score_data()
+
+    def score_data_grid(self, shareds):
+        """one score_data per candidate Shared (mixture.hpp:433-438; C++-only
+        in the reference, doc/overview.rst:143) -> float32 array"""
+        if not len(shareds):
+            return np.zeros(0, np.float32)
+        return self._handle(shareds[0]).score_data_grid(
+            [s.params for s in shareds])

@@ -162,6 +162,13 @@ int dist_mixture_score_value(const dist_mixture_t * m, uint32_t value,
 /* score_data: log marginal likelihood of all groups' data    mixture.hpp:427-431
  * (float terms of the reference, summed in binary64; 1e-5 relative) */
 int dist_mixture_score_data(const dist_mixture_t * m, float * out);
+/* score_data_grid: scores_out[i] = score_data under candidate shareds[i]
+ * (hyper-parameter grid, mixture.hpp:433-438 / 238-247; DirichletDiscrete
+ * carries alpha_sum from candidate to candidate like dd.hpp:259-284,320-344).
+ * One launch scores every (candidate, group) pair; same tolerance. */
+int dist_mixture_score_data_grid(const dist_mixture_t * m,
+                                 const dist_shared_t * shareds, size_t n,
+                                 float * scores_out);
 
 /* ---- Model::Group scalar API (host side, O(1); dd.hpp:113-199 etc.) ------ */
 int dist_group_init(const dist_shared_t * shared, uint32_t * group);

@@ -127,6 +127,25 @@ struct Model {
                                            scores_accum.data(),
                                            scores_accum.size()));
         }
+        // mixture.hpp:427-431
+        float score_data(const Shared & shared, rng_t &) {
+            float out = 0;
+            check(dist_mixture_score_data(handle(shared), &out));
+            return out;
+        }
+        // mixture.hpp:433-438: one score per candidate Shared
+        void score_data_grid(const std::vector<Shared> & shareds,
+                             VectorFloat & scores_out, rng_t &) {
+            static_assert(sizeof(Shared) == sizeof(dist_shared_t),
+                          "Shared adds no members");
+            if (shareds.size() != scores_out.size())
+                throw std::invalid_argument("shareds.size() != scores_out.size()");
+            if (shareds.empty()) return;
+            check(dist_mixture_score_data_grid(
+                handle(shareds[0]),
+                static_cast<const dist_shared_t *>(shareds.data()),
+                shareds.size(), scores_out.data()));
+        }
 
       private:
         dist_mixture_t * handle(const Shared & shared) {

@@ -952,10 +952,15 @@ float orc_group_score_data(const orc_shared * sh, const uint32_t * group) {
 /* MixtureDataScorer::score_data (dd.hpp:250-256,287-318; bb.hpp:207-229;
  * gp.hpp:220-241; nich.hpp:262-288; dpd.hpp:344-374), float accumulation in
  * the reference's loop order (DD's final vector_sum taken in index order) */
+static float slave_score_data_with(const feat * f, const orc_shared * sh,
+                                   const float * betas);
 float orc_mix_slave_score_data(const orc_mix * m, int fi) {
-    unsigned saved = orc_ftz_enable();
     const feat * f = &m->f[fi];
-    const orc_shared * sh = &f->sh;
+    return slave_score_data_with(f, &f->sh, f->betas);
+}
+static float slave_score_data_with(const feat * f, const orc_shared * sh,
+                                   const float * betas) {
+    unsigned saved = orc_ftz_enable();
     float result = 0;
     if (sh->kind == ORC_DD) {
         int dim = sh->dim;
@@ -986,9 +991,9 @@ float orc_mix_slave_score_data(const orc_mix * m, int fi) {
             for (int v = 0; v < sh->dim; ++v) {
                 int32_t c = f->cnt[(size_t)k * sh->dim + v];
                 if (!c) continue;
-                float prior_i = f->betas[v] * alpha;
+                float prior_i = betas[v] * alpha;
                 result += orc_fast_lgamma(prior_i + (float)c)
-                        - orc_fast_lgamma(alpha * f->betas[v]);
+                        - orc_fast_lgamma(alpha * betas[v]);
             }
             result += shared_total - orc_fast_lgamma(alpha + (float)f->i0[k]);
         }
@@ -1037,6 +1042,73 @@ float orc_mix_slave_score_data(const orc_mix * m, int fi) {
     }
     orc_ftz_restore(saved);
     return result;
+}
+
+/* score_data_grid (mixture.hpp:238-247: one score_data per candidate Shared;
+ * DirichletDiscrete's incremental form, dd.hpp:259-345: _init on the first
+ * candidate, then per candidate only the changed alphas are re-accumulated,
+ * alpha_sum carried in binary64; _eval's vector_sum taken in index order) */
+void orc_mix_slave_score_data_grid(const orc_mix * m, int fi,
+                                   const orc_shared * shareds, size_t n,
+                                   float * scores_out) {
+    const feat * f = &m->f[fi];
+    if (f->sh.kind != ORC_DD) {
+        for (size_t i = 0; i < n; ++i)
+            scores_out[i] = slave_score_data_with(f, &shareds[i],
+                                                  shareds[i].betas);
+        return;
+    }
+    if (!n) return;
+    unsigned saved = orc_ftz_enable();
+    const int dim = f->sh.dim;
+    float * scores = calloc(dim + 1, sizeof(float));
+    float * shared_part = calloc(dim + 1, sizeof(float));
+    /* _init(shareds[0]) */
+    float alpha_sum_f = 0;
+    for (int v = 0; v < dim; ++v) {
+        alpha_sum_f += shareds[0].alphas[v];
+        shared_part[v] = orc_fast_lgamma(shareds[0].alphas[v]);
+    }
+    double alpha_sum_d = alpha_sum_f;
+    shared_part[dim] = orc_fast_lgamma(alpha_sum_f);
+    for (int k = 0; k < f->K; ++k) {
+        if (!f->i0[k]) continue;
+        for (int v = 0; v < dim; ++v)
+            scores[v] += orc_fast_lgamma(
+                shareds[0].alphas[v] + (float)f->cnt[(size_t)k * dim + v])
+                       - shared_part[v];
+        scores[dim] += shared_part[dim]
+                     - orc_fast_lgamma(alpha_sum_f + (float)f->i0[k]);
+    }
+    float total = 0;
+    for (int v = 0; v <= dim; ++v) total += scores[v];
+    scores_out[0] = total;
+    for (size_t i = 1; i < n; ++i) {
+        for (int v = 0; v < dim; ++v) {
+            const float old_alpha = shareds[i - 1].alphas[v];
+            const float new_alpha = shareds[i].alphas[v];
+            if (new_alpha == old_alpha) continue;
+            /* _update(value, old_alpha, new_alpha) */
+            shared_part[v] = orc_fast_lgamma(new_alpha);
+            alpha_sum_d += (double)new_alpha - (double)old_alpha;
+            const float alpha_sum = (float)alpha_sum_d;
+            shared_part[dim] = orc_fast_lgamma(alpha_sum);
+            scores[v] = 0;
+            scores[dim] = 0;
+            for (int k = 0; k < f->K; ++k) {   /* empty groups included */
+                scores[v] += orc_fast_lgamma(
+                    new_alpha + (float)f->cnt[(size_t)k * dim + v])
+                           - shared_part[v];
+                scores[dim] += shared_part[dim]
+                             - orc_fast_lgamma(alpha_sum + (float)f->i0[k]);
+            }
+        }
+        total = 0;
+        for (int v = 0; v <= dim; ++v) total += scores[v];
+        scores_out[i] = total;
+    }
+    free(scores); free(shared_part);
+    orc_ftz_restore(saved);
 }
 
 /* PitmanYor::score_counts (src/clustering.cc:144-183) */

@@ -143,6 +143,9 @@ float orc_group_score_value(const orc_shared * shared, const uint32_t * group,
  * score_data, PitmanYor::score_counts (clustering.cc:152-183) */
 float orc_group_score_data(const orc_shared * shared, const uint32_t * group);
 float orc_mix_slave_score_data(const orc_mix * m, int f);
+void orc_mix_slave_score_data_grid(const orc_mix * m, int fi,
+                                   const orc_shared * shareds, size_t n,
+                                   float * scores_out);
 float orc_py_score_counts(float alpha, float d, const int * counts, size_t n);
 /* PitmanYor::sample_assignments (clustering.cc:67-142) */
 void orc_py_sample_assignments(float alpha, float d, int size,

@@ -336,6 +336,77 @@ def test_mixture_score_data(module, EXAMPLE):
         check()
 
 
+def grid_candidates(module, raw):
+    """a hyper-parameter grid around an EXAMPLE's shared, as dicts; neighbours
+    differ in one or two entries (what DirichletDiscrete's incremental
+    score_data_grid exploits, dd.hpp:268-281)"""
+    import copy
+    out = [copy.deepcopy(raw)]
+    rng = np.random.default_rng(8)
+    for step in range(7):
+        d = copy.deepcopy(out[-1])
+        if 'alphas' in d:
+            for _ in range(1 + step % 2):
+                i = int(rng.integers(len(d['alphas'])))
+                d['alphas'][i] = float(d['alphas'][i]) * float(
+                    rng.uniform(0.5, 2.0))
+        else:
+            keys = [k for k in sorted(d) if isinstance(d[k], float)
+                    and k != 'beta0']
+            k = keys[step % len(keys)]
+            scale = float(rng.uniform(0.5, 2.0))
+            d[k] = d[k] * scale if k != 'mu' else d[k] + scale
+        out.append(d)
+    return out
+
+
+@pytest.mark.parametrize("module,EXAMPLE", examples())
+def test_mixture_score_data_grid(module, EXAMPLE):
+    """score_data_grid (mixture.hpp:433-438): every entry equals score_data
+    under that candidate, and the oracle's restatement of the reference's
+    loops (DirichletDiscrete's incremental one included) within 1e-5"""
+    L = ol.oracle()
+    L.orc_mix_slave_score_data_grid.restype = None
+    L.orc_mix_slave_score_data_grid.argtypes = [
+        ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t,
+        ctypes.c_void_p]
+    shared = module.Shared.from_dict(EXAMPLE['shared'])
+    values = EXAMPLE['values']
+    word = lambda v: module.Group._word(shared, v)   # noqa: E731
+    n_groups = 5
+    mixture = module.Mixture()
+    osh = oracle_twin(module, shared)
+    orc = ol.OracleMixture(1.0, 0.0, [osh])
+    for g in range(n_groups):
+        mixture.append(module.Group.from_values(shared, []))
+        L.orc_mix_slave_append_empty(orc.h, 0)
+    mixture.init(shared)
+    L.orc_mix_slave_init(orc.h, 0)
+    for i, value in enumerate(values * 3):
+        g = (5 * i + 2) % (n_groups - 1)        # the last group stays empty
+        mixture.add_value(shared, g, value)
+        L.orc_mix_slave_add_value(orc.h, 0, g, word(value))
+    cands = [module.Shared.from_dict(d)
+             for d in grid_candidates(module, shared.dump())]
+    got = mixture.score_data_grid(cands)
+    assert got.shape == (len(cands),) and got.dtype == np.float32
+    twins = [oracle_twin(module, c) for c in cands]
+    arr = (ol.Shared * len(twins))(*twins)
+    want = np.zeros(len(twins), np.float32)
+    L.orc_mix_slave_score_data_grid(orc.h, 0, ctypes.cast(arr, ctypes.c_void_p),
+                                    len(twins), want.ctypes.data)
+    for c, cand in enumerate(cands):
+        single = module.Mixture()
+        for g in range(n_groups):
+            single.append(mixture[g])
+        single.init(cand)
+        assert abs(got[c] - single.score_data(cand)) <= 1e-6 * (
+            1 + abs(got[c])), c
+        assert abs(got[c] - want[c]) <= 1e-5 * (1 + abs(want[c])), (
+            c, got[c], want[c])
+    assert len(set(np.round(got, 3))) > 1      # the grid does vary the score
+
+
 def test_py_score_counts_and_mixture_score_data():
     from distributions_amd.lp.clustering import PitmanYor
     L = ol.oracle()
