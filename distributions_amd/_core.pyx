@@ -8,7 +8,7 @@ arithmetic of its own: every score, cache entry and sample comes from the HIP
 library.  Errors of the library surface as RuntimeError, like the reference's
 `except +` translation of std::runtime_error.
 """
-from libc.stdint cimport uint32_t, uint64_t, int32_t
+from libc.stdint cimport uint8_t, uint32_t, uint64_t, int32_t
 from libc.stddef cimport size_t
 from libc.string cimport memset, memcpy
 from libc.stdlib cimport malloc, free
@@ -103,6 +103,14 @@ cdef extern from "distributions_hip.h" nogil:
     int dist_group_score_value(const dist_shared_t *, const uint32_t *,
                                uint32_t, float *)
     int dist_group_score_data(const dist_shared_t *, const uint32_t *, float *)
+    int dist_group_protobuf_dump(const dist_shared_t *, const uint32_t *,
+                                 const uint32_t *, uint8_t *, size_t, size_t *)
+    int dist_group_protobuf_load(const dist_shared_t *, const uint32_t *,
+                                 const uint8_t *, size_t, uint32_t *)
+    int dist_shared_protobuf_dump(const dist_shared_t *, uint8_t *, size_t,
+                                  size_t *)
+    int dist_shared_protobuf_load(int, const uint8_t *, size_t,
+                                  dist_shared_t *)
 
     ctypedef struct dist_id_tracker_t:
         pass
@@ -275,6 +283,52 @@ cdef class SharedParams:
         cdef float out = 0
         check(dist_group_score_data(&self.c, <const uint32_t *> g.data, &out))
         return out
+
+    # protobuf wire bytes (schema.proto messages) without libprotobuf
+    def group_protobuf_dump(self, cnp.ndarray[cnp.uint32_t, ndim=1] g,
+                            keys=None):
+        cdef cnp.ndarray[cnp.uint32_t, ndim=1] k
+        cdef const uint32_t * kp = NULL
+        if keys is not None:
+            k = np.ascontiguousarray(keys, np.uint32)
+            kp = <const uint32_t *> k.data
+        cdef size_t n = 0
+        check(dist_group_protobuf_dump(&self.c, <const uint32_t *> g.data, kp,
+                                       NULL, 0, &n))
+        cdef cnp.ndarray[cnp.uint8_t, ndim=1] buf = np.zeros(max(n, 1),
+                                                            np.uint8)
+        check(dist_group_protobuf_dump(&self.c, <const uint32_t *> g.data, kp,
+                                       <uint8_t *> buf.data, n, &n))
+        return buf[:n].tobytes()
+
+    def group_protobuf_load(self, bytes data, keys=None):
+        cdef cnp.ndarray[cnp.uint32_t, ndim=1] k
+        cdef const uint32_t * kp = NULL
+        if keys is not None:
+            k = np.ascontiguousarray(keys, np.uint32)
+            kp = <const uint32_t *> k.data
+        cdef cnp.ndarray[cnp.uint32_t, ndim=1] g = np.zeros(
+            self.group_words(), np.uint32)
+        cdef const unsigned char * d = data
+        check(dist_group_protobuf_load(&self.c, kp, <const uint8_t *> d,
+                                       len(data), <uint32_t *> g.data))
+        return g
+
+    def protobuf_dump(self):
+        cdef size_t n = 0
+        check(dist_shared_protobuf_dump(&self.c, NULL, 0, &n))
+        cdef cnp.ndarray[cnp.uint8_t, ndim=1] buf = np.zeros(max(n, 1),
+                                                            np.uint8)
+        check(dist_shared_protobuf_dump(&self.c, <uint8_t *> buf.data, n, &n))
+        return buf[:n].tobytes()
+
+    @staticmethod
+    def protobuf_load(int kind, bytes data):
+        cdef SharedParams s = SharedParams()
+        cdef const unsigned char * d = data
+        check(dist_shared_protobuf_load(kind, <const uint8_t *> d, len(data),
+                                        &s.c))
+        return s
 
 
 # ---------------------------------------------------------------------------

@@ -17,7 +17,23 @@ from ... import _core
 from ..random import get_rng  # noqa: F401  (same import surface as the reference)
 
 
-class SharedBase(object):
+class ProtobufSerializable(object):
+    """distributions/mixins.py:61-72"""
+
+    @classmethod
+    def to_protobuf(cls, raw, message):
+        model = cls()
+        model.load(raw)
+        model.protobuf_dump(message)
+
+    @classmethod
+    def from_protobuf(cls, message):
+        model = cls()
+        model.protobuf_load(message)
+        return model.dump()
+
+
+class SharedBase(ProtobufSerializable):
     KIND = None
 
     def __init__(self):
@@ -78,7 +94,7 @@ def _message_set(message, name, value):
         setattr(message, name, value)
 
 
-class GroupBase(object):
+class GroupBase(ProtobufSerializable):
     """Model::Group; `words` is the statistics image the ABI uses."""
     SHARED = None
 

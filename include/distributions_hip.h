@@ -182,6 +182,27 @@ int dist_group_score_value(const dist_shared_t * shared,
 int dist_group_score_data(const dist_shared_t * shared, const uint32_t * group,
                           float * out);
 
+/* ---- protobuf wire format of Shared / Group -------------------------------
+ * The messages of distributions/io/schema.proto (package
+ * protobuf.distributions) as bytes, what Group::protobuf_dump / protobuf_load
+ * exchange through generated classes in the reference (dd.hpp:94-111,
+ * bb.hpp:84-93, gp.hpp:90-101, nich.hpp:104-115, dpd.hpp:161-180) -- here
+ * without libprotobuf.  dump: buf == NULL asks for the size (*len_out).
+ * keys (DirichletProcessDiscrete only): keys[i] = the value that dense index
+ * i stands for; NULL = identity. */
+int dist_group_protobuf_dump(const dist_shared_t * shared,
+                             const uint32_t * group, const uint32_t * keys,
+                             uint8_t * buf, size_t cap, size_t * len_out);
+int dist_group_protobuf_load(const dist_shared_t * shared,
+                             const uint32_t * keys, const uint8_t * data,
+                             size_t len, uint32_t * group_out);
+/* Shared messages of DD / BB / GP / NICH (DPD's Shared carries the
+ * stick-breaking state, which lives in the lp layer) */
+int dist_shared_protobuf_dump(const dist_shared_t * shared, uint8_t * buf,
+                              size_t cap, size_t * len_out);
+int dist_shared_protobuf_load(int kind, const uint8_t * data, size_t len,
+                              dist_shared_t * shared_out);
+
 /* ---- MixtureIdTracker (mixture.hpp:460-521) ------------------------------ */
 typedef struct dist_id_tracker dist_id_tracker_t;
 dist_id_tracker_t * dist_id_tracker_create(void);

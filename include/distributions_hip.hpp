@@ -20,6 +20,7 @@
 #include <cstdint>
 #include <cstring>
 #include <stdexcept>
+#include <string>
 #include <vector>
 
 #include "distributions_hip.h"
@@ -65,6 +66,28 @@ struct Model {
         void remove_value(const Shared & shared, const Value & value, rng_t &) {
             check(dist_group_remove_value(&shared, words.data(),
                                           detail::word(value)));
+        }
+        // the Model::Group message of schema.proto as wire bytes (what
+        // protobuf_dump/protobuf_load exchange via generated classes in the
+        // reference, dd.hpp:94-111 etc.); keys: DirichletProcessDiscrete's
+        // dense index -> value table, else nullptr
+        std::string protobuf_dump(const Shared & shared,
+                                  const uint32_t * keys = nullptr) const {
+            size_t n = 0;
+            check(dist_group_protobuf_dump(&shared, words.data(), keys,
+                                           nullptr, 0, &n));
+            std::string out(n, '\0');
+            check(dist_group_protobuf_dump(
+                &shared, words.data(), keys,
+                reinterpret_cast<uint8_t *>(&out[0]), n, &n));
+            return out;
+        }
+        void protobuf_load(const Shared & shared, const std::string & data,
+                           const uint32_t * keys = nullptr) {
+            words.assign(dist_group_words(&shared), 0);
+            check(dist_group_protobuf_load(
+                &shared, keys, reinterpret_cast<const uint8_t *>(data.data()),
+                data.size(), words.data()));
         }
         float score_value(const Shared & shared, const Value & value,
                           rng_t &) const {

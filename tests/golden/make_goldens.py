@@ -17,6 +17,11 @@ Sources of the expected outputs:
       std::uniform_real_distribution<float>, i.e. what rng_t/sample_unif01
       (random_fwd.hpp:34, random.hpp:47-50) resolve to; via
       oracle/_ref/check_libstdcxx.
+  schema_fields.json, protobuf_messages.json   the FileDescriptorProto that
+      protoc embedded in the reference's generated distributions/io/
+      schema_pb2.py (its `serialized_pb` literal): the field table of every
+      message, and sample messages serialized by classes built from THAT
+      descriptor (hex of the wire bytes).
 The fixtures are data (inputs + expected outputs); no reference source.
 """
 import ctypes
@@ -166,7 +171,98 @@ def rng_libstdcxx():
     np.savez_compressed(os.path.join(HERE, "rng_libstdcxx.npz"), **out)
 
 
+PROTOBUF_SAMPLES = [
+    ("Clustering", {"pitman_yor": {"alpha": 1.0, "d": 0.2}}),
+    ("Clustering", {"low_entropy": {"dataset_size": 123456789012}}),
+    ("BetaBernoulli.Shared", {"alpha": 0.5, "beta": 2.0}),
+    ("BetaBernoulli.Group", {"heads": 3, "tails": 70000}),
+    ("DirichletDiscrete.Shared", {"alphas": [0.5, 0.25, 4.0]}),
+    ("DirichletDiscrete.Group", {"counts": [0, 1, 300, 2 ** 33]}),
+    ("DirichletDiscrete.Group", {"counts": []}),
+    ("DirichletDiscrete.Group", {"counts": [5, 0, 17, 4000000000, 1]}),
+    ("DirichletProcessDiscrete.Shared",
+     {"gamma": 0.5, "alpha": 0.5, "values": [0, 1, 7, 300],
+      "betas": [0.25, 0.25, 0.125, 0.125], "counts": [1, 2, 4, 1]}),
+    ("DirichletProcessDiscrete.Group",
+     {"keys": [0, 7, 300], "values": [4, 1, 129]}),
+    ("GammaPoisson.Shared", {"alpha": 1.0, "inv_beta": 0.7}),
+    ("GammaPoisson.Group", {"count": 5, "sum": 31, "log_prod": 17.502307}),
+    ("BetaNegativeBinomial.Shared", {"alpha": 1.5, "beta": 2.5, "r": 9}),
+    ("BetaNegativeBinomial.Group", {"count": 4, "sum": 40}),
+    ("NormalInverseChiSq.Shared",
+     {"mu": -0.25, "kappa": 1.0, "sigmasq": 2.0, "nu": 3.5}),
+    ("NormalInverseChiSq.Group",
+     {"count": 3, "mean": 0.5, "count_times_variance": 2.0}),
+]
+
+
+def protobuf_schema():
+    """field table + sample wire bytes from the reference's own descriptor"""
+    import ast
+    import json
+    import re
+    from google.protobuf import (descriptor_pb2, descriptor_pool,
+                                 message_factory)
+    src = open("/root/reference/distributions/io/schema_pb2.py",
+               encoding="latin-1").read()
+    literal = re.search(r"serialized_pb='((?:[^'\\]|\\.)*)'", src).group(1)
+    raw = ast.literal_eval("b'" + literal + "'")
+    fdp = descriptor_pb2.FileDescriptorProto()
+    fdp.ParseFromString(raw)
+    F = descriptor_pb2.FieldDescriptorProto
+    type_names = {F.TYPE_FLOAT: "float", F.TYPE_UINT64: "uint64",
+                  F.TYPE_UINT32: "uint32", F.TYPE_INT32: "int32"}
+    label_names = {F.LABEL_REQUIRED: "required", F.LABEL_OPTIONAL: "optional",
+                   F.LABEL_REPEATED: "repeated"}
+    table = {}
+
+    def walk(prefix, msg):
+        full = prefix + msg.name
+        if msg.field:
+            table[full] = [
+                [label_names[f.label],
+                 type_names.get(f.type) or f.type_name.split(".")[-1],
+                 f.name, f.number, bool(f.options.packed)]
+                for f in msg.field]
+        for nested in msg.nested_type:
+            walk(full + ".", nested)
+
+    for msg in fdp.message_type:
+        walk("", msg)
+    with open(os.path.join(HERE, "schema_fields.json"), "w") as f:
+        json.dump({"package": fdp.package, "messages": table}, f, indent=1,
+                  sort_keys=True)
+
+    pool = descriptor_pool.DescriptorPool()
+    pool.Add(fdp)
+
+    def fill(message, content):
+        for name, value in content.items():
+            if isinstance(value, dict):
+                fill(getattr(message, name), value)
+            elif isinstance(value, list):
+                getattr(message, name).extend(value)
+            else:
+                setattr(message, name, value)
+
+    samples = []
+    for full, content in PROTOBUF_SAMPLES:
+        cls = message_factory.GetMessageClass(
+            pool.FindMessageTypeByName(fdp.package + "." + full))
+        message = cls()
+        fill(message, content)
+        samples.append({"message": full, "content": content,
+                        "hex": message.SerializeToString().hex()})
+    with open(os.path.join(HERE, "protobuf_messages.json"), "w") as f:
+        json.dump(samples, f, indent=1)
+    print("schema_fields.json: %d messages; protobuf_messages.json: %d samples"
+          % (len(table), len(samples)))
+
+
 if __name__ == "__main__":
+    protobuf_schema()
+    if "--schema-only" in sys.argv:
+        sys.exit(0)
     R = ol.ref()
     assert R is not None, "build oracle/_ref first (make -C oracle ref)"
     special(R)
