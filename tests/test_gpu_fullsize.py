@@ -113,3 +113,25 @@ def test_full_size_sweep(config, dim, first, batch, kinds):
     again.sweep(first, N, batch, seed, draw_base=0)
     np.testing.assert_array_equal(again.assignments(), final)
     np.testing.assert_array_equal(again.counts(), gpu.counts())
+
+
+def test_c5_shape_dpd_8192_groups_streamed_tables():
+    """BASELINE configs[4]'s shape -- DirichletProcessDiscrete over V = 10 000
+    values with K = 8192 groups, likelihood tables (V*K*4 B = 328 MB) streamed
+    from HBM by the vector-load form of the value-sorted kernel -- on as many
+    rows as the oracle follows in seconds: bit-exact."""
+    from distributions_amd import engine
+    n, k, dim = 120_000, 8192, 10_000
+    osh, gsh, vals, assign = workloads.make("dpd", n, k, dim=dim)
+    orc = ol.OracleMixture(0.5, 0.1, osh)
+    orc.init_from_assignments(vals, assign, k, 1)
+    gpu = engine.Gibbs(0.5, 0.1, gsh)
+    gpu.set_option("value_sorted", 2)
+    gpu.load_rows(vals, assign, k, 1)
+    seed = 77
+    st = ol.oracle().orc_rng_seed(seed)
+    for b in range(0, n, 60_000):
+        orc.gibbs_batch(b, b + 60_000, st, 0)
+    gpu.sweep(0, n, 60_000, seed, draw_base=0)
+    assert tuple(gpu.path_counts()) == (2, 0)   # value-sorted, generic
+    assert_same_state(orc, gpu, "dpd V=10000 K=8192")
