@@ -25,6 +25,7 @@ cdef extern from "distributions_hip.h" nogil:
         DIST_GP
         DIST_NICH
         DIST_DPD
+        DIST_BNB
     ctypedef struct dist_shared_t:
         int kind
         int dim
@@ -173,6 +174,7 @@ KIND_BB = DIST_BB
 KIND_GP = DIST_GP
 KIND_NICH = DIST_NICH
 KIND_DPD = DIST_DPD
+KIND_BNB = DIST_BNB
 DPD_OTHER = 0xFFFFFFFF
 
 

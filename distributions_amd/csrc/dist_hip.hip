@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cstring>
 #include <memory>
+#include <map>
 #include <mutex>
 #include <set>
 
@@ -26,6 +27,7 @@ void sort_pairs(void * temp, size_t temp_bytes, const uint32_t * keys_in,
                 uint32_t * vals_out, size_t n, int bits, hipStream_t stream);
 
 __device__ Tables g_tables_dev;
+__device__ LgammaLut g_lgamma_lut;
 static Tables g_tables_host_storage;
 const Tables * g_tables_host = nullptr;
 
@@ -74,6 +76,36 @@ void ensure_device_ready() {
 
 hipStream_t stream() { return nullptr; }   // the per-thread default stream
 
+// (y, glibc lgammaf(y)) pairs for the current device's table, sorted by y
+static std::map<int, std::map<float, float>> g_lgamma_registered;
+// Adds the arguments below 2.5 among `ys` to the device's table (see
+// special.h: the reference evaluates libm's lgammaf there).
+static void register_small_lgamma(const std::vector<float> & ys) {
+    std::lock_guard<std::mutex> lock(g_init_mutex);
+    int dev = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    std::map<float, float> & table = g_lgamma_registered[dev];
+    bool grew = false;
+    for (float y : ys) {
+        if (!(y > 0.f && y < 2.5f) || table.count(y)) continue;
+        if ((int)table.size() >= kLgammaLutCap) break;
+        table[y] = ::lgammaf(y);
+        grew = true;
+    }
+    if (!grew) return;
+    static LgammaLut staging;
+    staging.n = 0;
+    for (auto & kv : table) {
+        staging.y[staging.n] = kv.first;
+        staging.v[staging.n] = kv.second;
+        staging.n += 1;
+    }
+    HIP_CHECK(hipDeviceSynchronize());   // no kernel may be reading the table
+    HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_lgamma_lut), &staging,
+                                sizeof(LgammaLut)));
+    HIP_CHECK(hipDeviceSynchronize());
+}
+
 static inline dim3 grid_for(size_t n, int block = kBlock) {
     return dim3((unsigned)std::max<size_t>(1, (n + block - 1) / block));
 }
@@ -94,11 +126,14 @@ static void sync() { HIP_CHECK(hipStreamSynchronize(stream())); }
 
 static size_t group_words(const dist_shared_t & sh) {
     return is_cat(sh.kind) ? 1 + (size_t)sh.dim
-                           : (sh.kind == DIST_BB ? 2 : 3);
+           : (sh.kind == DIST_BB || sh.kind == DIST_BNB ? 2 : 3);
 }
 
 static void check_shared(const dist_shared_t & sh) {
-    DIST_REQUIRE(sh.kind >= DIST_DD && sh.kind <= DIST_DPD, "bad model kind");
+    DIST_REQUIRE(sh.kind >= DIST_DD && sh.kind <= DIST_BNB, "bad model kind");
+    if (sh.kind == DIST_BNB)
+        DIST_REQUIRE(sh.p[2] >= 1.f && sh.p[2] == (float)(uint32_t)sh.p[2],
+                     "BetaNegativeBinomial: r must be a positive integer");
     if (sh.kind == DIST_DD)
         DIST_REQUIRE(sh.dim >= 1 && sh.dim <= DIST_DD_MAX_DIM,
                      "expected 1 <= dim <= 256");
@@ -144,6 +179,32 @@ struct Slave {
                     gp_lut[6 + n] = ::lgammaf(y);
                     n += 1;
                 }
+        }
+        if (sh.kind == DIST_BNB) {
+            // every argument below 2.5 that Scorer::init / eval can hand to
+            // fast_lgamma (bnb.hpp:200-223): post.alpha = alpha + r*n,
+            // post.beta = beta + s, their sum, post.alpha + r, post.beta + x
+            // and its sum with (post.alpha + r), for n, s, x <= 2
+            std::vector<float> ys;
+            const float r = sh.p[2];
+            for (int n = 0; n <= 2; ++n) {
+                const float pa = sh.p[0] + r * (float)n;
+                const float a2 = pa + r;
+                ys.push_back(pa);
+                ys.push_back(a2);
+                for (int s = 0; s <= 2; ++s) {
+                    const float pb = sh.p[1] + (float)s;
+                    ys.push_back(pb);
+                    ys.push_back(pa + pb);
+                    for (int x = 0; x <= 2; ++x) {
+                        const float b2 = pb + (float)x;
+                        ys.push_back(b2);
+                        ys.push_back(b2 + a2);
+                    }
+                }
+            }
+            ys.push_back(sh.p[0] + sh.p[1]);
+            register_small_lgamma(ys);
         }
         if (sh.kind == DIST_DD) {
             // dd.hpp:403-406: alpha_sum_ accumulates in index order
@@ -243,6 +304,7 @@ struct Slave {
                                      hipMemcpyHostToDevice, stream()));
             break;
         case DIST_BB:
+        case DIST_BNB:
             b = (int32_t)g[1];
             break;
         case DIST_GP:
@@ -279,6 +341,7 @@ struct Slave {
                                 hipMemcpyDeviceToHost));
             break;
         case DIST_BB:
+        case DIST_BNB:
             out[1] = (uint32_t)b;
             break;
         case DIST_GP:
@@ -795,7 +858,8 @@ struct Gibbs {
         max_value.assign((size_t)F(), 0);
         vs_cache.clear();
         for (int f = 0; f < F(); ++f) {
-            if (feats[f]->sh.kind != DIST_GP || !n) continue;
+            const int kind = feats[f]->sh.kind;
+            if ((kind != DIST_GP && kind != DIST_BNB) || !n) continue;
             DeviceBuf<uint32_t> mx;
             mx.reserve(1, 0);
             LAUNCH(k_max_value, n, values[f], n, mx.p);
@@ -842,6 +906,7 @@ struct Gibbs {
         if (F() == 1 && k0 == DIST_BB) return fn.template run<DIST_BB, -1, 1>();
         if (F() == 1 && k0 == DIST_GP) return fn.template run<DIST_GP, -1, 1>();
         if (F() == 1 && k0 == DIST_NICH) return fn.template run<DIST_NICH, -1, 1>();
+        if (F() == 1 && k0 == DIST_BNB) return fn.template run<DIST_BNB, -1, 1>();
         if (F() == 2 && k0 == DIST_GP && k1 == DIST_NICH)
             return fn.template run<DIST_GP, DIST_NICH, 2>();
         return fn.template run<-1, -1, 0>();
@@ -911,7 +976,8 @@ struct Gibbs {
     int vs_nvals() const {
         const dist_shared_t & sh = feats[0]->sh;
         if (sh.kind == DIST_BB) return 2;
-        if (sh.kind == DIST_GP)   // counts beyond the table: generic kernel
+        if (sh.kind == DIST_GP || sh.kind == DIST_BNB)
+            // counts beyond the table: generic kernel
             return (int)std::min<uint32_t>(max_value[0] + 1, 256);
         return sh.dim;
     }
@@ -919,7 +985,7 @@ struct Gibbs {
         if (value_sorted_mode == 0 || F() != 1) return false;
         const int kind = feats[0]->sh.kind;
         if (kind != DIST_DD && kind != DIST_DPD && kind != DIST_BB
-            && kind != DIST_GP)
+            && kind != DIST_GP && kind != DIST_BNB)
             return false;
         if (value_sorted_mode == 2) return true;
         return rows >= (size_t)16 * vs_nvals() && rows >= 4096;
@@ -1044,6 +1110,7 @@ struct Gibbs {
         case DIST_DD: L.go<DIST_DD>(); break;
         case DIST_DPD: L.go<DIST_DPD>(); break;
         case DIST_GP: L.go<DIST_GP>(); break;
+        case DIST_BNB: L.go<DIST_BNB>(); break;
         default: L.go<DIST_BB>(); break;
         }
         // the handed-over rows, by the generic kernel in list mode
@@ -1229,6 +1296,7 @@ struct Gibbs {
             const bool sort = lds_sort <= 60 * 1024;
             const bool bb = feats[0]->sh.kind == DIST_BB;
             const bool gp = feats[0]->sh.kind == DIST_GP;
+            const bool bnb = feats[0]->sh.kind == DIST_BNB;
             const dim3 grid(c.n_chunks), block(kBlock);
             // float statistics replay in ROW order: un-sort the moves first
             // (before the kernel below permutes sorted_rows)
@@ -1250,6 +1318,8 @@ struct Gibbs {
             else if (bb) VS_APPLY(DIST_BB, false, lds_plain);
             else if (gp && sort) VS_APPLY(DIST_GP, true, lds_sort);
             else if (gp) VS_APPLY(DIST_GP, false, lds_plain);
+            else if (bnb && sort) VS_APPLY(DIST_BNB, true, lds_sort);
+            else if (bnb) VS_APPLY(DIST_BNB, false, lds_plain);
             else if (sort) VS_APPLY(DIST_DD, true, lds_sort);
             else VS_APPLY(DIST_DD, false, lds_plain);
 #undef VS_APPLY
@@ -1769,7 +1839,7 @@ int dist_group_init(const dist_shared_t * shared, uint32_t * group) {
 static Stats group_to_stats(const dist_shared_t & sh, const uint32_t * g) {
     Stats st = {0, 0, 0.f, 0.f};
     st.i0 = (int32_t)g[0];
-    if (sh.kind == DIST_BB) st.i1 = (int32_t)g[1];
+    if (sh.kind == DIST_BB || sh.kind == DIST_BNB) st.i1 = (int32_t)g[1];
     if (sh.kind == DIST_GP) { st.i1 = (int32_t)g[1]; st.f0 = u2f(g[2]); }
     if (sh.kind == DIST_NICH) { st.f0 = u2f(g[1]); st.f1 = u2f(g[2]); }
     return st;
@@ -1777,7 +1847,7 @@ static Stats group_to_stats(const dist_shared_t & sh, const uint32_t * g) {
 static void stats_to_group(const dist_shared_t & sh, const Stats & st,
                            uint32_t * g) {
     g[0] = (uint32_t)st.i0;
-    if (sh.kind == DIST_BB) g[1] = (uint32_t)st.i1;
+    if (sh.kind == DIST_BB || sh.kind == DIST_BNB) g[1] = (uint32_t)st.i1;
     if (sh.kind == DIST_GP) { g[1] = (uint32_t)st.i1; g[2] = f2u(st.f0); }
     if (sh.kind == DIST_NICH) { g[1] = f2u(st.f0); g[2] = f2u(st.f1); }
 }

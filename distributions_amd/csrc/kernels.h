@@ -810,7 +810,7 @@ __device__ __forceinline__ float vs_own_score(const SweepParams & P,
 __device__ __forceinline__ bool vs_group_has_value(const SlaveView & v, int g,
                                                    uint32_t x) {
     if (is_cat(v.kind)) return v.cnt[(size_t)g * v.dim + x] >= 1;
-    if (v.kind == DIST_GP)
+    if (v.kind == DIST_GP || v.kind == DIST_BNB)
         return (uint32_t)v.i0[g] >= 1u && (uint32_t)v.i1[g] >= x;
     return (x ? v.i0[g] : v.i1[g]) >= 1;   // BB: heads / tails
 }
@@ -1142,7 +1142,7 @@ __global__ __launch_bounds__(kBlock) void k_vs_apply(
         atomicAdd(&img.counts[k], dlt);
         if (KIND == DIST_BB) {
             atomicAdd(x ? &img.i0[0][k] : &img.i1[0][k], dlt);
-        } else if (KIND == DIST_GP) {
+        } else if (KIND == DIST_GP || KIND == DIST_BNB) {
             atomicAdd(&img.i0[0][k], dlt);                    // count
             atomicAdd(&img.i1[0][k], dlt * (int32_t)x);       // sum
         } else {
@@ -1295,6 +1295,7 @@ __global__ void k_apply_moves(SweepParams P, StatImage img,
             atomicAdd(x ? &img.i0[f][gn] : &img.i1[f][gn], 1);
             break;
         case DIST_GP:
+        case DIST_BNB:
             atomicAdd(&img.i0[f][go], -1);
             atomicAdd(&img.i0[f][gn], 1);
             atomicAdd(&img.i1[f][go], -(int32_t)x);
@@ -1439,6 +1440,7 @@ __global__ void k_load_counts(SweepParams P, StatImage img,
             atomicAdd(x ? &img.i0[f][g] : &img.i1[f][g], 1);
             break;
         case DIST_GP:
+        case DIST_BNB:
             atomicAdd(&img.i0[f][g], 1);
             atomicAdd(&img.i1[f][g], (int32_t)x);
             break;

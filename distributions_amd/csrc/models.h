@@ -77,6 +77,10 @@ DIST_HD void stats_add(int kind, Stats & s, uint32_t value) {
         s.i1 = (int32_t)((uint32_t)s.i1 + value);
         s.f0 += fast_log_factorial(value);
         break;
+    case DIST_BNB:   // bnb.hpp:106-112
+        s.i0 = (int32_t)((uint32_t)s.i0 + 1u);
+        s.i1 = (int32_t)((uint32_t)s.i1 + value);
+        break;
     default: {  // DIST_NICH
         const float x = u2f(value);
         s.i0 += 1;
@@ -102,6 +106,10 @@ DIST_HD void stats_remove(int kind, Stats & s, uint32_t value) {
         s.i0 = (int32_t)((uint32_t)s.i0 - 1u);
         s.i1 = (int32_t)((uint32_t)s.i1 - value);
         s.f0 -= fast_log_factorial(value);
+        break;
+    case DIST_BNB:   // bnb.hpp:124-130
+        s.i0 = (int32_t)((uint32_t)s.i0 - 1u);
+        s.i1 = (int32_t)((uint32_t)s.i1 - value);
         break;
     default: {  // DIST_NICH
         const float x = u2f(value);
@@ -163,6 +171,17 @@ DIST_HD Entry scorer_init(int kind, const float * p, const Stats & s) {
         e.c2 = score_coeff;
         break;
     }
+    case DIST_BNB: {   // bnb.hpp:55-61 (plus_group), 200-215 (Scorer::init)
+        const float r = p[2];
+        const float post_alpha = p[0] + r * (float)(uint32_t)s.i0;
+        const float post_beta = p[1] + (float)(uint32_t)s.i1;
+        const float alpha = post_alpha + r;
+        e.c0 = fast_lgamma(post_alpha + post_beta) - fast_lgamma(post_alpha)
+             - fast_lgamma(post_beta) + fast_lgamma(alpha);
+        e.c1 = post_beta;
+        e.c2 = alpha;
+        break;
+    }
     case DIST_NICH: {
         const float mu = p[0], kappa = p[1], sigmasq = p[2], nu = p[3];
         const float count = (float)s.i0, mean = s.f0, ctv = s.f1;
@@ -207,6 +226,10 @@ DIST_HD float accumulate(int kind, float acc, const Entry & e, uint32_t value,
         const float fv = (float)value;
         return acc + (e.c0 + gp_lgamma(e.c1 + fv, p) - lf + e.c2 * fv);
     }
+    case DIST_BNB: {   // bnb.hpp:316-327
+        const float beta = e.c1 + (float)value;
+        return acc + (e.c0 + fast_lgamma(beta) - fast_lgamma(beta + e.c2));
+    }
     default: {  // DIST_NICH
         const float x = u2f(value);
         const float d = x - e.c3;
@@ -229,6 +252,10 @@ DIST_HD float score_group(int kind, const Entry & e, uint32_t value, float lf,
     case DIST_GP: {
         const float fv = (float)value;
         return e.c0 + gp_lgamma(e.c1 + fv, p) - lf + e.c2 * fv;
+    }
+    case DIST_BNB: {   // bnb.hpp:304-314
+        const float beta = e.c1 + (float)value;
+        return e.c0 + fast_lgamma(beta) - fast_lgamma(beta + e.c2);
     }
     default: {
         const float x = u2f(value);
@@ -338,6 +365,14 @@ DIST_HD float scalar_group_score_data(int kind, const float * p,
         score += fast_lgamma(p[0] + p[1]) - fast_lgamma(alpha + beta);
         return score;
     }
+    case DIST_BNB: {   // bnb.hpp:157-166
+        const float pa = p[0] + p[2] * (float)(uint32_t)s.i0;
+        const float pb = p[1] + (float)(uint32_t)s.i1;
+        float score = fast_lgamma(p[0] + p[1]) - fast_lgamma(pa + pb);
+        score += fast_lgamma(pa) - fast_lgamma(p[0]);
+        score += fast_lgamma(pb) - fast_lgamma(p[1]);
+        return score;
+    }
     case DIST_GP: {
         const float post_alpha = p[0] + (float)(uint32_t)s.i1;
         const float post_inv_beta = p[1] + (float)(uint32_t)s.i0;
@@ -375,6 +410,16 @@ DIST_HD int scalar_mixture_score_terms(int kind, const float * p,
             + fast_lgamma(alpha) + fast_lgamma(beta) - fast_lgamma(alpha + beta);
         t[0] = shared_part + group_part;
         return 1;
+    }
+    case DIST_BNB: {   // bnb.hpp:226-245
+        if (s.i0 == 0) return 0;
+        const float shared_part =
+            fast_lgamma(p[0] + p[1]) - fast_lgamma(p[0]) - fast_lgamma(p[1]);
+        const float pa = p[0] + p[2] * (float)(uint32_t)s.i0;
+        const float pb = p[1] + (float)(uint32_t)s.i1;
+        t[0] = fast_lgamma(pa) + fast_lgamma(pb) - fast_lgamma(pa + pb);
+        t[1] = shared_part;
+        return 2;
     }
     case DIST_GP: {
         if (s.i0 == 0) return 0;

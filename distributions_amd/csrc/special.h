@@ -36,6 +36,19 @@ struct Tables {
 extern __device__ Tables g_tables_dev;   // defined in kernels.hip
 extern const Tables * g_tables_host;     // host copy
 
+// glibc lgammaf values for the few arguments below 2.5 that a model can
+// reach (special.hpp:121-123 calls libm there): lgammaf is a pure function,
+// so one table of (y, lgammaf(y)) pairs, sorted by y, serves every feature
+// on the device.  The host registers a model's reachable arguments when the
+// feature is created (register_small_lgamma, dist_hip.hip).
+constexpr int kLgammaLutCap = 2048;
+struct LgammaLut {
+    int n;
+    float y[kLgammaLutCap];
+    float v[kLgammaLutCap];
+};
+extern __device__ LgammaLut g_lgamma_lut;
+
 DIST_HD float u2f(uint32_t u) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return __uint_as_float(u);
@@ -115,6 +128,14 @@ DIST_HD float fast_exp_nonpos(float x, const uint32_t * exp_table, float a,
 // glibc elsewhere (DESIGN.md "Known numeric gaps").
 DIST_HD float libm_lgammaf(float y) {
 #if defined(__HIP_DEVICE_COMPILE__)
+    // registered arguments: glibc's value, bit for bit
+    int lo = 0, hi = g_lgamma_lut.n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (g_lgamma_lut.y[mid] < y) lo = mid + 1; else hi = mid;
+    }
+    if (lo < g_lgamma_lut.n && g_lgamma_lut.y[lo] == y)
+        return g_lgamma_lut.v[lo];
     return (float)::lgamma((double)y);
 #else
     return ::lgammaf(y);   // host side: the very libm call of the reference

@@ -130,6 +130,7 @@ int dist_group_protobuf_dump(const dist_shared_t * shared,
                 if (group[1 + v]) w.field_varint(2, group[1 + v]);
             break;
         case DIST_BB:     // BetaBernoulli.Group: heads = 1, tails = 2
+        case DIST_BNB:    // BetaNegativeBinomial.Group: count = 1, sum = 2
             w.field_varint(1, group[0]);
             w.field_varint(2, group[1]);
             break;
@@ -223,6 +224,11 @@ int dist_shared_protobuf_dump(const dist_shared_t * shared, uint8_t * buf,
         case DIST_NICH:   // mu = 1, kappa = 2, sigmasq = 3, nu = 4
             for (int i = 0; i < 4; ++i) w.field_float(1 + i, shared->p[i]);
             break;
+        case DIST_BNB:    // alpha = 1, beta = 2, uint64 r = 3
+            w.field_float(1, shared->p[0]);
+            w.field_float(2, shared->p[1]);
+            w.field_varint(3, (uint64_t)shared->p[2]);
+            break;
         default:
             throw Error("ERROR Shared message of this model carries state the "
                         "dense remap does not hold (use the lp layer)");
@@ -235,12 +241,15 @@ int dist_shared_protobuf_load(int kind, const uint8_t * data, size_t len,
                               dist_shared_t * shared_out) {
     return dist::guarded([&] {
         DIST_REQUIRE(kind == DIST_DD || kind == DIST_BB || kind == DIST_GP
-                         || kind == DIST_NICH,
+                         || kind == DIST_NICH || kind == DIST_BNB,
                      "Shared message of this model is not supported here");
         memset(shared_out, 0, sizeof(*shared_out));
         shared_out->kind = kind;
-        parse(data, len, 0x1eu,
-              [&](int, uint64_t) {},
+        parse(data, len, kind == DIST_BNB ? 0x6u : 0x1eu,
+              [&](int number, uint64_t v) {
+                  if (kind == DIST_BNB && number == 3)
+                      shared_out->p[2] = (float)v;
+              },
               [&](int number, float f) {
                   if (kind == DIST_DD) {
                       if (number != 1) return;

@@ -12,7 +12,8 @@ import numpy as np
 from . import _core
 
 KIND = {"dd": _core.KIND_DD, "bb": _core.KIND_BB, "gp": _core.KIND_GP,
-        "nich": _core.KIND_NICH, "dpd": _core.KIND_DPD}
+        "nich": _core.KIND_NICH, "dpd": _core.KIND_DPD,
+        "bnb": _core.KIND_BNB}
 
 
 def dd_shared(alphas):
@@ -34,6 +35,12 @@ def nich_shared(mu, kappa, sigmasq, nu):
     """NormalInverseChiSq::Shared (models/nich.hpp:52-95)"""
     return _core.SharedParams.make(_core.KIND_NICH,
                                    p=(mu, kappa, sigmasq, nu))
+
+
+def bnb_shared(alpha, beta, r):
+    """BetaNegativeBinomial::Shared (models/bnb.hpp:50-84)"""
+    return _core.SharedParams.make(_core.KIND_BNB,
+                                   p=(alpha, beta, float(int(r))))
 
 
 def dpd_shared(alpha, betas, beta0=0.0):

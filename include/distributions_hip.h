@@ -38,8 +38,9 @@ enum dist_kind {
     DIST_BB = 1,   /* models/bb.hpp   BetaBernoulli                   */
     DIST_GP = 2,   /* models/gp.hpp   GammaPoisson                    */
     DIST_NICH = 3, /* models/nich.hpp NormalInverseChiSq              */
-    DIST_DPD = 4   /* models/dpd.hpp  DirichletProcessDiscrete (dense
+    DIST_DPD = 4,  /* models/dpd.hpp  DirichletProcessDiscrete (dense
                       value remap: value v in [0,dim), OTHER = 2^32-1) */
+    DIST_BNB = 5   /* models/bnb.hpp  BetaNegativeBinomial            */
 };
 
 #define DIST_DD_MAX_DIM 256
@@ -52,7 +53,8 @@ typedef struct dist_shared {
     int kind;
     int dim;             /* DD: dim; DPD: number of known values            */
     float p[4];          /* BB: alpha,beta | GP: alpha,inv_beta |
-                            NICH: mu,kappa,sigmasq,nu | DPD: alpha,beta0    */
+                            NICH: mu,kappa,sigmasq,nu | DPD: alpha,beta0 |
+                            BNB: alpha,beta,r (r a positive integer)        */
     float alphas[DIST_DD_MAX_DIM]; /* DD                                    */
     const float * betas; /* DPD: betas[dim], host pointer, copied           */
 } dist_shared_t;
@@ -61,7 +63,8 @@ typedef struct dist_shared {
  * nich.hpp:98-102, dpd.hpp:157-158):
  *   DD / DPD: { count_sum, counts[dim] }     BB:   { heads, tails }
  *   GP:       { count, sum, log_prod(f32) }  NICH: { count, mean(f32),
- *                                                    count_times_variance(f32) } */
+ *                                                    count_times_variance(f32) }
+ *   BNB:      { count, sum }                                  (bnb.hpp:87-89) */
 size_t dist_group_words(const dist_shared_t * shared);
 
 int dist_abi_version(void);

@@ -393,6 +393,10 @@ static void group_add(feat * f, int k, uint32_t value) {
         f->i1[k] = (int32_t)((uint32_t)f->i1[k] + value);
         f->f0[k] += orc_fast_log_factorial(value);
         break;
+    case ORC_BNB:   /* bnb.hpp:106-112 */
+        f->i0[k] = (int32_t)((uint32_t)f->i0[k] + 1u);
+        f->i1[k] = (int32_t)((uint32_t)f->i1[k] + value);
+        break;
     case ORC_NICH: {
         float x = u2f(value);
         f->i0[k] += 1;
@@ -420,6 +424,10 @@ static void group_remove(feat * f, int k, uint32_t value) {
         f->i0[k] = (int32_t)((uint32_t)f->i0[k] - 1u);
         f->i1[k] = (int32_t)((uint32_t)f->i1[k] - value);
         f->f0[k] -= orc_fast_log_factorial(value);
+        break;
+    case ORC_BNB:   /* bnb.hpp:124-130 */
+        f->i0[k] = (int32_t)((uint32_t)f->i0[k] - 1u);
+        f->i1[k] = (int32_t)((uint32_t)f->i1[k] - value);
         break;
     case ORC_NICH: {
         float x = u2f(value);
@@ -464,6 +472,19 @@ static scorer4 scorer_init(const orc_shared * sh, int32_t i0, int32_t i1,
              + post_alpha * (orc_fast_log(post_inv_beta) + score_coeff);
         s.c1 = post_alpha;
         s.c2 = score_coeff;
+        break;
+    }
+    case ORC_BNB: {   /* bnb.hpp:55-61 (plus_group), 200-215 (Scorer::init) */
+        float r = sh->p[2];
+        float post_alpha = sh->p[0] + r * (float)(uint32_t)i0;
+        float post_beta = sh->p[1] + (float)(uint32_t)i1;
+        float alpha = post_alpha + r;
+        s.c0 = orc_fast_lgamma(post_alpha + post_beta)
+             - orc_fast_lgamma(post_alpha)
+             - orc_fast_lgamma(post_beta)
+             + orc_fast_lgamma(alpha);
+        s.c1 = post_beta;
+        s.c2 = alpha;
         break;
     }
     case ORC_NICH: {
@@ -565,6 +586,10 @@ static inline float noncat_term(int kind, scorer4 s, uint32_t value,
         float fv = (float)value;
         return s.c0 + orc_fast_lgamma(s.c1 + fv) - log_factorial_value
              + s.c2 * fv;
+    }
+    case ORC_BNB: {   /* bnb.hpp:217-223, 316-327 */
+        float beta = s.c1 + (float)value;
+        return s.c0 + orc_fast_lgamma(beta) - orc_fast_lgamma(beta + s.c2);
     }
     default: { /* ORC_NICH */
         float x = u2f(value);
@@ -815,6 +840,7 @@ void orc_mix_slave_get_group(const orc_mix * m, int fi, int g,
         memcpy(out + 1, f->cnt + (size_t)g * f->sh.dim, 4 * f->sh.dim);
         break;
     case ORC_BB:
+    case ORC_BNB:
         out[0] = (uint32_t)f->i0[g]; out[1] = (uint32_t)f->i1[g];
         break;
     case ORC_GP:
@@ -921,6 +947,12 @@ float orc_group_score_data(const orc_shared * sh, const uint32_t * group) {
         score += orc_fast_lgamma(beta) - orc_fast_lgamma(sh->p[1]);
         score += orc_fast_lgamma(sh->p[0] + sh->p[1])
                - orc_fast_lgamma(alpha + beta);
+    } else if (sh->kind == ORC_BNB) {   /* bnb.hpp:157-166 */
+        float pa = sh->p[0] + sh->p[2] * (float)group[0];
+        float pb = sh->p[1] + (float)group[1];
+        score = orc_fast_lgamma(sh->p[0] + sh->p[1]) - orc_fast_lgamma(pa + pb);
+        score += orc_fast_lgamma(pa) - orc_fast_lgamma(sh->p[0]);
+        score += orc_fast_lgamma(pb) - orc_fast_lgamma(sh->p[1]);
     } else if (sh->kind == ORC_GP) {
         float post_alpha = sh->p[0] + (float)group[1];
         float post_inv_beta = sh->p[1] + (float)group[0];
@@ -1007,6 +1039,18 @@ static float slave_score_data_with(const feat * f, const orc_shared * sh,
             float group_part = + orc_fast_lgamma(alpha) + orc_fast_lgamma(beta)
                                - orc_fast_lgamma(alpha + beta);
             result += shared_part + group_part;
+        }
+    } else if (sh->kind == ORC_BNB) {   /* bnb.hpp:226-245 */
+        float shared_part = orc_fast_lgamma(sh->p[0] + sh->p[1])
+                          - orc_fast_lgamma(sh->p[0])
+                          - orc_fast_lgamma(sh->p[1]);
+        for (int k = 0; k < f->K; ++k) {
+            if (!f->i0[k]) continue;
+            float pa = sh->p[0] + sh->p[2] * (float)(uint32_t)f->i0[k];
+            float pb = sh->p[1] + (float)(uint32_t)f->i1[k];
+            result += orc_fast_lgamma(pa) + orc_fast_lgamma(pb)
+                    - orc_fast_lgamma(pa + pb);
+            result += shared_part;
         }
     } else if (sh->kind == ORC_GP) {
         float alpha_part = orc_fast_lgamma(sh->p[0]);

@@ -34,14 +34,16 @@
 extern "C" {
 #endif
 
-enum { ORC_DD = 0, ORC_BB = 1, ORC_GP = 2, ORC_NICH = 3, ORC_DPD = 4 };
+enum { ORC_DD = 0, ORC_BB = 1, ORC_GP = 2, ORC_NICH = 3, ORC_DPD = 4,
+       ORC_BNB = 5 };
 
 /* hyper-parameters of one feature ("Shared" of the reference models) */
 typedef struct {
     int kind;
     int dim;            /* DD: number of categories (<=256); DPD: #values   */
     float p[4];         /* BB: alpha,beta   GP: alpha,inv_beta
-                           NICH: mu,kappa,sigmasq,nu   DPD: alpha,beta0     */
+                           NICH: mu,kappa,sigmasq,nu   DPD: alpha,beta0
+                           BNB: alpha,beta,r (r integral)                   */
     float alphas[256];  /* DD alphas                                        */
     const float * betas;/* DPD: betas[dim] (dense remap: value v -> betas[v]) */
 } orc_shared;

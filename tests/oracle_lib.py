@@ -13,7 +13,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 
-DD, BB, GP, NICH, DPD = 0, 1, 2, 3, 4
+DD, BB, GP, NICH, DPD, BNB = 0, 1, 2, 3, 4, 5
 
 c_f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
 c_u32p = np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")
@@ -45,6 +45,8 @@ def make_shared(kind, **kw):
     elif kind == NICH:
         s.p[0], s.p[1], s.p[2], s.p[3] = (kw["mu"], kw["kappa"],
                                           kw["sigmasq"], kw["nu"])
+    elif kind == BNB:
+        s.p[0], s.p[1], s.p[2] = kw["alpha"], kw["beta"], float(int(kw["r"]))
     elif kind == DPD:
         betas = np.ascontiguousarray(kw["betas"], np.float32)
         s._keep = betas
@@ -277,7 +279,8 @@ class OracleMixture(object):
 
     def get_group(self, f, g):
         s = self.shareds[f]
-        n = 1 + s.dim if s.kind in (DD, DPD) else (2 if s.kind == BB else 3)
+        n = 1 + s.dim if s.kind in (DD, DPD) else (
+            2 if s.kind in (BB, BNB) else 3)
         out = np.zeros(n, np.uint32)
         self.L.orc_mix_slave_get_group(self.h, f, g, out)
         return out

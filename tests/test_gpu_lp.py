@@ -28,8 +28,8 @@ def bits(x):
 
 
 def modules():
-    from distributions_amd.lp.models import dd, bb, gp, nich, dpd
-    return [dd, bb, gp, nich, dpd]
+    from distributions_amd.lp.models import dd, bb, gp, nich, dpd, bnb
+    return [dd, bb, gp, nich, dpd, bnb]
 
 
 def examples():
@@ -53,6 +53,8 @@ def oracle_twin(module, shared):
     if kind == ol.NICH:
         return ol.make_shared(ol.NICH, mu=p.p[0], kappa=p.p[1],
                               sigmasq=p.p[2], nu=p.p[3])
+    if kind == ol.BNB:
+        return ol.make_shared(ol.BNB, alpha=p.p[0], beta=p.p[1], r=p.p[2])
     return ol.make_shared(ol.DPD, alpha=p.p[0], beta0=p.p[1], betas=p.betas)
 
 

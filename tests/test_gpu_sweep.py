@@ -10,7 +10,7 @@ import workloads
 pytestmark = pytest.mark.gpu
 
 
-VS_ELIGIBLE = ("dd", "dd_skew", "bb", "dpd", "dpd_other", "gp")
+VS_ELIGIBLE = ("dd", "dd_skew", "bb", "dpd", "dpd_other", "gp", "bnb")
 
 
 def both(config, n, k, alpha, d, empty=1, dim=None, seed=workloads.SEED,
@@ -43,7 +43,7 @@ def assert_same_state(orc, gpu, what=""):
 
 
 CONFIGS = ["dd", "dd_skew", "bb", "gp", "nich", "gp_nich", "dpd",
-           "dpd_other", "dd_bb_gp"]
+           "dpd_other", "dd_bb_gp", "bnb"]
 
 
 @pytest.mark.parametrize("config", CONFIGS)
@@ -270,3 +270,38 @@ def test_gamma_poisson_small_arguments_use_libm_values(alpha):
             orc.gibbs_batch(b, b + 200, st, sweep * n)
         gpu.sweep(0, n, 200, 11, draw_base=sweep * n)
         assert_same_state(orc, gpu, "gp alpha=%g sweep %d" % (alpha, sweep))
+
+
+@pytest.mark.parametrize("alpha,beta,r", [(0.3, 0.45, 1), (1.25, 0.2, 1),
+                                          (0.6, 1.1, 2), (1.0, 1.0, 1)])
+def test_beta_negative_binomial_small_arguments_use_libm_values(alpha, beta,
+                                                               r):
+    """BetaNegativeBinomial hands fast_lgamma arguments below 2.5 whenever a
+    group is empty or nearly so (bnb.hpp:200-223); the device must return
+    glibc's lgammaf there (the registered table of special.h), so scores and
+    assignments stay bit-exact for non-integer hyper-parameters."""
+    from distributions_amd import engine
+    rng = np.random.default_rng(5)
+    n, k = 600, 150
+    vals = [rng.integers(0, 3, n).astype(np.uint32)]
+    assign = (np.arange(n) % k).astype(np.uint32)
+    osh = [ol.make_shared(ol.BNB, alpha=alpha, beta=beta, r=r)]
+    orc = ol.OracleMixture(2.0, 0.3, osh)
+    orc.init_from_assignments(vals, assign, k, 2)
+    for mode in (0, 2):
+        gpu = engine.Gibbs(2.0, 0.3, [engine.bnb_shared(alpha, beta, r)])
+        gpu.set_option("value_sorted", mode)
+        gpu.load_rows(vals, assign, k, 2)
+        for row in [0, 7, 599]:
+            g = int(ol.oracle().orc_mix_global_to_packed(orc.h,
+                                                        int(orc.assign[row])))
+            want = orc.row_scores(row, g)
+            got = gpu.row_scores(row)
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    st = ol.oracle().orc_rng_seed(11)
+    for sweep in range(3):
+        for b in range(0, n, 200):
+            orc.gibbs_batch(b, b + 200, st, sweep * n)
+        gpu.sweep(0, n, 200, 11, draw_base=sweep * n)
+        assert_same_state(orc, gpu, "bnb %g %g %d sweep %d" % (
+            alpha, beta, r, sweep))

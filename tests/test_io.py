@@ -62,8 +62,8 @@ def test_messages_serialize_to_the_reference_bytes():
 
 
 def lp_modules():
-    from distributions_amd.lp.models import bb, dd, dpd, gp, nich
-    return [bb, dd, dpd, gp, nich]
+    from distributions_amd.lp.models import bb, bnb, dd, dpd, gp, nich
+    return [bb, bnb, dd, dpd, gp, nich]
 
 
 def assert_close(a, b):
@@ -203,6 +203,11 @@ def _kind_params(full, content):
         return _core.SharedParams.make(
             _core.KIND_GP, p=(content.get("alpha", 1.0),
                               content.get("inv_beta", 1.0))), None
+    if model == "BetaNegativeBinomial":
+        return _core.SharedParams.make(
+            _core.KIND_BNB, p=(content.get("alpha", 1.0),
+                               content.get("beta", 1.0),
+                               float(content.get("r", 1)))), None
     if model == "NormalInverseChiSq":
         return _core.SharedParams.make(
             _core.KIND_NICH, p=(content.get("mu", 0.0),
@@ -253,7 +258,7 @@ def test_c_codec_writes_and_reads_the_reference_bytes():
             fill(want, content)
             assert message == want
         checked += 1
-    assert checked >= 9
+    assert checked >= 11
 
 
 def test_c_codec_round_trips_lp_groups_through_python_protobuf():

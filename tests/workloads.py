@@ -32,6 +32,10 @@ def make(config, n, k, seed=SEED, dim=None):
         vals = [rng.poisson(5.0, n).astype(np.uint32)]
         osh = [ol.make_shared(ol.GP, alpha=1.0, inv_beta=1.0)]
         gsh = [engine.gp_shared(1.0, 1.0)]
+    elif config == "bnb":
+        vals = [rng.negative_binomial(3, 0.4, n).astype(np.uint32)]
+        osh = [ol.make_shared(ol.BNB, alpha=1.5, beta=0.75, r=3)]
+        gsh = [engine.bnb_shared(1.5, 0.75, 3)]
     elif config == "nich":
         vals = [rng.normal(0, 1, n).astype(np.float32)]
         osh = [ol.make_shared(ol.NICH, mu=0.0, kappa=1.0, sigmasq=1.0, nu=1.0)]
