@@ -59,6 +59,23 @@ cdef extern from "distributions_hip.h" nogil:
 
     ctypedef struct dist_py_mixture_t:
         pass
+    ctypedef struct dist_le_mixture_t:
+        pass
+    int dist_le_score_add_value(int, int, int, int, int, float *)
+    int dist_le_score_remove_value(int, int, int, int, int, float *)
+    int dist_le_log_partition_function(int, float *)
+    int dist_le_score_counts(int, const int *, size_t, float *)
+    dist_le_mixture_t * dist_le_mixture_create()
+    void dist_le_mixture_destroy(dist_le_mixture_t *)
+    int dist_le_mixture_init(dist_le_mixture_t *, const int *, size_t)
+    int dist_le_mixture_add_value(dist_le_mixture_t *, size_t, int *)
+    int dist_le_mixture_remove_value(dist_le_mixture_t *, size_t, int *)
+    int dist_le_mixture_score_value(const dist_le_mixture_t *, int, float *,
+                                    size_t)
+    int dist_le_mixture_score_data(const dist_le_mixture_t *, int, float *)
+    size_t dist_le_mixture_size(const dist_le_mixture_t *)
+    size_t dist_le_mixture_sample_size(const dist_le_mixture_t *)
+    int dist_le_mixture_counts(const dist_le_mixture_t *, int *)
     dist_py_mixture_t * dist_py_mixture_create()
     void dist_py_mixture_destroy(dist_py_mixture_t *)
     int dist_py_mixture_init(dist_py_mixture_t *, float, float, const int *,
@@ -130,6 +147,8 @@ cdef extern from "distributions_hip.h" nogil:
     ctypedef struct dist_gibbs_t:
         pass
     dist_gibbs_t * dist_gibbs_create(float, float, int, const dist_shared_t *)
+    dist_gibbs_t * dist_gibbs_create_low_entropy(int, int,
+                                                 const dist_shared_t *)
     void dist_gibbs_destroy(dist_gibbs_t *)
     int dist_gibbs_load_rows(dist_gibbs_t *, size_t, const uint32_t * const *,
                              const uint32_t *, int, int, uint64_t)
@@ -540,6 +559,95 @@ cdef class PyMixture:
 
 
 # ---------------------------------------------------------------------------
+# Clustering<int>::LowEntropy
+
+def le_score_add_value(int dataset_size, int group_size, int nonempty,
+                       int sample_size, int empty=1):
+    cdef float out = 0
+    check(dist_le_score_add_value(dataset_size, group_size, nonempty,
+                                  sample_size, empty, &out))
+    return out
+
+
+def le_score_remove_value(int dataset_size, int group_size, int nonempty,
+                          int sample_size, int empty=1):
+    cdef float out = 0
+    check(dist_le_score_remove_value(dataset_size, group_size, nonempty,
+                                     sample_size, empty, &out))
+    return out
+
+
+def le_log_partition_function(int sample_size):
+    cdef float out = 0
+    check(dist_le_log_partition_function(sample_size, &out))
+    return out
+
+
+def le_score_counts(int dataset_size, counts):
+    cdef cnp.ndarray[cnp.int32_t, ndim=1] c = np.ascontiguousarray(
+        counts, dtype=np.int32)
+    cdef float out = 0
+    check(dist_le_score_counts(dataset_size, <const int *> c.data, c.shape[0],
+                               &out))
+    return out
+
+
+cdef class LeMixture:
+    cdef dist_le_mixture_t * ptr
+
+    def __cinit__(self):
+        self.ptr = dist_le_mixture_create()
+        if self.ptr == NULL:
+            raise RuntimeError(dist_last_error().decode())
+
+    def __dealloc__(self):
+        if self.ptr != NULL:
+            dist_le_mixture_destroy(self.ptr)
+
+    def __len__(self):
+        return dist_le_mixture_size(self.ptr)
+
+    def init(self, counts):
+        cdef cnp.ndarray[cnp.int32_t, ndim=1] c = np.ascontiguousarray(
+            counts, dtype=np.int32)
+        check(dist_le_mixture_init(self.ptr, <const int *> c.data, c.shape[0]))
+
+    def add_value(self, size_t groupid):
+        cdef int added = 0
+        check(dist_le_mixture_add_value(self.ptr, groupid, &added))
+        return bool(added)
+
+    def remove_value(self, size_t groupid):
+        cdef int removed = 0
+        check(dist_le_mixture_remove_value(self.ptr, groupid, &removed))
+        return bool(removed)
+
+    def score_value(self, int dataset_size,
+                    cnp.ndarray[cnp.float32_t, ndim=1] scores):
+        check(dist_le_mixture_score_value(self.ptr, dataset_size,
+                                          <float *> scores.data,
+                                          scores.shape[0]))
+
+    def score_data(self, int dataset_size):
+        cdef float out = 0
+        check(dist_le_mixture_score_data(self.ptr, dataset_size, &out))
+        return out
+
+    def sample_size(self):
+        return dist_le_mixture_sample_size(self.ptr)
+
+    def counts(self):
+        cdef cnp.ndarray[cnp.int32_t, ndim=1] out = np.zeros(len(self),
+                                                            np.int32)
+        if len(self):
+            check(dist_le_mixture_counts(self.ptr, <int *> out.data))
+        return out
+
+    def empty_groupids(self):
+        return [i for i, c in enumerate(self.counts()) if c == 0]
+
+
+# ---------------------------------------------------------------------------
 # Model::Mixture
 
 cdef class SlaveMixture:
@@ -677,7 +785,9 @@ cdef class GibbsEngine:
     cdef list shareds
     cdef object _keep   # device tensors / arrays the engine points into
 
-    def __cinit__(self, float alpha, float d, shareds):
+    def __cinit__(self, float alpha, float d, shareds, dataset_size=None):
+        """dataset_size: the LowEntropy clustering model instead of
+        PitmanYor(alpha, d)"""
         cdef int n = len(shareds)
         cdef dist_shared_t * arr = <dist_shared_t *> malloc(
             sizeof(dist_shared_t) * (n + 1))
@@ -687,7 +797,10 @@ cdef class GibbsEngine:
             s = shareds[i]
             memcpy(&arr[i], &s.c, sizeof(dist_shared_t))
         self.shareds = list(shareds)
-        self.ptr = dist_gibbs_create(alpha, d, n, arr)
+        if dataset_size is None:
+            self.ptr = dist_gibbs_create(alpha, d, n, arr)
+        else:
+            self.ptr = dist_gibbs_create_low_entropy(int(dataset_size), n, arr)
         free(arr)
         if self.ptr == NULL:
             raise RuntimeError(dist_last_error().decode())

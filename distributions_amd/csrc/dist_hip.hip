@@ -17,6 +17,7 @@
 
 #include "common.h"
 #include "kernels.h"
+#include "le_table.h"
 
 namespace dist {
 
@@ -613,6 +614,8 @@ struct Tracker {
 
 struct Gibbs {
     float alpha, d;
+    int cluster = 0;        // 0 PitmanYor(alpha, d), 1 LowEntropy(dataset_size)
+    int dataset_size = 0;
     PyDriver py;
     std::vector<std::unique_ptr<Slave>> feats;
     Tracker tracker;
@@ -733,6 +736,8 @@ struct Gibbs {
         P.n_empty = py.n_empty;
         P.alpha = alpha;
         P.d = d;
+        P.cluster = cluster;
+        P.dataset_size = dataset_size;
         P.sample_size = py.sample_size;
         P.assign = assign;
         P.g2p = d_g2p.p;
@@ -1722,6 +1727,135 @@ int dist_py_mixture_score_data(const dist_py_mixture_t * m, float alpha,
     });
 }
 
+// ---- Clustering<int>::LowEntropy ------------------------------------------
+static float le_log_partition_function(int n) {   // clustering.cc:204-215
+    ensure_host_tables();
+    DIST_REQUIRE(n >= 0, "negative sample size");
+    if (n < 48) return u2f(DIST_LE_LOG_PARTITION[n]);
+    const float coeff = 0.28269584f;
+    const float log_z_max = (float)n * fast_log((float)n);
+    return log_z_max * (1.f + coeff * powf((float)n, -0.75f));
+}
+int dist_le_score_add_value(int dataset_size, int group_size,
+                            int nonempty_group_count, int sample_size,
+                            int empty_group_count, float * out) {
+    (void)nonempty_group_count;
+    return guarded([&] {
+        ensure_device_ready();
+        Scratch & sc = scratch();
+        sc.f.reserve(1, 0);
+        LAUNCH1(k_le_score_add_value, dataset_size, group_size, sample_size,
+                empty_group_count, sc.f.p);
+        sc.f.download(out, 1);
+    });
+}
+int dist_le_score_remove_value(int dataset_size, int group_size,
+                               int nonempty_group_count, int sample_size,
+                               int empty_group_count, float * out) {
+    // clustering.hpp:294-309
+    const int rc = dist_le_score_add_value(dataset_size, group_size - 1,
+                                           nonempty_group_count, sample_size,
+                                           empty_group_count, out);
+    if (rc == 0) *out = -*out;
+    return rc;
+}
+int dist_le_log_partition_function(int sample_size, float * out) {
+    return guarded([&] { *out = le_log_partition_function(sample_size); });
+}
+// clustering.cc:229-248; the sum of n log n terms in binary64 on the device,
+// the closing scalar arithmetic in float like the reference
+static float le_score_counts(int dataset_size, const int * counts, size_t n) {
+    ensure_device_ready();
+    long long sample_size = 0;
+    for (size_t i = 0; i < n; ++i) {
+        DIST_REQUIRE(counts[i] >= 0, "negative group size");
+        sample_size += counts[i];
+    }
+    DIST_REQUIRE(sample_size <= dataset_size, "sample_size > dataset_size");
+    double terms = 0.0;
+    if (n) {
+        DeviceBuf<int32_t> dc;
+        DeviceBuf<double> out;
+        dc.upload(counts, n);
+        out.reserve(1, 0);
+        LAUNCH(k_le_count_terms, n, dc.p, (int)n, out.p);
+        out.download(&terms, 1);
+    }
+    float score = (float)terms;
+    if (sample_size != dataset_size) {
+        const float log_factor =
+            le_postpred_correction((float)sample_size, dataset_size);
+        score += log_factor * (float)(n - 1);
+        const float ln = fast_log((float)sample_size);
+        const float lN = fast_log((float)dataset_size);
+        score += 0.061f * ln * (ln - lN) * powf(ln + lN, 0.75f);
+    }
+    score -= le_log_partition_function((int)sample_size);
+    return score;
+}
+int dist_le_score_counts(int dataset_size, const int * counts,
+                         size_t group_count, float * out) {
+    return guarded(
+        [&] { *out = le_score_counts(dataset_size, counts, group_count); });
+}
+
+// LowEntropy::Mixture = MixtureDriver<LowEntropy, int> (mixture.hpp:48-163):
+// the counts bookkeeping is the cached driver's, the scores are computed
+// afresh per call as the generic driver does
+struct dist_le_mixture {
+    PyDriver impl;
+};
+dist_le_mixture_t * dist_le_mixture_create(void) {
+    dist_le_mixture_t * m = nullptr;
+    guarded([&] { m = new dist_le_mixture(); });
+    return m;
+}
+void dist_le_mixture_destroy(dist_le_mixture_t * m) { delete m; }
+int dist_le_mixture_init(dist_le_mixture_t * m, const int * counts, size_t n) {
+    return guarded([&] { m->impl.init(0.f, 0.f, counts, n); sync(); });
+}
+int dist_le_mixture_add_value(dist_le_mixture_t * m, size_t groupid,
+                              int * added_out) {
+    return guarded([&] { *added_out = m->impl.add_value(0.f, 0.f, groupid); });
+}
+int dist_le_mixture_remove_value(dist_le_mixture_t * m, size_t groupid,
+                                 int * removed_out) {
+    return guarded(
+        [&] { *removed_out = m->impl.remove_value(0.f, 0.f, groupid); });
+}
+int dist_le_mixture_score_value(const dist_le_mixture_t * m, int dataset_size,
+                                float * scores, size_t size) {
+    return guarded([&] {
+        const PyDriver & d = m->impl;
+        DIST_REQUIRE(size == d.counts.size(),
+                     "scores.size() != counts().size()");
+        if (!size) return;
+        Scratch & sc = scratch();
+        sc.f.reserve(size, 0);
+        LAUNCH(k_le_score, size, d.d_counts.p, sc.f.p, d.K(), dataset_size,
+               (int)d.sample_size, d.n_empty);
+        sc.f.download(scores, size);
+    });
+}
+int dist_le_mixture_score_data(const dist_le_mixture_t * m, int dataset_size,
+                               float * out) {
+    return guarded([&] {
+        *out = le_score_counts(dataset_size, m->impl.counts.data(),
+                               m->impl.counts.size());
+    });
+}
+size_t dist_le_mixture_size(const dist_le_mixture_t * m) {
+    return m->impl.counts.size();
+}
+size_t dist_le_mixture_sample_size(const dist_le_mixture_t * m) {
+    return (size_t)m->impl.sample_size;
+}
+int dist_le_mixture_counts(const dist_le_mixture_t * m, int * out) {
+    return guarded([&] {
+        std::copy(m->impl.counts.begin(), m->impl.counts.end(), out);
+    });
+}
+
 dist_py_mixture_t * dist_py_mixture_create(void) {
     dist_py_mixture_t * m = nullptr;
     guarded([&] { m = new dist_py_mixture(); });
@@ -1967,6 +2101,21 @@ dist_gibbs_t * dist_gibbs_create(float alpha, float d, int n_features,
     guarded([&] {
         std::unique_ptr<dist_gibbs> p(new dist_gibbs());
         p->impl.reset(new Gibbs(alpha, d, n_features, shareds));
+        g = p.release();
+    });
+    return g;
+}
+dist_gibbs_t * dist_gibbs_create_low_entropy(int dataset_size, int n_features,
+                                             const dist_shared_t * shareds) {
+    dist_gibbs_t * g = nullptr;
+    guarded([&] {
+        DIST_REQUIRE(dataset_size > 0, "LowEntropy: dataset_size must be > 0");
+        std::unique_ptr<dist_gibbs> p(new dist_gibbs());
+        // (alpha, d) only feed the cached PitmanYor scores, which the
+        // LowEntropy kernels never read
+        p->impl.reset(new Gibbs(1.f, 0.f, n_features, shareds));
+        p->impl->cluster = 1;
+        p->impl->dataset_size = dataset_size;
         g = p.release();
     });
     return g;

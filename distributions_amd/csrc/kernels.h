@@ -105,6 +105,30 @@ __global__ void k_py_score(const float * __restrict__ shifted,
     out[k] = shifted[k] + py_shift(sample_size, alpha);
 }
 
+// MixtureDriver<LowEntropy>::score_value (mixture.hpp:124-141)
+__global__ void k_le_score(const int32_t * __restrict__ counts,
+                           float * __restrict__ out, int K, int dataset_size,
+                           int sample_size, int empty) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    out[k] = le_score_add_value(dataset_size, counts[k], sample_size, empty);
+}
+__global__ void k_le_score_add_value(int dataset_size, int group_size,
+                                     int sample_size, int empty, float * out) {
+    *out = le_score_add_value(dataset_size, group_size, sample_size, empty);
+}
+// LowEntropy::score_counts (clustering.cc:229-238): sum of n log n, in
+// binary64 (the reference accumulates in float)
+__global__ void k_le_count_terms(const int32_t * __restrict__ counts, int K,
+                                 double * out) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    double acc = 0.0;
+    if (k < K && counts[k] > 1)
+        acc = (double)((float)counts[k] * fast_log((float)counts[k]));
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if ((threadIdx.x & 63) == 0 && acc != 0.0) atomicAdd(out, acc);
+}
+
 __global__ void k_py_score_add_value(float alpha, float d, int group_size,
                                      int nonempty, int sample_size, int empty,
                                      float * out) {
@@ -340,6 +364,11 @@ struct SweepParams {
     int K;
     int n_empty;
     float alpha, d;
+    // the clustering model: 0 = PitmanYor(alpha, d) through the cached
+    // driver (clustering.hpp:126-234); 1 = LowEntropy(dataset_size) through
+    // the generic MixtureDriver (mixture.hpp:124-141)
+    int cluster;
+    int dataset_size;
     long long sample_size;
     const uint32_t * assign;   // global group id per local row
     const int32_t * g2p;       // global -> packed at batch entry
@@ -366,6 +395,17 @@ struct SweepParams {
     const uint32_t * sorted_rows;
     const uint32_t * assign_pos;
 };
+
+// the clustering model's score of the row's own group, which keeps
+// `remaining` >= 1 members once the row is out
+__device__ __forceinline__ float cluster_own_score(const SweepParams & P,
+                                                   int remaining,
+                                                   float shift) {
+    if (P.cluster == 1)
+        return le_score_add_value(P.dataset_size, remaining,
+                                  (int)P.sample_size - 1, P.n_empty);
+    return py_nonempty_score(remaining, P.d) + shift;
+}
 
 // Integer statistics are exact under atomics.  `stats` is either the live
 // state or a zeroed delta image in the stat-word layout:
@@ -407,6 +447,23 @@ __global__ void k_sweep_prepare(SweepParams P, float * __restrict__ base,
                                 float * __restrict__ base_single,
                                 SweepScalars * scalars) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (P.cluster == 1) {
+        // MixtureDriver<LowEntropy>::score_value with the row removed:
+        // sample_size - 1 rows; the score of a slot depends on its own size
+        // only, so a vanished singleton changes nothing else
+        if (i == 0) {
+            scalars->shift = 0.f;
+            scalars->shift_full = 0.f;
+            scalars->empty_single = le_score_add_value(
+                P.dataset_size, 0, (int)P.sample_size - 1, P.n_empty);
+        }
+        if (i >= (size_t)P.K) return;
+        const float s = le_score_add_value(P.dataset_size, P.counts[i],
+                                           (int)P.sample_size - 1, P.n_empty);
+        base[i] = s;
+        base_single[i] = s;
+        return;
+    }
     const float shift = py_shift(P.sample_size - 1, P.alpha);
     const float empty_single =
         py_empty_score(P.alpha, P.d, P.K - P.n_empty - 1, P.n_empty);
@@ -530,7 +587,7 @@ struct RowScorer {
             lf[f] = kind_of(f) == DIST_GP ? fast_log_factorial(x[f]) : 0.f;
         }
         if (!singleton) {
-            float s = py_nonempty_score(n_g - 1, P.d) + shift;
+            float s = cluster_own_score(P, n_g - 1, shift);
 #pragma unroll kUnroll
             for (int f = 0; f < nf(); ++f) {
                 SlaveView v = P.feat[f];
@@ -752,7 +809,10 @@ __global__ void k_score_rows(SweepParams P, float * __restrict__ out,
     const size_t r = i / P.K;
     const int k = (int)(i % P.K);
     const size_t row = P.row_begin + r;
-    float s = P.shifted[k] + P.scalars->shift_full;
+    float s = P.cluster == 1
+        ? le_score_add_value(P.dataset_size, P.counts[k], (int)P.sample_size,
+                             P.n_empty)
+        : P.shifted[k] + P.scalars->shift_full;
     for (int f = 0; f < P.F; ++f) {
         const SlaveView & v = P.feat[f];
         const uint32_t x = P.values[f][row];
@@ -801,7 +861,7 @@ __device__ __forceinline__ float vs_own_score(const SweepParams & P,
                                               const SlaveView & v, int g,
                                               int n_g, uint32_t x, float lf,
                                               float shift) {
-    const float s = py_nonempty_score(n_g - 1, P.d) + shift;
+    const float s = cluster_own_score(P, n_g - 1, shift);
     return accumulate(v.kind, s, entry_after_remove(v, g, x), x, lf, v.p);
 }
 

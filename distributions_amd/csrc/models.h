@@ -485,6 +485,31 @@ DIST_HD float py_empty_score(float alpha, float d, int nonempty, int empty) {
 DIST_HD float py_shift(long long sample_size, float alpha) {
     return -fast_log((float)(unsigned long long)sample_size + alpha);
 }
+// Clustering<int>::LowEntropy (clustering.hpp:245-331).  dataset_size is the
+// model's only parameter; nonempty_group_count does not enter its scores.
+// _approximate_postpred_correction, clustering.hpp:318-327
+DIST_HD float le_postpred_correction(float sample_size, int dataset_size) {
+    const float exponent =
+        0.45f - 0.1f / sample_size - 0.1f / (float)dataset_size;
+    const float scale = (float)dataset_size / sample_size;
+    return fast_log(scale) * exponent;
+}
+// score_add_value, clustering.hpp:267-292
+DIST_HD float le_score_add_value(int dataset_size, int group_size,
+                                 int sample_size, int empty) {
+    if (group_size == 0) {
+        float score = -fast_log((float)empty);
+        if (sample_size + 1 < dataset_size)
+            score += le_postpred_correction((float)(sample_size + 1),
+                                            dataset_size);
+        return score;
+    }
+    const float bigger = 1.f + (float)group_size;
+    if (group_size > 10000) return 1.f + fast_log(bigger);
+    return fast_log(bigger / (float)group_size) * (float)group_size
+         + fast_log(bigger);
+}
+
 // clustering.hpp:81-104
 DIST_HD float py_score_add_value(float alpha, float d, int group_size,
                                  int nonempty, int sample_size, int empty) {

@@ -51,13 +51,17 @@ def dpd_shared(alpha, betas, beta0=0.0):
 
 
 class Gibbs(object):
-    """PitmanYor(alpha, d) driver + feature slaves over resident rows."""
+    """Clustering driver + feature slaves over resident rows.  The clustering
+    model is PitmanYor(alpha, d), or LowEntropy(dataset_size) when
+    `dataset_size` is given (alpha and d are then ignored)."""
 
-    def __init__(self, alpha, d, shareds):
+    def __init__(self, alpha, d, shareds, dataset_size=None):
         self.alpha = float(alpha)
         self.d = float(d)
+        self.dataset_size = dataset_size
         self.shareds = list(shareds)
-        self.core = _core.GibbsEngine(self.alpha, self.d, self.shareds)
+        self.core = _core.GibbsEngine(self.alpha, self.d, self.shareds,
+                                      dataset_size)
 
     # -- data ---------------------------------------------------------------
     def load_rows(self, values, assign_packed, nonempty_groups,

@@ -114,6 +114,38 @@ int dist_py_sample_assignments(float alpha, float d, int size,
 int dist_py_score_counts(float alpha, float d, const int * counts,
                          size_t group_count, float * out);
 
+/* ---- Clustering<int>::LowEntropy (clustering.hpp:245-331) ----------------
+ * dataset_size is the model; nonempty_group_count is accepted and unused, as
+ * in the reference.  score_counts: clustering.cc:229-248 (n log n terms summed
+ * in binary64, 1e-6 relative); log_partition_function: clustering.cc:204-215.
+ * sample_assignments is not provided (initialisation only). */
+int dist_le_score_add_value(int dataset_size, int group_size,
+                            int nonempty_group_count, int sample_size,
+                            int empty_group_count, float * out);
+int dist_le_score_remove_value(int dataset_size, int group_size,
+                               int nonempty_group_count, int sample_size,
+                               int empty_group_count, float * out);
+int dist_le_log_partition_function(int sample_size, float * out);
+int dist_le_score_counts(int dataset_size, const int * counts,
+                         size_t group_count, float * out);
+/* LowEntropy::Mixture = MixtureDriver<LowEntropy, int> (mixture.hpp:48-163) */
+typedef struct dist_le_mixture dist_le_mixture_t;
+dist_le_mixture_t * dist_le_mixture_create(void);
+void dist_le_mixture_destroy(dist_le_mixture_t * m);
+int dist_le_mixture_init(dist_le_mixture_t * m, const int * counts,
+                         size_t group_count);                 /* mixture.hpp:59-71   */
+int dist_le_mixture_add_value(dist_le_mixture_t * m, size_t groupid,
+                              int * added_out);               /* mixture.hpp:73-92   */
+int dist_le_mixture_remove_value(dist_le_mixture_t * m, size_t groupid,
+                                 int * removed_out);          /* mixture.hpp:94-122  */
+int dist_le_mixture_score_value(const dist_le_mixture_t * m, int dataset_size,
+                                float * scores, size_t size); /* mixture.hpp:124-141 */
+int dist_le_mixture_score_data(const dist_le_mixture_t * m, int dataset_size,
+                               float * out);                  /* mixture.hpp:143-145 */
+size_t dist_le_mixture_size(const dist_le_mixture_t * m);
+size_t dist_le_mixture_sample_size(const dist_le_mixture_t * m);
+int dist_le_mixture_counts(const dist_le_mixture_t * m, int * out);
+
 /* ---- PitmanYor::Mixture = CachedMixture (clustering.hpp:126-234) --------- */
 typedef struct dist_py_mixture dist_py_mixture_t;
 dist_py_mixture_t * dist_py_mixture_create(void);
@@ -234,6 +266,10 @@ size_t dist_id_tracker_global_size(const dist_id_tracker_t * t);
 typedef struct dist_gibbs dist_gibbs_t;
 dist_gibbs_t * dist_gibbs_create(float alpha, float d, int n_features,
                                  const dist_shared_t * shareds);
+/* the same engine under the LowEntropy clustering model (generic driver
+ * scores, mixture.hpp:124-141); dataset_size >= the total number of rows */
+dist_gibbs_t * dist_gibbs_create_low_entropy(int dataset_size, int n_features,
+                                             const dist_shared_t * shareds);
 void dist_gibbs_destroy(dist_gibbs_t * g);
 
 /* Make n_rows rows resident.  values[f] -> n_rows words; assign_packed[i] in

@@ -317,6 +317,8 @@ typedef struct {
 
 struct orc_mix {
     float alpha, d;
+    int cluster;          /* 0: PitmanYor (cached), 1: LowEntropy (generic driver) */
+    int dataset_size;     /* LowEntropy */
     int K, cap;
     int32_t * counts;
     float * shifted;
@@ -633,6 +635,75 @@ static float feat_score_value_group(const feat * f, int k, uint32_t value) {
 }
 
 /* ------------------------------------------------------------------------ */
+/* Clustering<int>::LowEntropy (clustering.hpp:245-331, clustering.cc:186-283) */
+#include "le_table.h"
+
+/* clustering.hpp:318-327 */
+static float le_postpred_correction(float sample_size, int dataset_size) {
+    float exponent = 0.45f - 0.1f / sample_size - 0.1f / (float)dataset_size;
+    float scale = (float)dataset_size / sample_size;
+    return orc_fast_log(scale) * exponent;
+}
+/* clustering.hpp:267-292 (nonempty_group_count is unused by the model) */
+float orc_le_score_add_value(int dataset_size, int group_size,
+                             int nonempty_group_count, int sample_size,
+                             int empty_group_count) {
+    (void)nonempty_group_count;
+    if (group_size == 0) {
+        float score = -orc_fast_log((float)empty_group_count);
+        if (sample_size + 1 < dataset_size)
+            score += le_postpred_correction((float)(sample_size + 1),
+                                            dataset_size);
+        return score;
+    }
+    const int very_large = 10000;
+    float bigger = 1.f + (float)group_size;
+    if (group_size > very_large) return 1.f + orc_fast_log(bigger);
+    return orc_fast_log(bigger / (float)group_size) * (float)group_size
+         + orc_fast_log(bigger);
+}
+/* clustering.hpp:294-309 */
+float orc_le_score_remove_value(int dataset_size, int group_size,
+                                int nonempty_group_count, int sample_size,
+                                int empty_group_count) {
+    return -orc_le_score_add_value(dataset_size, group_size - 1,
+                                   nonempty_group_count, sample_size,
+                                   empty_group_count);
+}
+/* clustering.cc:204-215 */
+float orc_le_log_partition_function(int n) {
+    if (n < 48) return u2f(DIST_LE_LOG_PARTITION[n]);
+    float coeff = 0.28269584f;
+    float log_z_max = (float)n * orc_fast_log((float)n);
+    return log_z_max * (1.f + coeff * powf((float)n, -0.75f));
+}
+/* clustering.cc:221-248 */
+float orc_le_score_counts(int dataset_size, const int * counts, size_t size) {
+    unsigned saved = orc_ftz_enable();
+    float score = 0.f;
+    int sample_size = 0;
+    for (size_t i = 0; i < size; ++i) {
+        sample_size += counts[i];
+        if (counts[i] > 1)
+            score += (float)counts[i] * orc_fast_log((float)counts[i]);
+    }
+    if (sample_size != dataset_size) {
+        float log_factor = le_postpred_correction((float)sample_size,
+                                                  dataset_size);
+        score += log_factor * (float)(size - 1);
+        float n = orc_fast_log((float)sample_size);
+        float N = orc_fast_log((float)dataset_size);
+        score += 0.061f * n * (n - N) * powf(n + N, 0.75f);
+    }
+    score -= orc_le_log_partition_function(sample_size);
+    orc_ftz_restore(saved);
+    return score;
+}
+/* LowEntropy::sample_assignments (clustering.cc:250-283) draws through the
+ * two-argument sample_from_likelihoods, whose total is the re-associated
+ * vector_sum of the release build: not restated (initialisation only). */
+
+/* ------------------------------------------------------------------------ */
 /* driver: clustering.hpp:126-234 over mixture.hpp:48-163                   */
 
 static void py_reserve(orc_mix * m, int need) {
@@ -645,6 +716,7 @@ static void py_reserve(orc_mix * m, int need) {
 }
 /* clustering.hpp:215-219 */
 static void py_update_nonempty(orc_mix * m, int k) {
+    if (m->cluster) return;   /* the generic driver keeps no cache */
     m->shifted[k] = orc_fast_log((float)m->counts[k] - m->d);
 }
 static float py_empty_score(float alpha, float d, int nonempty, int empty) {
@@ -654,6 +726,7 @@ static float py_empty_score(float alpha, float d, int nonempty, int empty) {
 }
 /* clustering.hpp:221-230 */
 static void py_update_empty(orc_mix * m) {
+    if (m->cluster) return;
     float s = py_empty_score(m->alpha, m->d, m->K - m->n_empty, m->n_empty);
     for (int k = 0; k < m->K; ++k)
         if (m->counts[k] == 0) m->shifted[k] = s;
@@ -710,6 +783,13 @@ int orc_mix_driver_remove_value(orc_mix * m, int g) {
 
 /* clustering.hpp:195-208 */
 void orc_mix_driver_score_value(const orc_mix * m, float * scores) {
+    if (m->cluster) {   /* MixtureDriver::score_value, mixture.hpp:124-141 */
+        for (int k = 0; k < m->K; ++k)
+            scores[k] = orc_le_score_add_value(
+                m->dataset_size, m->counts[k], m->K - m->n_empty,
+                (int)m->sample_size, m->n_empty);
+        return;
+    }
     const float shift =
         -orc_fast_log((float)(uint64_t)m->sample_size + m->alpha);
     for (int k = 0; k < m->K; ++k) scores[k] = m->shifted[k] + shift;
@@ -771,6 +851,8 @@ orc_mix * orc_mix_create(float alpha, float d, int F,
     orc_mix * m = calloc(1, sizeof(orc_mix));
     m->alpha = alpha;
     m->d = d;
+    m->cluster = 0;
+    m->dataset_size = 0;
     m->F = F;
     m->f = calloc(F > 0 ? F : 1, sizeof(feat));
     for (int i = 0; i < F; ++i) {
@@ -783,6 +865,10 @@ orc_mix * orc_mix_create(float alpha, float d, int F,
         }
     }
     return m;
+}
+void orc_mix_set_low_entropy(orc_mix * m, int dataset_size) {
+    m->cluster = 1;
+    m->dataset_size = dataset_size;
 }
 void orc_mix_destroy(orc_mix * m) {
     if (!m) return;
@@ -1268,7 +1354,16 @@ int orc_mix_batch_row_scores(const orc_mix * m, const uint32_t * x, uint32_t g,
     if (singleton)
         empty_score = py_empty_score(m->alpha, m->d,
                                      K - m->n_empty - 1, m->n_empty);
-    for (int k = 0; k < Kl; ++k) {
+    for (int k = 0; m->cluster && k < Kl; ++k) {
+        /* generic driver after remove_value: sizes as they stand, one row
+         * and (for a singleton) one non-empty group fewer */
+        int src = (singleton && k == (int)g) ? K - 1 : k;
+        int n = m->counts[src] - ((!singleton && k == (int)g) ? 1 : 0);
+        scores[k] = orc_le_score_add_value(
+            m->dataset_size, n, K - m->n_empty - singleton,
+            (int)m->sample_size - 1, m->n_empty);
+    }
+    for (int k = 0; !m->cluster && k < Kl; ++k) {
         int src = (singleton && k == (int)g) ? K - 1 : k;
         float c;
         if (!singleton && k == (int)g) {

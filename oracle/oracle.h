@@ -100,6 +100,19 @@ float orc_py_score_remove_value(float alpha, float d, int group_size,
 /* ---- a full mixture: PY driver + feature slaves + id tracker ------------ */
 typedef struct orc_mix orc_mix;
 
+/* Clustering<int>::LowEntropy (clustering.hpp:245-331, clustering.cc:186-283);
+ * orc_mix_set_low_entropy switches a mixture's driver from the cached
+ * PitmanYor one to MixtureDriver<LowEntropy> (mixture.hpp:48-163) */
+float orc_le_score_add_value(int dataset_size, int group_size,
+                             int nonempty_group_count, int sample_size,
+                             int empty_group_count);
+float orc_le_score_remove_value(int dataset_size, int group_size,
+                                int nonempty_group_count, int sample_size,
+                                int empty_group_count);
+float orc_le_log_partition_function(int sample_size);
+float orc_le_score_counts(int dataset_size, const int * counts, size_t size);
+void orc_mix_set_low_entropy(orc_mix * m, int dataset_size);
+
 orc_mix * orc_mix_create(float alpha, float d, int n_features,
                          const orc_shared * shareds);
 void orc_mix_destroy(orc_mix * m);

@@ -259,8 +259,26 @@ def protobuf_schema():
           % (len(table), len(samples)))
 
 
+def low_entropy_table():
+    """the 48 log Z(n) values the reference ships for its low-entropy
+    clustering model (src/clustering.cc:189-202), as data"""
+    import json
+    import re
+    src = open("/root/reference/src/clustering.cc").read()
+    body = re.search(r"log_partition_function_table\[48\] = \{(.*?)\};", src,
+                     re.S).group(1)
+    values = [float(x) for x in body.replace("\n", " ").split(",")]
+    assert len(values) == 48
+    bits = [int(np.float32(v).view(np.uint32)) for v in values]
+    with open(os.path.join(HERE, "low_entropy.json"), "w") as f:
+        json.dump({"log_partition_function_table": values,
+                   "float32_bits": bits}, f, indent=1)
+    print("low_entropy.json: %d table entries" % len(values))
+
+
 if __name__ == "__main__":
     protobuf_schema()
+    low_entropy_table()
     if "--schema-only" in sys.argv:
         sys.exit(0)
     R = ol.ref()

@@ -426,3 +426,90 @@ def test_py_score_counts_and_mixture_score_data():
         mixture = PitmanYor.Mixture()
         mixture.init(model, counts)
         assert abs(mixture.score_data(model) - want) <= 1e-6 * (1 + abs(want))
+
+
+def test_low_entropy_model_and_mixture():
+    """LowEntropy through distributions_amd.lp: score_add_value and
+    score_counts against the oracle (bit-exact / 1e-6), and the reference's
+    test_mixture_score_matches_score_add_value (test_clustering.py:243-327)
+    for LowEntropy.Mixture = MixtureDriver<LowEntropy>"""
+    from distributions_amd.lp.clustering import LowEntropy
+    from distributions_amd.lp.mixture import MixtureIdTracker
+    from distributions_amd.lp import random as lprandom
+    L = ol.oracle()
+    i = ctypes.c_int
+    L.orc_le_score_add_value.restype = ctypes.c_float
+    L.orc_le_score_add_value.argtypes = [i, i, i, i, i]
+    L.orc_le_score_counts.restype = ctypes.c_float
+    L.orc_le_score_counts.argtypes = [i, ctypes.c_void_p, ctypes.c_size_t]
+    rng = np.random.default_rng(21)
+    lprandom.seed(3)
+    for ex in LowEntropy.EXAMPLES + [{'dataset_size': 100000}]:
+        model = LowEntropy(**ex)
+        assert model.dump() == ex
+        N = model.dataset_size
+        for size, sample, empty in [(0, 0, 1), (0, N - 2, 3), (1, 1, 1),
+                                    (3, N // 2, 2), (N - 1, N - 1, 1)]:
+            if sample >= N or size > sample:
+                continue
+            want = L.orc_le_score_add_value(N, size, 1, sample, empty)
+            got = model.score_add_value(size, 1, sample, empty)
+            assert np.float32(got) == np.float32(want), (ex, size, sample)
+            if size:
+                assert model.score_remove_value(size + 1, 1, sample + 1,
+                                                empty) == -got
+        counts = [int(c) for c in rng.multinomial(
+            min(N, 5000) // 2, np.ones(6) / 6)] + [0]
+        c = np.ascontiguousarray(counts, np.int32)
+        want = L.orc_le_score_counts(N, c.ctypes.data, c.size)
+        got = model.score_counts(counts)
+        assert abs(got - want) <= 1e-6 * (1 + abs(want)), (ex, got, want)
+
+    model = LowEntropy(dataset_size=1000)
+    nonempty_counts = [int(c) for c in rng.integers(1, 30, 7)]
+    for empty_group_count in [1, 10]:
+        counts = nonempty_counts + [0] * empty_group_count
+        rng.shuffle(counts)
+        counts = [int(c) for c in counts]
+        mixture = LowEntropy.Mixture()
+        id_tracker = MixtureIdTracker()
+        mixture.init(model, counts)
+        id_tracker.init(len(counts))
+
+        def check(counts):
+            empties = frozenset(mixture.empty_groupids)
+            assert len(empties) == empty_group_count
+            assert all(counts[g] == 0 for g in empties)
+            expected = [model.score_add_value(
+                size, len(counts) - empty_group_count, sum(counts),
+                empty_group_count) for size in counts]
+            actual = rng.normal(size=len(counts)).astype(np.float32)
+            mixture.score_value(model, actual)
+            assert np.array_equal(actual, np.float32(expected))
+            assert abs(mixture.score_data(model) - model.score_counts(counts)
+                       ) < 1e-4
+            return actual
+
+        groupids = []
+        for _ in range(60):
+            scores = check(counts)
+            probs = np.exp(scores - scores.max())
+            groupid = int(rng.choice(len(counts), p=probs / probs.sum()))
+            added = mixture.add_value(model, groupid)
+            assert added == (counts[groupid] == 0)
+            counts[groupid] += 1
+            groupids.append(id_tracker.packed_to_global(groupid))
+            if added:
+                id_tracker.add_group()
+                counts.append(0)
+        for global_id in groupids:
+            groupid = id_tracker.global_to_packed(global_id)
+            counts[groupid] -= 1
+            removed = mixture.remove_value(model, groupid)
+            assert removed == (counts[groupid] == 0)
+            if removed:
+                id_tracker.remove_group(groupid)
+                back = counts.pop()
+                if groupid < len(counts):
+                    counts[groupid] = back
+            check(counts)

@@ -1,6 +1,8 @@
 """GPU parity of the batched row update against the oracle (bit-exact
 assignment indices, integer statistics and float statistics; scores to the
 tolerance stated in each test)."""
+import ctypes
+
 import numpy as np
 import pytest
 
@@ -305,3 +307,41 @@ def test_beta_negative_binomial_small_arguments_use_libm_values(alpha, beta,
         gpu.sweep(0, n, 200, 11, draw_base=sweep * n)
         assert_same_state(orc, gpu, "bnb %g %g %d sweep %d" % (
             alpha, beta, r, sweep))
+
+
+@pytest.mark.parametrize("config,mode", [("dd", 0), ("dd", 2), ("bb", 2),
+                                         ("gp_nich", 0), ("bnb", 2)])
+@pytest.mark.parametrize("slack", [0, 1000])
+def test_low_entropy_clustering_sweeps_bit_exact(config, mode, slack):
+    """the row update under Clustering::LowEntropy (clustering.hpp:245-331)
+    scored through the generic MixtureDriver (mixture.hpp:124-141) instead of
+    PitmanYor's cached driver: batches, sequential chain, groups appearing
+    and vanishing; dataset_size == N (no size correction) and > N"""
+    from distributions_amd import engine
+    L = ol.oracle()
+    L.orc_mix_set_low_entropy.restype = None
+    L.orc_mix_set_low_entropy.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    n, k = 3000, 40
+    osh, gsh, vals, assign = workloads.make(config, n, k)
+    orc = ol.OracleMixture(1.0, 0.0, osh)
+    L.orc_mix_set_low_entropy(orc.h, n + slack)
+    orc.init_from_assignments(vals, assign, k, 2)
+    gpu = engine.Gibbs(0.0, 0.0, gsh, dataset_size=n + slack)
+    gpu.set_option("value_sorted", mode)
+    gpu.load_rows(vals, assign, k, 2)
+    for row in [0, 17, n - 1]:
+        g = int(L.orc_mix_global_to_packed(orc.h, int(orc.assign[row])))
+        want = orc.row_scores(row, g)
+        got = gpu.row_scores(row)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    seed = 31
+    st = L.orc_rng_seed(seed)
+    for sweep in range(2):
+        for b in range(0, n, 700):
+            orc.gibbs_batch(b, min(n, b + 700), st, sweep * n)
+        gpu.sweep(0, n, 700, seed, draw_base=sweep * n)
+        assert_same_state(orc, gpu, "low entropy %s sweep %d" % (config, sweep))
+    # and the sequential chain (batches of one)
+    state = orc.gibbs_sequential(0, 300, st)
+    assert gpu.sweep_sequential(0, 300, st) == state
+    assert_same_state(orc, gpu, "low entropy %s sequential" % config)

@@ -361,3 +361,138 @@ def test_sample_assignments_recorded_probe():
     L.orc_py_sample_assignments(1.0, 0.2, 20, ctypes.byref(st), out)
     assert list(out) == [0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 2, 0, 0, 2, 0, 0, 0, 0,
                          0, 0]
+
+
+# ---------------------------------------------------------------------------
+# Clustering<int>::LowEntropy (clustering.hpp:245-331, clustering.cc:186-283)
+
+def _le_sigs():
+    L = ol.oracle()
+    i = ctypes.c_int
+    L.orc_le_score_add_value.restype = ctypes.c_float
+    L.orc_le_score_add_value.argtypes = [i, i, i, i, i]
+    L.orc_le_score_remove_value.restype = ctypes.c_float
+    L.orc_le_score_remove_value.argtypes = [i, i, i, i, i]
+    L.orc_le_log_partition_function.restype = ctypes.c_float
+    L.orc_le_log_partition_function.argtypes = [i]
+    L.orc_le_score_counts.restype = ctypes.c_float
+    L.orc_le_score_counts.argtypes = [i, ctypes.c_void_p, ctypes.c_size_t]
+    return L
+
+
+def _le_score_counts(L, dataset_size, counts):
+    c = np.ascontiguousarray(counts, np.int32)
+    return L.orc_le_score_counts(dataset_size, c.ctypes.data, c.size)
+
+
+def _partitions(n, largest=None):
+    """integer partitions of n as non-increasing tuples"""
+    largest = n if largest is None else largest
+    if n == 0:
+        yield ()
+        return
+    for first in range(min(n, largest), 0, -1):
+        for rest in _partitions(n - first, first):
+            yield (first,) + rest
+
+
+def _set_partition_count(shape):
+    """number of set partitions of [sum(shape)] with these block sizes"""
+    from math import factorial
+    from collections import Counter
+    n = sum(shape)
+    ways = factorial(n)
+    for size in shape:
+        ways //= factorial(size)
+    for mult in Counter(shape).values():
+        ways //= factorial(mult)
+    return ways
+
+
+def test_low_entropy_partition_table_is_the_reference_table():
+    """the table derived in tools/gen_le_table.py (exact recurrence) equals
+    the one the reference ships, to the last bit of binary32"""
+    import json
+    import os
+    L = _le_sigs()
+    here = os.path.dirname(os.path.abspath(__file__))
+    with open(os.path.join(here, "golden", "low_entropy.json")) as f:
+        ref = json.load(f)
+    got = np.array([L.orc_le_log_partition_function(n) for n in range(48)],
+                   np.float32)
+    assert np.array_equal(got.view(np.uint32),
+                          np.array(ref["float32_bits"], np.uint32))
+    # beyond the table: the asymptotic form (clustering.cc:210-214)
+    for n in [48, 100, 1000]:
+        want = n * np.log(n) * (1 + 0.28269584 * n ** -0.75)
+        assert abs(L.orc_le_log_partition_function(n) - want) < 1e-3 * want
+
+
+def test_low_entropy_score_counts_is_normalised_at_full_size():
+    """test_clustering.py:168-193: sum over all set partitions of
+    exp(score_counts) is 1 when sample_size == dataset_size"""
+    L = _le_sigs()
+    for n in range(1, 11):
+        total = 0.0
+        for shape in _partitions(n):
+            total += _set_partition_count(shape) * np.exp(
+                _le_score_counts(L, n, list(shape)))
+        assert abs(total - 1.0) < 1e-4, (n, total)
+
+
+@pytest.mark.parametrize("dataset_size", [5, 10, 100, 1000])
+def test_low_entropy_score_add_value_matches_score_counts(dataset_size):
+    """test_clustering.py:201-238: probabilities from score_add_value agree
+    with ratios of score_counts to 0.05"""
+    L = _le_sigs()
+
+    def probs(scores):
+        scores = np.array(scores, np.float64)
+        p = np.exp(scores - scores.max())
+        return p / p.sum()
+
+    for sample_size in range(2, min(10, dataset_size) + 1):
+        for shape in _partitions(sample_size - 1):
+            counts = list(shape)
+            nonempty = len(counts)
+            actual, expected = [], []
+            for i, size in enumerate(counts):
+                bumped = counts[:]
+                bumped[i] += 1
+                expected.append(_le_score_counts(L, dataset_size, bumped))
+                actual.append(L.orc_le_score_add_value(
+                    dataset_size, size, nonempty, sample_size - 1, 1))
+            expected.append(_le_score_counts(L, dataset_size, counts + [1]))
+            actual.append(L.orc_le_score_add_value(
+                dataset_size, 0, nonempty, sample_size - 1, 1))
+            np.testing.assert_allclose(probs(actual), probs(expected),
+                                       atol=0.05)
+
+
+def test_low_entropy_score_remove_value_is_minus_add_of_the_smaller_group():
+    L = _le_sigs()
+    for n in [1, 2, 7, 10001, 20000]:
+        assert L.orc_le_score_remove_value(50000, n + 1, 3, 100, 1) == \
+            -L.orc_le_score_add_value(50000, n, 3, 100, 1)
+    # beyond very_large the closed form 1 + log(n + 1) (clustering.hpp:283-291)
+    b = L.orc_le_score_add_value(10 ** 6, 10001, 1, 10, 1)
+    assert abs(b - (1 + np.log(10002.0))) < 1e-3
+
+
+def test_low_entropy_driver_scores_are_score_add_value():
+    """MixtureDriver<LowEntropy>::score_value (mixture.hpp:124-141) through
+    the oracle mixture's driver"""
+    L = _le_sigs()
+    L.orc_mix_set_low_entropy.restype = None
+    L.orc_mix_set_low_entropy.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    m = ol.OracleMixture(1.0, 0.0, [ol.make_shared(ol.BB, alpha=1.0, beta=1.0)])
+    L.orc_mix_set_low_entropy(m.h, 500)
+    counts = np.array([5, 0, 3, 1, 0, 40], np.int32)
+    L.orc_mix_driver_init(m.h, counts, len(counts))
+    scores = np.zeros(len(counts), np.float32)
+    L.orc_mix_driver_score_value(m.h, scores)
+    for k, c in enumerate(counts):
+        assert scores[k] == np.float32(L.orc_le_score_add_value(
+            500, int(c), 4, int(counts.sum()), 2))
+    assert L.orc_mix_driver_add_value(m.h, 1) == 1      # an empty group filled
+    assert L.orc_mix_size(m.h) == len(counts) + 1
