@@ -1203,6 +1203,12 @@ struct Gibbs {
         kernel_ms += ms;
         kernel_launches += 1;
         kernel_rows += batch_end - batch_begin;
+        if (batch_value_sorted && getenv("DIST_TRACE_DEFERRED")) {
+            uint32_t n = 0;
+            deferred_count.download(&n, 1);
+            fprintf(stderr, "[dist] batch [%zu, %zu): %u rows handed over\n",
+                    batch_begin, batch_end, n);
+        }
     }
 
     bool any_float_stats() const {

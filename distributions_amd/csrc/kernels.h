@@ -771,16 +771,32 @@ __global__ __launch_bounds__(kBlock) void k_rows_wave(SweepParams P) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // ... their total in index order (random.cc:100-103)
+        // ... their total in index order (random.cc:100-103).  The serial
+        // recurrences take 64 entries per LDS read and walk them by
+        // v_readlane, so the dependent chain is the add alone, not an LDS
+        // round trip per entry.
         float total = 0.f;
-        for (int k = 0; k < Kl; ++k) total += sl[k];
-        // sample_from_likelihoods (random.hpp:316-333)
-        float t = total * batch_row_unif01(P, row);
-        int g2 = Kl - 1;
-        for (int k = 0; k < Kl; ++k) {
-            t -= sl[k];
-            if (t <= 0.f) { g2 = k; break; }
+        for (int k0 = 0; k0 < Kl; k0 += 64) {
+            const float mine = (k0 + lane < Kl) ? sl[k0 + lane] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 64; ++j)
+                total += u2f((uint32_t)__builtin_amdgcn_readlane(
+                    (int)f2u(mine), j));   // + 0.f beyond Kl: exact
         }
+        // sample_from_likelihoods (random.hpp:316-333): t never increases,
+        // so the index is the number of entries that leave t above zero
+        float t = total * batch_row_unif01(P, row);
+        int g2 = 0;
+        for (int k0 = 0; k0 < Kl && t > 0.f; k0 += 64) {
+            const float mine = (k0 + lane < Kl) ? sl[k0 + lane] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 64; ++j) {
+                t -= u2f((uint32_t)__builtin_amdgcn_readlane(
+                    (int)f2u(mine), j));
+                g2 += (t > 0.f) ? 1 : 0;
+            }
+        }
+        g2 = g2 < Kl - 1 ? g2 : Kl - 1;
         if (rs.singleton && g2 == rs.g) g2 = K - 1;   // slot g held group K-1
         if (lane == 0) {
             P.old_packed[out] = (uint32_t)rs.g;
