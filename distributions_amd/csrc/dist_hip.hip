@@ -681,6 +681,24 @@ struct Gibbs {
             c->dirty = false;
         }
     }
+    // A cached range's position-ordered assignments go stale when rows of the
+    // range are re-assigned through any other path (another batch tiling, the
+    // sequential chain): such caches are written back and dropped.
+    void drop_overlapping_caches(size_t r0, size_t r1, bool keep_exact) {
+        for (size_t i = 0; i < vs_cache.size();) {
+            VsCache & c = *vs_cache[i];
+            const bool overlap = c.r0 < r1 && r0 < c.r1;
+            const bool exact = c.r0 == r0 && c.r1 == r1;
+            if (!overlap || (exact && keep_exact)) { ++i; continue; }
+            if (c.dirty) {
+                const size_t n = c.r1 - c.r0;
+                LAUNCH(k_pos_scatter, n, c.assign_pos.p, c.sorted_rows.p,
+                       assign + c.r0, n);
+            }
+            sync();   // the cache's buffers are freed below
+            vs_cache.erase(vs_cache.begin() + (long)i);
+        }
+    }
     std::vector<std::unique_ptr<VsCache>> vs_cache;
     DeviceBuf<float> vsLA, vsLB, vsM, vsmB;
     DeviceBuf<int> vsArg;
@@ -1170,6 +1188,7 @@ struct Gibbs {
         upload_maps();
         SweepParams P = params(r0, r1, seed, draw_base);
         batch_value_sorted = use_value_sorted(r1 - r0);
+        drop_overlapping_caches(r0, r1, batch_value_sorted);
         if (!batch_value_sorted) flush_assign_pos();
         if (batch_value_sorted) {
             sample_value_sorted(P);

@@ -345,3 +345,31 @@ def test_low_entropy_clustering_sweeps_bit_exact(config, mode, slack):
     state = orc.gibbs_sequential(0, 300, st)
     assert gpu.sweep_sequential(0, 300, st) == state
     assert_same_state(orc, gpu, "low entropy %s sequential" % config)
+
+
+def test_changing_the_batch_tiling_between_sweeps():
+    """value-sorted batches cache their range's assignments by position; a
+    different tiling of the same rows (other batch size, the sequential
+    chain) must not leave a stale cache behind"""
+    from distributions_amd import engine
+    n, k = 6000, 24
+    osh, gsh, vals, assign = workloads.make("dd", n, k)
+    orc = ol.OracleMixture(1.0, 0.2, osh)
+    orc.init_from_assignments(vals, assign, k, 1)
+    gpu = engine.Gibbs(1.0, 0.2, gsh)
+    gpu.set_option("value_sorted", 2)
+    gpu.load_rows(vals, assign, k, 1)
+    L = ol.oracle()
+    seed = 9
+    st = L.orc_rng_seed(seed)
+    draw = 0
+    for step, batch in enumerate([1500, 1000, None, 1500, 6000, 1500]):
+        if batch is None:
+            state = orc.gibbs_sequential(100, 400, st)
+            assert gpu.sweep_sequential(100, 400, st) == state
+        else:
+            for b in range(0, n, batch):
+                orc.gibbs_batch(b, min(n, b + batch), st, draw)
+            gpu.sweep(0, n, batch, seed, draw_base=draw)
+            draw += n
+        assert_same_state(orc, gpu, "tiling step %d" % step)
