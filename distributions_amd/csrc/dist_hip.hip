@@ -701,6 +701,8 @@ struct Gibbs {
     }
     std::vector<std::unique_ptr<VsCache>> vs_cache;
     DeviceBuf<float> vsLA, vsLB, vsM, vsmB;
+    DeviceBuf<ChainResult> chain_result;
+    int sequential_mode = 1;   // 0: every row as a batch of one (diagnostic)
     DeviceBuf<int> vsArg;
     DeviceBuf<uint32_t> deferred, deferred_count;
     int value_sorted_mode = 1;   // 0 off, 1 auto, 2 always (when eligible)
@@ -1166,14 +1168,16 @@ struct Gibbs {
         void run() {
             hipLaunchKernelGGL((k_rows_wave<A, B, NF>), dim3(blocks),
                                dim3(kBlock),
-                               (size_t)(kBlock / 64) * K * sizeof(float),
+                               (size_t)(kBlock / 64) * ((K + 63) & ~63)
+                                   * sizeof(float),
                                stream(), *P);
             HIP_CHECK(hipGetLastError());
         }
     };
     // the wave-per-row kernel keeps K floats per wave in LDS
     bool wave_rows_fit() const {
-        return (size_t)(kBlock / 64) * K() * sizeof(float) <= 60 * 1024;
+        return (size_t)(kBlock / 64) * ((K() + 63) & ~63) * sizeof(float)
+               <= 60 * 1024;
     }
 
     void batch_sample(size_t r0, size_t r1, uint32_t seed, uint64_t draw_base) {
@@ -1485,14 +1489,69 @@ struct Gibbs {
         }
         sync();
     }
+    struct ChainLaunch {
+        SweepParams * P;
+        float * base;
+        int32_t * counts;
+        uint32_t * assign;
+        const uint32_t * p2g;
+        uint32_t rng;
+        ChainResult * res;
+        int K;
+        template <int A, int B, int NF>
+        void run() {
+            hipLaunchKernelGGL((k_chain_rows<A, B, NF>), dim3(1), dim3(kBlock),
+                               (size_t)((K + 63) & ~63) * sizeof(float),
+                               stream(), *P, base,
+                               counts, assign, p2g, rng, res);
+            HIP_CHECK(hipGetLastError());
+        }
+    };
+    // one row as a batch of one: the structural steps of the chain (a group
+    // vanishing with its last member) take this path
+    void sequential_row_as_batch(size_t r, uint32_t * rng_state) {
+        // draw index (draw_base + row_offset + r) must be 0 for this row
+        const uint64_t draw_base = (uint64_t)0 - (row_offset + r);
+        batch_sample(r, r + 1, *rng_state, draw_base);
+        batch_apply_local();
+        batch_finish();
+        *rng_state = lcg_mulmod(*rng_state, 16807u);
+    }
     void sweep_sequential(size_t r0, size_t r1, uint32_t * rng_state) {
-        for (size_t r = r0; r < r1; ++r) {
-            // draw index (draw_base + row_offset + r) must be 0 for this row
-            const uint64_t draw_base = (uint64_t)0 - (row_offset + r);
-            batch_sample(r, r + 1, *rng_state, draw_base);
-            batch_apply_local();
+        DIST_REQUIRE(!batch_open, "previous batch not finished");
+        DIST_REQUIRE(r0 <= r1 && r1 <= n_rows, "bad row range");
+        size_t r = r0;
+        while (r < r1) {
+            if ((size_t)((K() + 63) & ~63) * sizeof(float) > 60 * 1024
+                || sequential_mode == 0) {   // scores do not fit one LDS strip
+                sequential_row_as_batch(r, rng_state);
+                r += 1;
+                continue;
+            }
+            // the device-resident chain, up to its first structural step
+            drop_overlapping_caches(r, r1, false);
+            flush_assign_pos();
+            upload_maps();
+            SweepParams P = params(r, r1, 0, 0);
+            prepare(P, false);
+            chain_result.reserve(1, 0);
+            ChainLaunch L{&P, base.p, py.d_counts.p, assign, d_p2g.p,
+                          *rng_state, chain_result.p, K()};
+            dispatch(L);
+            ChainResult res;
+            chain_result.download(&res, 1);
+            // bookkeeping as after a batch: host mirrors, appended groups,
+            // caches rebuilt from the statistics
+            batch_begin = batch_end = r;
+            batch_value_sorted = false;
+            batch_open = true;
             batch_finish();
-            *rng_state = lcg_mulmod(*rng_state, 16807u);
+            *rng_state = res.rng_state;
+            r += res.rows_done;
+            if (res.event == 1) {
+                sequential_row_as_batch(r, rng_state);
+                r += 1;
+            }
         }
         sync();
     }
@@ -2286,6 +2345,11 @@ int dist_gibbs_set_option(dist_gibbs_t * g, const char * name, int value) {
         if (key == "value_sorted") {
             DIST_REQUIRE(value >= 0 && value <= 2, "value_sorted: 0, 1 or 2");
             g->impl->value_sorted_mode = value;
+        } else if (key == "sequential_chain") {
+            // 1 (default): the device-resident chain kernel; 0: every row
+            // as a batch of one
+            DIST_REQUIRE(value == 0 || value == 1, "sequential_chain: 0 or 1");
+            g->impl->sequential_mode = value;
         } else {
             throw Error("unknown option: " + key);
         }

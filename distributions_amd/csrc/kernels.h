@@ -716,6 +716,57 @@ __global__ __launch_bounds__(kBlock) void k_sweep_sample(SweepParams P) {
     }
 }
 
+// The two order-sensitive recurrences over a likelihood strip in LDS, computed
+// redundantly by every lane of a wave (uniform-address LDS reads broadcast):
+//   total = ((l_0 + l_1) + l_2) + ...              random.cc:100-103
+//   t = total * u; t -= l_k until t <= 0           random.hpp:316-333
+// The strip holds `n` entries followed by zeros up to a multiple of 64 (adding
+// or subtracting +0 is exact).  64 entries arrive as 16 ds_read_b128, so the
+// dependent chain is the VALU add alone.  t never increases: the scan walks
+// whole chunks and replays only the chunk in which t crosses zero.
+__device__ __forceinline__ float strip_total(const float * strip, int n) {
+    float total = 0.f;
+    for (int k0 = 0; k0 < n; k0 += 64) {
+        float4 v[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+            v[q] = *reinterpret_cast<const float4 *>(strip + k0 + 4 * q);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            total += v[q].x; total += v[q].y; total += v[q].z; total += v[q].w;
+        }
+    }
+    return total;
+}
+__device__ __forceinline__ int strip_sample(const float * strip, int n,
+                                            float t) {
+    for (int k0 = 0; k0 < n; k0 += 64) {
+        float4 v[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+            v[q] = *reinterpret_cast<const float4 *>(strip + k0 + 4 * q);
+        const float t0 = t;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            t -= v[q].x; t -= v[q].y; t -= v[q].z; t -= v[q].w;
+        }
+        if (!(t > 0.f)) {   // crossed inside this chunk: replay it, counting
+            float tt = t0;
+            int steps = 0;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                tt -= v[q].x; steps += tt > 0.f ? 1 : 0;
+                tt -= v[q].y; steps += tt > 0.f ? 1 : 0;
+                tt -= v[q].z; steps += tt > 0.f ? 1 : 0;
+                tt -= v[q].w; steps += tt > 0.f ? 1 : 0;
+            }
+            const int k = k0 + steps;
+            return k < n - 1 ? k : n - 1;
+        }
+    }
+    return n - 1;
+}
+
 // One WAVE per row, for the rows that come one at a time: the hand-overs of
 // the value-sorted kernel, tiny batches, the sequential chain.  Lanes score 64
 // slots at once (coalesced cache reads) and exponentiate them in parallel into
@@ -735,7 +786,7 @@ __global__ __launch_bounds__(kBlock) void k_rows_wave(SweepParams P) {
     const int K = P.K;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    float * sl = wave_lds + (size_t)wave * K;
+    float * sl = wave_lds + (size_t)wave * ((K + 63) & ~63);
 
     const size_t n_items = P.row_list ? (size_t)*P.row_list_count
                                       : P.row_end - P.row_begin;
@@ -766,43 +817,183 @@ __global__ __launch_bounds__(kBlock) void k_rows_wave(SweepParams P) {
             m = o > m ? o : m;
         }
         // scores_to_likelihoods: the exponentials in parallel ...
-        for (int k = lane; k < Kl; k += 64)
-            sl[k] = fast_exp_nonpos(sl[k] - m, s_exp, ea, eb);
+        for (int k = lane; k < ((Kl + 63) & ~63); k += 64)
+            sl[k] = k < Kl ? fast_exp_nonpos(sl[k] - m, s_exp, ea, eb) : 0.f;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // ... their total in index order (random.cc:100-103).  The serial
-        // recurrences take 64 entries per LDS read and walk them by
-        // v_readlane, so the dependent chain is the add alone, not an LDS
-        // round trip per entry.
-        float total = 0.f;
-        for (int k0 = 0; k0 < Kl; k0 += 64) {
-            const float mine = (k0 + lane < Kl) ? sl[k0 + lane] : 0.f;
-#pragma unroll
-            for (int j = 0; j < 64; ++j)
-                total += u2f((uint32_t)__builtin_amdgcn_readlane(
-                    (int)f2u(mine), j));   // + 0.f beyond Kl: exact
-        }
-        // sample_from_likelihoods (random.hpp:316-333): t never increases,
-        // so the index is the number of entries that leave t above zero
-        float t = total * batch_row_unif01(P, row);
-        int g2 = 0;
-        for (int k0 = 0; k0 < Kl && t > 0.f; k0 += 64) {
-            const float mine = (k0 + lane < Kl) ? sl[k0 + lane] : 0.f;
-#pragma unroll
-            for (int j = 0; j < 64; ++j) {
-                t -= u2f((uint32_t)__builtin_amdgcn_readlane(
-                    (int)f2u(mine), j));
-                g2 += (t > 0.f) ? 1 : 0;
-            }
-        }
-        g2 = g2 < Kl - 1 ? g2 : Kl - 1;
+        // ... their total in index order, then the scan (strip_total /
+        // strip_sample: every lane computes the same)
+        const float total = strip_total(sl, Kl);
+        int g2 = strip_sample(sl, Kl, total * batch_row_unif01(P, row));
         if (rs.singleton && g2 == rs.g) g2 = K - 1;   // slot g held group K-1
         if (lane == 0) {
             P.old_packed[out] = (uint32_t)rs.g;
             P.new_packed[out] = (uint32_t)g2;
         }
         __builtin_amdgcn_wave_barrier();   // before the strip is reused
+    }
+}
+
+// The reference's sequential chain, resident on the device: ONE workgroup
+// walks rows [row_begin, row_end) one after the other -- remove the row from
+// its group, score every group against the updated state, sample, add
+// (examples/mixture/main.py:236-244 over mixture.hpp:376-425) -- so a row costs
+// a few barriers instead of a dozen launches and a host round trip.  The kernel
+// handles the rows that leave the group set alone and returns to the host at
+// the first structural step, which the host performs with the batch code:
+//   event 1: the next row is alone in its group (the group would vanish);
+//            nothing has been done for it;
+//   event 2: the last processed row filled an empty group (a new empty group
+//            must be appended, clustering.hpp:163-176 / mixture.hpp:361-368).
+// base[k] is the driver's score with the row taken out (k_sweep_prepare);
+// the kernel keeps it, the group sizes, the statistics and the caches current.
+struct ChainResult {
+    uint32_t rng_state;
+    uint32_t rows_done;
+    int event;
+    int pad;
+};
+
+// Group::add_value / remove_value plus the cache refresh of that group
+// (k_slave_value_op as a device function).  Categorical kinds take the loads
+// up front and the logarithms from the LDS copy of the table, so the update
+// is one memory round trip, not five dependent ones.
+__device__ __forceinline__ void chain_value_op(const SlaveView & s, int k,
+                                               uint32_t value, bool add,
+                                               const uint32_t * log_tab) {
+    if (is_cat(s.kind)) {
+        const size_t cell = (size_t)k * s.dim + value;
+        const int c2 = s.cnt[cell] + (add ? 1 : -1);
+        const int n2 = s.i0[k] + (add ? 1 : -1);
+        const float prior = s.prior[value];
+        s.cnt[cell] = c2;
+        s.i0[k] = n2;
+        // dd.hpp:458-467 / dpd.hpp:458-470
+        s.S[(size_t)value * s.cap + k] = fast_log_t(prior + (float)c2, log_tab);
+        s.c0[k] = fast_log_t(s.alpha_sum + (float)n2, log_tab);
+        return;
+    }
+    Stats st = load_stats(s, k);
+    if (add) stats_add(s.kind, st, value); else stats_remove(s.kind, st, value);
+    store_stats(s, k, st);
+    refresh_scalar_entry(s, k);
+}
+
+template <int KIND0, int KIND1, int NF>
+__global__ __launch_bounds__(kBlock) void k_chain_rows(
+        SweepParams P, float * __restrict__ base, int32_t * counts,
+        uint32_t * assign, const uint32_t * __restrict__ p2g,
+        uint32_t rng_state, ChainResult * result) {
+    extern __shared__ float chain_lds[];   // [K] scores, then likelihoods
+    __shared__ uint32_t s_exp[1024];
+    __shared__ uint32_t s_log[16384];      // FastLog table: the per-row cache
+    __shared__ float s_red[kBlock / 64];   // refreshes run on one thread
+    __shared__ int s_g2, s_n2;
+    for (int i = threadIdx.x; i < 1024; i += kBlock)
+        s_exp[i] = g_tables_dev.exp_table[i];
+    for (int i = threadIdx.x; i < 16384; i += kBlock)
+        s_log[i] = g_tables_dev.log_table[i];
+    __syncthreads();
+    const float ea = u2f(g_tables_dev.exp_ab[0]);
+    const float eb = u2f(g_tables_dev.exp_ab[1]);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int K = P.K;
+    const int nf = NF > 0 ? NF : P.F;
+    const float shift = P.scalars->shift;
+    float * sc = chain_lds;
+    uint32_t done = 0;
+    int event = 0;
+    for (size_t row = P.row_begin; row < P.row_end; ++row) {
+        const int g = P.g2p[assign[row]];
+        const int n_g = counts[g];
+        if (n_g == 1) { event = 1; break; }
+        uint32_t x[kMaxF];
+        float lf[kMaxF];
+        int kind[kMaxF];
+#pragma unroll
+        for (int f = 0; f < (NF > 0 ? NF : kMaxF); ++f) {
+            if (f >= nf) break;
+            kind[f] = f == 0 && KIND0 >= 0 ? KIND0
+                    : f == 1 && KIND1 >= 0 ? KIND1 : P.feat[f].kind;
+            x[f] = P.values[f][row];
+            lf[f] = kind[f] == DIST_GP ? fast_log_factorial(x[f]) : 0.f;
+        }
+        // remove_value (mixture.hpp:94-122,386-398; clustering.hpp:178-193)
+        if (tid == 0) {
+            counts[g] = n_g - 1;
+            base[g] = P.cluster == 0
+                ? fast_log_t((float)(n_g - 1) - P.d, s_log) + shift
+                : cluster_own_score(P, n_g - 1, shift);
+            for (int f = 0; f < nf; ++f) {
+                SlaveView v = P.feat[f];
+                v.kind = kind[f];
+                chain_value_op(v, g, x[f], false, s_log);
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+        // score_value: driver, then every feature accumulates
+        float m = -INFINITY;
+        for (int k = tid; k < K; k += kBlock) {
+            float s = base[k];
+#pragma unroll
+            for (int f = 0; f < (NF > 0 ? NF : kMaxF); ++f) {
+                if (f >= nf) break;
+                SlaveView v = P.feat[f];
+                v.kind = kind[f];
+                s = accumulate(kind[f], s, load_entry(v, k, x[f]), x[f],
+                               lf[f], v.p);
+            }
+            sc[k] = s;
+            m = s > m ? s : m;
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            const float o = __shfl_xor(m, off);
+            m = o > m ? o : m;
+        }
+        if (lane == 0) s_red[wave] = m;
+        __syncthreads();
+        m = s_red[0];
+#pragma unroll
+        for (int w = 1; w < kBlock / 64; ++w) m = s_red[w] > m ? s_red[w] : m;
+        // scores_to_likelihoods (random.cc:94-106): exponentials in parallel
+        for (int k = tid; k < ((K + 63) & ~63); k += kBlock)
+            sc[k] = k < K ? fast_exp_nonpos(sc[k] - m, s_exp, ea, eb) : 0.f;
+        __syncthreads();
+        if (wave == 0) {
+            const float total = strip_total(sc, K);
+            rng_state = lcg_mulmod(rng_state, 16807u);
+            const int g2 = strip_sample(sc, K, total * lcg_unif01(rng_state));
+            if (lane == 0) {
+                s_g2 = g2;
+                s_n2 = counts[g2];
+            }
+        }
+        __syncthreads();
+        const int g2 = s_g2, n2 = s_n2;
+        // add_value (mixture.hpp:73-92,376-384; clustering.hpp:163-176)
+        if (tid == 0) {
+            counts[g2] = n2 + 1;
+            base[g2] = P.cluster == 0
+                ? fast_log_t((float)(n2 + 1) - P.d, s_log) + shift
+                : cluster_own_score(P, n2 + 1, shift);
+            for (int f = 0; f < nf; ++f) {
+                SlaveView v = P.feat[f];
+                v.kind = kind[f];
+                chain_value_op(v, g2, x[f], true, s_log);
+            }
+            assign[row] = p2g[g2];
+        }
+        __threadfence_block();
+        __syncthreads();
+        done += 1;
+        if (n2 == 0) { event = 2; break; }
+    }
+    if (tid == 0) {
+        result->rng_state = rng_state;
+        result->rows_done = done;
+        result->event = event;
     }
 }
 
