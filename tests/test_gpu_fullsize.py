@@ -135,3 +135,26 @@ def test_c5_shape_dpd_8192_groups_streamed_tables():
     gpu.sweep(0, n, 60_000, seed, draw_base=0)
     assert tuple(gpu.path_counts()) == (2, 0)   # value-sorted, generic
     assert_same_state(orc, gpu, "dpd V=10000 K=8192")
+
+
+def test_more_groups_than_the_lds_paths_hold():
+    """K = 16 000 groups: beyond the LDS-aggregated apply kernel (K*4 B > 60
+    KiB), the wave-per-row strip and the device-resident chain; the
+    direct-atomics, lane-per-row and batch-of-one paths take over"""
+    from distributions_amd import engine
+    n, k, dim = 48_000, 16_000, 4
+    osh, gsh, vals, assign = workloads.make("dd", n, k, dim=dim)
+    orc = ol.OracleMixture(1.0, 0.2, osh)
+    orc.init_from_assignments(vals, assign, k, 1)
+    gpu = engine.Gibbs(1.0, 0.2, gsh)
+    gpu.set_option("value_sorted", 2)
+    gpu.load_rows(vals, assign, k, 1)
+    seed = 5
+    st = ol.oracle().orc_rng_seed(seed)
+    for b in range(0, n, 16_000):
+        orc.gibbs_batch(b, b + 16_000, st, 0)
+    gpu.sweep(0, n, 16_000, seed, draw_base=0)
+    assert_same_state(orc, gpu, "K=16000 batches")
+    state = orc.gibbs_sequential(0, 40, st)
+    assert gpu.sweep_sequential(0, 40, st) == state
+    assert_same_state(orc, gpu, "K=16000 sequential")
