@@ -626,8 +626,10 @@ struct Gibbs {
     std::vector<const uint32_t *> values;   // device pointers
     DeviceBuf<uint32_t> own_assign;
     uint32_t * assign = nullptr;             // device, global ids
-    DeviceBuf<int32_t> d_g2p;
-    DeviceBuf<uint32_t> d_p2g;
+    DeviceBuf<uint32_t> d_maps;             // see upload_maps
+    std::vector<uint32_t> maps_host;
+    const uint32_t * d_p2g_ptr = nullptr;
+    const int32_t * d_g2p_ptr = nullptr;
     bool maps_dirty = true;
 
     DeviceBuf<uint32_t> old_packed, new_packed;
@@ -732,10 +734,18 @@ struct Gibbs {
     int F() const { return (int)feats.size(); }
     int K() const { return py.K(); }
 
+    // both id maps travel in one copy: [p2g (capacity slots) | g2p]
     void upload_maps() {
         if (!maps_dirty) return;
-        d_g2p.upload(tracker.g2p.data(), tracker.g2p.size());
-        d_p2g.upload(tracker.p2g.data(), tracker.p2g.size());
+        const size_t np = tracker.p2g.size(), ng = tracker.g2p.size();
+        const size_t pcap = grow_capacity(np);
+        maps_host.resize(pcap + ng);
+        std::copy(tracker.p2g.begin(), tracker.p2g.end(), maps_host.begin());
+        for (size_t i = 0; i < ng; ++i)
+            maps_host[pcap + i] = (uint32_t)tracker.g2p[i];
+        d_maps.upload(maps_host.data(), maps_host.size());
+        d_p2g_ptr = d_maps.p;
+        d_g2p_ptr = reinterpret_cast<const int32_t *>(d_maps.p + pcap);
         maps_dirty = false;
     }
 
@@ -760,7 +770,7 @@ struct Gibbs {
         P.dataset_size = dataset_size;
         P.sample_size = py.sample_size;
         P.assign = assign;
-        P.g2p = d_g2p.p;
+        P.g2p = d_g2p_ptr;
         P.old_packed = old_packed.p;
         P.new_packed = new_packed.p;
         P.row_begin = r0;
@@ -914,7 +924,7 @@ struct Gibbs {
             LAUNCH(k_load_counts, n, P, live_image(), packed_dev);
             replay_sorted(nullptr, packed_dev, 0, n);
             // assignments become global ids (identity map right after init)
-            LAUNCH(k_packed_to_global, n, packed_dev, d_p2g.p, assign, n);
+            LAUNCH(k_packed_to_global, n, packed_dev, d_p2g_ptr, assign, n);
         }
         refresh_host_counts();
         rebuild_caches();
@@ -1347,7 +1357,7 @@ struct Gibbs {
 #define VS_APPLY(KIND, SORT, LDS)                                            \
             hipLaunchKernelGGL((k_vs_apply<KIND, SORT>), grid, block, LDS,   \
                                stream(), P, img, c.chunks.p,                 \
-                               c.sorted_rows.p, d_p2g.p, c.assign_pos.p)
+                               c.sorted_rows.p, d_p2g_ptr, c.assign_pos.p)
             if (bb && sort) VS_APPLY(DIST_BB, true, lds_sort);
             else if (bb) VS_APPLY(DIST_BB, false, lds_plain);
             else if (gp && sort) VS_APPLY(DIST_GP, true, lds_sort);
@@ -1370,12 +1380,12 @@ struct Gibbs {
             moves_in_row_order = true;
             P.old_packed = old_row.p;
             P.new_packed = new_row.p;
-            LAUNCH(k_apply_moves, n, P, img, d_p2g.p, assign);
+            LAUNCH(k_apply_moves, n, P, img, d_p2g_ptr, assign);
             // assign[] is now current: refresh the position copy
             LAUNCH(k_pos_gather, n, assign + batch_begin, c.sorted_rows.p,
                    c.assign_pos.p, n);
         } else {
-            LAUNCH(k_apply_moves, n, P, img, d_p2g.p, assign);
+            LAUNCH(k_apply_moves, n, P, img, d_p2g_ptr, assign);
         }
     }
     void batch_apply_local() {
@@ -1535,7 +1545,7 @@ struct Gibbs {
             SweepParams P = params(r, r1, 0, 0);
             prepare(P, false);
             chain_result.reserve(1, 0);
-            ChainLaunch L{&P, base.p, py.d_counts.p, assign, d_p2g.p,
+            ChainLaunch L{&P, base.p, py.d_counts.p, assign, d_p2g_ptr,
                           *rng_state, chain_result.p, K()};
             dispatch(L);
             ChainResult res;

@@ -1359,7 +1359,7 @@ __global__ __launch_bounds__(kBlock) void k_vs_sample(
 //   counts[k] += d[k];  DD/DPD: count_sum[k] += d[k], cnt[k][x] += d[k];
 //   BB: (x ? heads : tails)[k] += d[k]
 // (6 global atomics per moved row become <= 3 per touched group and chunk).
-constexpr int kVsApplyRows = 2048;
+constexpr int kVsApplyRows = 4096;
 
 // SORT: also reorder the chunk's rows by their NEW group (LDS counting sort),
 // in place in sorted_rows.  Next time this batch range is sampled, the 64
