@@ -64,6 +64,7 @@ cdef extern from "distributions_hip.h" nogil:
     int dist_le_score_add_value(int, int, int, int, int, float *)
     int dist_le_score_remove_value(int, int, int, int, int, float *)
     int dist_le_log_partition_function(int, float *)
+    int dist_le_sample_assignments(int, int, uint32_t *, int *)
     int dist_le_score_counts(int, const int *, size_t, float *)
     dist_le_mixture_t * dist_le_mixture_create()
     void dist_le_mixture_destroy(dist_le_mixture_t *)
@@ -581,6 +582,14 @@ def le_log_partition_function(int sample_size):
     cdef float out = 0
     check(dist_le_log_partition_function(sample_size, &out))
     return out
+
+
+def le_sample_assignments(int dataset_size, int size, uint32_t rng_state):
+    """-> (int32 assignments, new rng state)"""
+    cdef cnp.ndarray[cnp.int32_t, ndim=1] out = np.zeros(max(size, 1), np.int32)
+    cdef uint32_t s = rng_state
+    check(dist_le_sample_assignments(dataset_size, size, &s, <int *> out.data))
+    return out[:size], s
 
 
 def le_score_counts(int dataset_size, counts):

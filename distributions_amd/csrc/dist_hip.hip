@@ -1887,6 +1887,64 @@ static float le_score_counts(int dataset_size, const int * counts, size_t n) {
     score -= le_log_partition_function((int)sample_size);
     return score;
 }
+// vector_sum (vector_math.cc:85-93) in the association of the reference's
+// release build: four lane accumulators (element i in lane i mod 4) over the
+// first 4*floor(n/4) elements, (lane1 + lane3) + (lane0 + lane2), then the
+// tail in order; fewer than four elements in order
+static float vector_sum_as_built(size_t n, const float * x) {
+    if (n < 4) {
+        float s = 0.f;
+        for (size_t i = 0; i < n; ++i) s += x[i];
+        return s;
+    }
+    float lane[4] = {0.f, 0.f, 0.f, 0.f};
+    const size_t body = n & ~(size_t)3;
+    for (size_t i = 0; i < body; i += 4)
+        for (int j = 0; j < 4; ++j) lane[j] += x[i + j];
+    float s = (lane[1] + lane[3]) + (lane[0] + lane[2]);
+    for (size_t i = body; i < n; ++i) s += x[i];
+    return s;
+}
+// LowEntropy::sample_assignments (clustering.cc:250-283): a sequential draw
+// over a growing likelihood vector -- host code, like the reference's and
+// like dist_py_sample_assignments
+int dist_le_sample_assignments(int dataset_size, int sample_size,
+                               uint32_t * rng_state, int * assignments) {
+    return guarded([&] {
+        DIST_REQUIRE(sample_size >= 0 && sample_size <= dataset_size,
+                     "expected 0 <= sample_size <= dataset_size");
+        ensure_host_tables();
+        std::vector<int> counts;
+        std::vector<float> likelihoods;
+        counts.reserve(100);
+        likelihoods.reserve(100);
+        int size = 0;
+        for (int i = 0; i < sample_size; ++i) {
+            const float likelihood_empty =
+                fast_exp(le_score_add_value(dataset_size, 0, size, 1));
+            if (counts.empty() || counts.back()) {
+                counts.push_back(0);
+                likelihoods.push_back(likelihood_empty);
+            } else {
+                likelihoods.back() = likelihood_empty;
+            }
+            // sample_from_likelihoods(rng, likelihoods), random.hpp:316-341
+            const float total =
+                vector_sum_as_built(likelihoods.size(), likelihoods.data());
+            float t = total * lcg_unif01(dist_rng_next(rng_state));
+            int assign = (int)likelihoods.size() - 1;
+            for (size_t k = 0; k < likelihoods.size(); ++k) {
+                t -= likelihoods[k];
+                if (t <= 0) { assign = (int)k; break; }
+            }
+            assignments[i] = assign;
+            counts[assign] += 1;
+            size += 1;
+            likelihoods[assign] =
+                fast_exp(le_score_add_value(dataset_size, counts[assign], 0, 1));
+        }
+    });
+}
 int dist_le_score_counts(int dataset_size, const int * counts,
                          size_t group_count, float * out) {
     return guarded(

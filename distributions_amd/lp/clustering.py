@@ -206,6 +206,8 @@ class LowEntropy(object):
         return _core.le_log_partition_function(int(sample_size))
 
     def sample_assignments(self, size):
-        raise NotImplementedError(
-            "LowEntropy.sample_assignments (clustering.cc:250-283) is "
-            "initialisation code outside the row-update path")
+        from .random import get_rng
+        rng = get_rng()
+        out, rng.state = _core.le_sample_assignments(self.dataset_size,
+                                                     int(size), rng.state)
+        return [int(a) for a in out]

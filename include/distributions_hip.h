@@ -118,7 +118,8 @@ int dist_py_score_counts(float alpha, float d, const int * counts,
  * dataset_size is the model; nonempty_group_count is accepted and unused, as
  * in the reference.  score_counts: clustering.cc:229-248 (n log n terms summed
  * in binary64, 1e-6 relative); log_partition_function: clustering.cc:204-215.
- * sample_assignments is not provided (initialisation only). */
+ * sample_assignments: clustering.cc:250-283, host-side like the reference
+ * (its totals follow the release build's vector_sum association). */
 int dist_le_score_add_value(int dataset_size, int group_size,
                             int nonempty_group_count, int sample_size,
                             int empty_group_count, float * out);
@@ -126,6 +127,8 @@ int dist_le_score_remove_value(int dataset_size, int group_size,
                                int nonempty_group_count, int sample_size,
                                int empty_group_count, float * out);
 int dist_le_log_partition_function(int sample_size, float * out);
+int dist_le_sample_assignments(int dataset_size, int sample_size,
+                               uint32_t * rng_state, int * assignments_out);
 int dist_le_score_counts(int dataset_size, const int * counts,
                          size_t group_count, float * out);
 /* LowEntropy::Mixture = MixtureDriver<LowEntropy, int> (mixture.hpp:48-163) */

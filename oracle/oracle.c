@@ -635,6 +635,26 @@ static float feat_score_value_group(const feat * f, int k, uint32_t value) {
 }
 
 /* ------------------------------------------------------------------------ */
+/* vector_sum (vector_math.cc:85-93) as the release build executes it: the
+ * -ffast-math loop is vectorised into four lane accumulators (element i goes
+ * to lane i mod 4) over the first 4*floor(n/4) elements, combined as
+ * (lane1 + lane3) + (lane0 + lane2), and the tail is added in order; fewer
+ * than four elements are summed in order.  Pinned against oracle/_ref. */
+float orc_vector_sum(size_t n, const float * x) {
+    if (n < 4) {
+        float s = 0.f;
+        for (size_t i = 0; i < n; ++i) s += x[i];
+        return s;
+    }
+    float lane[4] = {0.f, 0.f, 0.f, 0.f};
+    const size_t body = n & ~(size_t)3;
+    for (size_t i = 0; i < body; i += 4)
+        for (int j = 0; j < 4; ++j) lane[j] += x[i + j];
+    float s = (lane[1] + lane[3]) + (lane[0] + lane[2]);
+    for (size_t i = body; i < n; ++i) s += x[i];
+    return s;
+}
+
 /* Clustering<int>::LowEntropy (clustering.hpp:245-331, clustering.cc:186-283) */
 #include "le_table.h"
 
@@ -699,9 +719,38 @@ float orc_le_score_counts(int dataset_size, const int * counts, size_t size) {
     orc_ftz_restore(saved);
     return score;
 }
-/* LowEntropy::sample_assignments (clustering.cc:250-283) draws through the
- * two-argument sample_from_likelihoods, whose total is the re-associated
- * vector_sum of the release build: not restated (initialisation only). */
+/* LowEntropy::sample_assignments (clustering.cc:250-283); the two-argument
+ * sample_from_likelihoods takes its total from vector_sum (random.hpp:335-341);
+ * one engine step per row */
+void orc_le_sample_assignments(int dataset_size, int sample_size,
+                               uint32_t * rng_state, int * assignments) {
+    unsigned saved = orc_ftz_enable();
+    int * counts = malloc(sizeof(int) * (size_t)(sample_size + 2));
+    float * likelihoods = malloc(sizeof(float) * (size_t)(sample_size + 2));
+    int n = 0;
+    int size = 0;
+    for (int i = 0; i < sample_size; ++i) {
+        float likelihood_empty = orc_fast_exp(
+            orc_le_score_add_value(dataset_size, 0, 0, size, 1));
+        if (n == 0 || counts[n - 1]) {
+            counts[n] = 0;
+            likelihoods[n] = likelihood_empty;
+            n += 1;
+        } else {
+            likelihoods[n - 1] = likelihood_empty;
+        }
+        float total = orc_vector_sum((size_t)n, likelihoods);
+        int assign = (int)orc_sample_from_likelihoods(rng_state, (size_t)n,
+                                                      likelihoods, total);
+        assignments[i] = assign;
+        counts[assign] += 1;
+        size += 1;
+        likelihoods[assign] = orc_fast_exp(
+            orc_le_score_add_value(dataset_size, counts[assign], 0, 0, 1));
+    }
+    free(counts); free(likelihoods);
+    orc_ftz_restore(saved);
+}
 
 /* ------------------------------------------------------------------------ */
 /* driver: clustering.hpp:126-234 over mixture.hpp:48-163                   */
@@ -1069,7 +1118,7 @@ float orc_group_score_data(const orc_shared * sh, const uint32_t * group) {
 
 /* MixtureDataScorer::score_data (dd.hpp:250-256,287-318; bb.hpp:207-229;
  * gp.hpp:220-241; nich.hpp:262-288; dpd.hpp:344-374), float accumulation in
- * the reference's loop order (DD's final vector_sum taken in index order) */
+ * the reference's loop order (DD's final vector_sum as orc_vector_sum) */
 static float slave_score_data_with(const feat * f, const orc_shared * sh,
                                    const float * betas);
 float orc_mix_slave_score_data(const orc_mix * m, int fi) {
@@ -1099,7 +1148,7 @@ static float slave_score_data_with(const feat * f, const orc_shared * sh,
             scores[dim] += shared_part[dim]
                          - orc_fast_lgamma(alpha_sum + (float)f->i0[k]);
         }
-        for (int i = 0; i <= dim; ++i) result += scores[i];
+        result = orc_vector_sum((size_t)dim + 1, scores);   /* _eval */
         free(scores); free(shared_part);
     } else if (sh->kind == ORC_DPD) {
         float alpha = sh->p[0];
@@ -1177,7 +1226,7 @@ static float slave_score_data_with(const feat * f, const orc_shared * sh,
 /* score_data_grid (mixture.hpp:238-247: one score_data per candidate Shared;
  * DirichletDiscrete's incremental form, dd.hpp:259-345: _init on the first
  * candidate, then per candidate only the changed alphas are re-accumulated,
- * alpha_sum carried in binary64; _eval's vector_sum taken in index order) */
+ * alpha_sum carried in binary64; _eval through orc_vector_sum) */
 void orc_mix_slave_score_data_grid(const orc_mix * m, int fi,
                                    const orc_shared * shareds, size_t n,
                                    float * scores_out) {
@@ -1210,9 +1259,7 @@ void orc_mix_slave_score_data_grid(const orc_mix * m, int fi,
         scores[dim] += shared_part[dim]
                      - orc_fast_lgamma(alpha_sum_f + (float)f->i0[k]);
     }
-    float total = 0;
-    for (int v = 0; v <= dim; ++v) total += scores[v];
-    scores_out[0] = total;
+    scores_out[0] = orc_vector_sum((size_t)dim + 1, scores);
     for (size_t i = 1; i < n; ++i) {
         for (int v = 0; v < dim; ++v) {
             const float old_alpha = shareds[i - 1].alphas[v];
@@ -1233,9 +1280,7 @@ void orc_mix_slave_score_data_grid(const orc_mix * m, int fi,
                              - orc_fast_lgamma(alpha_sum + (float)f->i0[k]);
             }
         }
-        total = 0;
-        for (int v = 0; v <= dim; ++v) total += scores[v];
-        scores_out[i] = total;
+        scores_out[i] = orc_vector_sum((size_t)dim + 1, scores);
     }
     free(scores); free(shared_part);
     orc_ftz_restore(saved);

@@ -111,7 +111,10 @@ float orc_le_score_remove_value(int dataset_size, int group_size,
                                 int empty_group_count);
 float orc_le_log_partition_function(int sample_size);
 float orc_le_score_counts(int dataset_size, const int * counts, size_t size);
+void orc_le_sample_assignments(int dataset_size, int sample_size,
+                               uint32_t * rng_state, int * assignments);
 void orc_mix_set_low_entropy(orc_mix * m, int dataset_size);
+float orc_vector_sum(size_t n, const float * x);   /* vector_math.cc:85-93 */
 
 orc_mix * orc_mix_create(float alpha, float d, int n_features,
                          const orc_shared * shareds);

@@ -98,6 +98,24 @@ def vector_math(R):
     np.savez_compressed(os.path.join(HERE, "vector_math.npz"), **out)
 
 
+def vector_sum(R):
+    """vector_sum (vector_math.cc:85-93) of the release build: its
+    association is the vectoriser's, so the expected bits are recorded"""
+    R.ref_vector_sum.restype = ctypes.c_float
+    R.ref_vector_sum.argtypes = [ctypes.c_size_t, ctypes.c_void_p]
+    rng = np.random.default_rng(6)
+    out = {}
+    sizes = list(range(0, 20)) + [63, 64, 65, 257, 1000, 1001, 1002, 1003]
+    for n in sizes:
+        x = (rng.normal(size=max(n, 1)) * 10 ** rng.uniform(-3, 3)).astype(
+            np.float32)
+        out["n%d_x" % n] = x
+        out["n%d_sum" % n] = np.array(
+            [R.ref_vector_sum(n, x.ctypes.data)], np.float32).view(np.uint32)
+    out["sizes"] = np.array(sizes)
+    np.savez_compressed(os.path.join(HERE, "vector_sum.npz"), **out)
+
+
 def driver_tracker(R):
     """Random add/remove script; records every return flag and the state."""
     rng = np.random.default_rng(3)
@@ -280,6 +298,11 @@ if __name__ == "__main__":
     protobuf_schema()
     low_entropy_table()
     if "--schema-only" in sys.argv:
+        sys.exit(0)
+    if "--vector-sum-only" in sys.argv:
+        R = ol.ref()
+        assert R is not None, "build oracle/_ref first (make -C oracle ref)"
+        vector_sum(R)
         sys.exit(0)
     R = ol.ref()
     assert R is not None, "build oracle/_ref first (make -C oracle ref)"

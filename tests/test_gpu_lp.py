@@ -465,6 +465,21 @@ def test_low_entropy_model_and_mixture():
         got = model.score_counts(counts)
         assert abs(got - want) <= 1e-6 * (1 + abs(want)), (ex, got, want)
 
+    # sample_assignments (clustering.cc:250-283): the engine's draws, bit for bit
+    L.orc_le_sample_assignments.restype = None
+    L.orc_le_sample_assignments.argtypes = [i, i, ctypes.c_void_p,
+                                            ctypes.c_void_p]
+    for dataset_size, size in [(5, 5), (100, 60), (1000, 400), (10 ** 6, 300)]:
+        model = LowEntropy(dataset_size=dataset_size)
+        lprandom.seed(77)
+        got = model.sample_assignments(size)
+        state = ctypes.c_uint32(L.orc_rng_seed(77))
+        want = np.zeros(size, np.int32)
+        L.orc_le_sample_assignments(dataset_size, size, ctypes.byref(state),
+                                    want.ctypes.data)
+        assert got == want.tolist()
+        assert lprandom.get_rng().state == state.value
+
     model = LowEntropy(dataset_size=1000)
     nonempty_counts = [int(c) for c in rng.integers(1, 30, 7)]
     for empty_group_count in [1, 10]:

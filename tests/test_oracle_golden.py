@@ -110,6 +110,30 @@ def test_vector_math_matches_reference_goldens():
         assert L.orc_vector_max(n, io) == g["n%d_max" % n][0]
 
 
+def test_vector_sum_matches_reference_goldens():
+    """the release build's vector_sum (vectorised: four lane accumulators,
+    pairwise combine, tail in order) -- used by DirichletDiscrete's
+    score_data and by LowEntropy::sample_assignments"""
+    g = load("vector_sum.npz")
+    L = ol.oracle()
+    L.orc_vector_sum.restype = ctypes.c_float
+    L.orc_vector_sum.argtypes = [ctypes.c_size_t, ctypes.c_void_p]
+    for n in g["sizes"]:
+        x = np.ascontiguousarray(g["n%d_x" % n])
+        got = np.array([L.orc_vector_sum(int(n), x.ctypes.data)], np.float32)
+        assert got.view(np.uint32)[0] == g["n%d_sum" % n][0], n
+    R = ol.ref()
+    if R is not None:      # live against the compiled reference
+        R.ref_vector_sum.restype = ctypes.c_float
+        R.ref_vector_sum.argtypes = [ctypes.c_size_t, ctypes.c_void_p]
+        rng = np.random.default_rng(1)
+        for n in list(range(0, 70)) + [4097]:
+            x = rng.normal(size=max(n, 1)).astype(np.float32)
+            a = np.float32(L.orc_vector_sum(n, x.ctypes.data))
+            b = np.float32(R.ref_vector_sum(n, x.ctypes.data))
+            assert a.view(np.uint32) == b.view(np.uint32), n
+
+
 def test_driver_and_tracker_match_reference_goldens():
     """MixtureDriver (mixture.hpp:48-163) and MixtureIdTracker (:460-521):
     same return flags and same state after every step of the recorded

@@ -496,3 +496,38 @@ def test_low_entropy_driver_scores_are_score_add_value():
             500, int(c), 4, int(counts.sum()), 2))
     assert L.orc_mix_driver_add_value(m.h, 1) == 1      # an empty group filled
     assert L.orc_mix_size(m.h) == len(counts) + 1
+
+
+def test_low_entropy_sample_assignments_matches_score_counts():
+    """test_clustering.py:139-165 (test_sample_matches_score_counts): the
+    frequencies of sampled partitions follow exp(score_counts), at full size
+    where score_counts is exactly normalised"""
+    L = _le_sigs()
+    L.orc_le_sample_assignments.restype = None
+    L.orc_le_sample_assignments.argtypes = [
+        ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    from collections import Counter
+    size = 6
+    state = ctypes.c_uint32(L.orc_rng_seed(123))
+    n_samples = 20000
+    seen = Counter()
+    out = np.zeros(size, np.int32)
+    for _ in range(n_samples):
+        L.orc_le_sample_assignments(size, size, ctypes.byref(state),
+                                    out.ctypes.data)
+        # first-appearance labelling: group ids are 0..G-1 in order
+        assert out[0] == 0 and all(
+            out[i] <= out[:i].max() + 1 for i in range(1, size))
+        seen[tuple(out.tolist())] += 1
+    # every set partition of 6 elements (Bell(6) = 203) has probability
+    # exp(score_counts(shape)); compare by shape
+    by_shape = Counter()
+    for labels, count in seen.items():
+        shape = tuple(sorted(Counter(labels).values(), reverse=True))
+        by_shape[shape] += count
+    for shape in _partitions(size):
+        p = _set_partition_count(shape) * np.exp(
+            _le_score_counts(L, size, list(shape)))
+        got = by_shape[shape] / n_samples
+        assert abs(got - p) < 4 * np.sqrt(p * (1 - p) / n_samples) + 2e-3, (
+            shape, got, p)
