@@ -62,5 +62,23 @@ int main() {
     printf("groups %zu assignments", driver.size());
     for (int i = 0; i < 8; ++i) printf(" %zu", assignments[i]);
     printf("\n");
+
+    // either side of the update: a hyper-parameter grid in one call
+    // (mixture.hpp:433-438) and a group checkpointed in the reference's wire
+    // format (dd.hpp:94-111)
+    std::vector<Model::Shared> grid(3, shared);
+    grid[1].alphas[2] = 1.5f;
+    grid[2].alphas[2] = 1.5f;
+    grid[2].alphas[0] = 0.25f;
+    VectorFloat grid_scores(grid.size());
+    slave.score_data_grid(grid, grid_scores, rng);
+    printf("grid %.6f %.6f %.6f single %.6f\n", grid_scores[0], grid_scores[1],
+           grid_scores[2], slave.score_data(shared, rng));
+    Model::Group first = slave.groups(shared, 0);
+    const std::string wire = first.protobuf_dump(shared);
+    Model::Group back;
+    back.protobuf_load(shared, wire);
+    printf("wire %zu bytes roundtrip %s\n", wire.size(),
+           back.words == first.words ? "ok" : "MISMATCH");
     return 0;
 }

@@ -32,9 +32,16 @@ def test_shim_example_compiles_and_links():
 @pytest.mark.gpu
 def test_shim_example_reproduces_the_sequential_chain():
     build()
-    out = subprocess.check_output([EXE], text=True).split()
+    lines = subprocess.check_output([EXE], text=True).splitlines()
+    out = lines[0].split()
     groups = int(out[1])
     got = [int(v) for v in out[3:]]
+    # the grid's first entry is the plain score_data; the wire round trip holds
+    grid = lines[1].split()
+    assert grid[0] == "grid" and grid[4] == "single"
+    assert abs(float(grid[1]) - float(grid[5])) < 1e-5
+    assert len({grid[1], grid[2], grid[3]}) == 3
+    assert lines[2].endswith("roundtrip ok")
     values = np.array([0, 1, 0, 2, 0, 1, 0, 3], np.uint32)
     assign = (np.arange(8) % 3).astype(np.uint32)
     m = ol.OracleMixture(1.0, 0.2, [ol.make_shared(ol.DD, alphas=[0.5] * 4)])
