@@ -150,6 +150,7 @@ class ShardedGibbs(object):
         # rank (what N > 1 runs, exercised on a single GPU)
         self.collective = self.world > 1 or (force_collective
                                              and dist.is_initialized())
+        self._delta = None
         self.ordered = self.collective and backend.ordered_features() > 0
         self.columns = columns
         self.assign_packed = assign_packed
@@ -245,7 +246,12 @@ class ShardedGibbs(object):
                 self.backend.batch_apply_local()
             else:
                 n = self.backend.stat_words()
-                delta = torch.empty(n, dtype=torch.int32, device=self.device)
+                if self._delta is None or self._delta.numel() < n:
+                    # headroom: the image grows with the group count
+                    self._delta = torch.empty(n + n // 4 + 1024,
+                                              dtype=torch.int32,
+                                              device=self.device)
+                delta = self._delta[:n]
                 self.backend.batch_delta_dev(int(delta.data_ptr()))
                 self._all_reduce(delta)
                 self.backend.batch_apply_delta_dev(int(delta.data_ptr()))
