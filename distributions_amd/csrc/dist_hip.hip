@@ -107,6 +107,53 @@ static void register_small_lgamma(const std::vector<float> & ys) {
     HIP_CHECK(hipDeviceSynchronize());
 }
 
+// the arguments below 2.5 that MixtureDataScorer::score_data hands to
+// fast_lgamma for groups of at most two members under `sh` (dd.hpp:287-318,
+// bb.hpp:207-229, gp.hpp:220-241, nich.hpp:262-288, bnb.hpp:226-245)
+static void score_data_small_args(const dist_shared_t & sh,
+                                  std::vector<float> & ys) {
+    switch (sh.kind) {
+    case DIST_DD: {
+        float alpha_sum = 0.f;
+        for (int v = 0; v < sh.dim; ++v) {
+            alpha_sum += sh.alphas[v];
+            for (int c = 0; c <= 2; ++c) ys.push_back(sh.alphas[v] + (float)c);
+        }
+        for (int n = 0; n <= 2; ++n) ys.push_back(alpha_sum + (float)n);
+        break;
+    }
+    case DIST_BB:
+        ys.push_back(sh.p[0] + sh.p[1]);
+        for (int h = 0; h <= 2; ++h)
+            for (int t = 0; t <= 2; ++t) {
+                const float a = sh.p[0] + (float)h, b = sh.p[1] + (float)t;
+                ys.push_back(a);
+                ys.push_back(b);
+                ys.push_back(a + b);
+            }
+        break;
+    case DIST_GP:
+        for (int sum = 0; sum <= 2; ++sum) ys.push_back(sh.p[0] + (float)sum);
+        break;
+    case DIST_NICH:
+        for (int n = 0; n <= 5; ++n) ys.push_back(0.5f * (sh.p[3] + (float)n));
+        break;
+    case DIST_BNB:
+        ys.push_back(sh.p[0] + sh.p[1]);
+        for (int n = 0; n <= 2; ++n)
+            for (int sum = 0; sum <= 2; ++sum) {
+                const float pa = sh.p[0] + sh.p[2] * (float)n;
+                const float pb = sh.p[1] + (float)sum;
+                ys.push_back(pa);
+                ys.push_back(pb);
+                ys.push_back(pa + pb);
+            }
+        break;
+    default:
+        break;
+    }
+}
+
 static inline dim3 grid_for(size_t n, int block = kBlock) {
     return dim3((unsigned)std::max<size_t>(1, (n + block - 1) / block));
 }
@@ -398,15 +445,9 @@ struct Slave {
         return out;
     }
     float score_data() const {                // mixture.hpp:427-431
-        if (!K) return 0.f;
-        DeviceBuf<double> out;
-        out.reserve(1, 0);   // zero-filled
-        const size_t width = is_cat(sh.kind) ? sh.dim : 1;
-        SlaveView v = view();
-        LAUNCH(k_score_data, (size_t)K * width, v, out.p);
-        double total = 0.0;
-        out.download(&total, 1);
-        return (float)total;
+        float out = 0.f;
+        score_data_grid(&sh, 1, &out);
+        return out;
     }
     // mixture.hpp:433-438 over MixtureSlaveDataScorerMixin::score_data_grid
     // (mixture.hpp:238-247) / DirichletDiscrete's incremental form
@@ -450,23 +491,53 @@ struct Slave {
             for (size_t c = 0; c < n; ++c) scores_out[c] = 0.f;
             return;
         }
+        {   // glibc's lgammaf for the small arguments these candidates reach
+            std::vector<float> ys;
+            for (size_t c = 0; c < n; ++c) score_data_small_args(shareds[c], ys);
+            register_small_lgamma(ys);
+        }
         DeviceBuf<float> dp, dprior, dsum;
-        DeviceBuf<double> out;
         dp.upload(cp.data(), cp.size());
         dprior.upload(cprior.data(), cprior.size());
         dsum.upload(csum.data(), csum.size());
-        out.reserve(n, 0);   // zero-filled
-        const size_t cells = (size_t)K * (dimc ? dimc : 1);
         SlaveView v = view();
-        hipLaunchKernelGGL(k_score_data_grid,
-                           dim3((unsigned)((cells + kBlock - 1) / kBlock),
-                                (unsigned)n),
-                           dim3(kBlock), 0, stream(), v, dp.p, dprior.p,
-                           dsum.p, out.p);
-        HIP_CHECK(hipGetLastError());
-        std::vector<double> totals(n);
-        out.download(totals.data(), n);
-        for (size_t c = 0; c < n; ++c) scores_out[c] = (float)totals[c];
+        if (sh.kind == DIST_DPD) {
+            // sparse-counter iteration order is not defined in the reference
+            // (dpd.hpp:344-374): terms summed in binary64, 1e-5 relative
+            DeviceBuf<double> out;
+            out.reserve(n, 0);   // zero-filled
+            const size_t cells = (size_t)K * dimc;
+            hipLaunchKernelGGL(k_score_data_grid,
+                               dim3((unsigned)((cells + kBlock - 1) / kBlock),
+                                    (unsigned)n),
+                               dim3(kBlock), 0, stream(), v, dp.p, dprior.p,
+                               dsum.p, out.p);
+            HIP_CHECK(hipGetLastError());
+            std::vector<double> totals(n);
+            out.download(totals.data(), n);
+            for (size_t c = 0; c < n; ++c) scores_out[c] = (float)totals[c];
+            return;
+        }
+        // the reference's float accumulation order, bit for bit
+        DeviceBuf<float> out;
+        out.reserve(n, 0);
+        if (sh.kind == DIST_DD) {
+            hipLaunchKernelGGL(k_score_data_dd, dim3((unsigned)n), dim3(512), 0,
+                               stream(), v, dprior.p, dsum.p, out.p);
+            HIP_CHECK(hipGetLastError());
+        } else {
+            DeviceBuf<float> terms;
+            terms.reserve(n * (size_t)K * 4, 0);
+            hipLaunchKernelGGL(k_score_data_terms,
+                               dim3((unsigned)((K + kBlock - 1) / kBlock),
+                                    (unsigned)n),
+                               dim3(kBlock), 0, stream(), v, dp.p, terms.p);
+            HIP_CHECK(hipGetLastError());
+            hipLaunchKernelGGL(k_score_data_serial, dim3((unsigned)n), dim3(64),
+                               0, stream(), terms.p, (size_t)K * 4, out.p);
+            HIP_CHECK(hipGetLastError());
+        }
+        out.download(scores_out, n);
     }
     void score_value(uint32_t value, float * acc, size_t size) const {
         DIST_REQUIRE(size == (size_t)K, "scores_accum != len(mixture)");
@@ -1886,24 +1957,6 @@ static float le_score_counts(int dataset_size, const int * counts, size_t n) {
     }
     score -= le_log_partition_function((int)sample_size);
     return score;
-}
-// vector_sum (vector_math.cc:85-93) in the association of the reference's
-// release build: four lane accumulators (element i in lane i mod 4) over the
-// first 4*floor(n/4) elements, (lane1 + lane3) + (lane0 + lane2), then the
-// tail in order; fewer than four elements in order
-static float vector_sum_as_built(size_t n, const float * x) {
-    if (n < 4) {
-        float s = 0.f;
-        for (size_t i = 0; i < n; ++i) s += x[i];
-        return s;
-    }
-    float lane[4] = {0.f, 0.f, 0.f, 0.f};
-    const size_t body = n & ~(size_t)3;
-    for (size_t i = 0; i < body; i += 4)
-        for (int j = 0; j < 4; ++j) lane[j] += x[i + j];
-    float s = (lane[1] + lane[3]) + (lane[0] + lane[2]);
-    for (size_t i = body; i < n; ++i) s += x[i];
-    return s;
 }
 // LowEntropy::sample_assignments (clustering.cc:250-283): a sequential draw
 // over a growing likelihood vector -- host code, like the reference's and

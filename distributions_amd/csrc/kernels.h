@@ -323,6 +323,70 @@ __global__ void k_score_data_grid(SlaveView s, const float * __restrict__ cand_p
     block_sum_to(score_data_cell(s, i), out + c);
 }
 
+// MixtureDataScorer::score_data in the reference's own float accumulation
+// order (bit-exact against a float restatement of its loops):
+//   DirichletDiscrete (dd.hpp:287-318): one accumulator per value plus one for
+//   the shift, each fed group by group, closed by vector_sum -- one thread per
+//   accumulator walks the groups; blockIdx.x = candidate Shared
+__global__ __launch_bounds__(512) void k_score_data_dd(
+        SlaveView s, const float * __restrict__ cand_prior,
+        const float * __restrict__ cand_alpha_sum, float * out) {
+    __shared__ float chain[DIST_DD_MAX_DIM + 1];
+    const int c = blockIdx.x;
+    const float * prior = cand_prior + (size_t)c * s.dim;
+    const float alpha_sum = cand_alpha_sum[c];
+    const int v = threadIdx.x;
+    if (v <= s.dim) {
+        float acc = 0.f;
+        if (v < s.dim) {
+            const float a = prior[v];
+            const float shared_part = fast_lgamma(a);
+            for (int k = 0; k < s.K; ++k)
+                if (s.i0[k])
+                    acc += fast_lgamma(a + (float)s.cnt[(size_t)k * s.dim + v])
+                         - shared_part;
+        } else {
+            const float shared_part = fast_lgamma(alpha_sum);
+            for (int k = 0; k < s.K; ++k)
+                if (s.i0[k])
+                    acc += shared_part
+                         - fast_lgamma(alpha_sum + (float)s.i0[k]);
+        }
+        chain[v] = acc;
+    }
+    __syncthreads();
+    if (v == 0) out[c] = vector_sum_as_built((size_t)s.dim + 1, chain);
+}
+//   scalar kinds (bb.hpp:207-229, gp.hpp:220-241, nich.hpp:262-288,
+//   bnb.hpp:226-245): ONE accumulator, every group adds its terms in order.
+//   The terms are computed in parallel (absent ones as +0, which leaves the
+//   accumulator unchanged) ...
+__global__ void k_score_data_terms(SlaveView s, const float * __restrict__ cand_p,
+                                   float * __restrict__ terms) {
+    const int c = blockIdx.y;
+    for (int j = 0; j < 4; ++j) s.p[j] = cand_p[4 * c + j];
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= s.K) return;
+    float t[4] = {0.f, 0.f, 0.f, 0.f};
+    const int nt = scalar_mixture_score_terms(s.kind, s.p, load_stats(s, k), t);
+    float * dst = terms + ((size_t)c * s.K + k) * 4;
+    for (int j = 0; j < 4; ++j) dst[j] = j < nt ? t[j] : 0.f;
+}
+//   ... and summed by one wave per candidate in index order
+__global__ __launch_bounds__(64) void k_score_data_serial(
+        const float * __restrict__ terms, size_t n_terms, float * out) {
+    const float * src = terms + (size_t)blockIdx.x * n_terms;
+    const int lane = threadIdx.x;
+    float total = 0.f;
+    for (size_t i0 = 0; i0 < n_terms; i0 += 64) {
+        const float mine = (i0 + lane < n_terms) ? src[i0 + lane] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 64; ++j)
+            total += u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(mine), j));
+    }
+    if (lane == 0) out[blockIdx.x] = total;
+}
+
 // PitmanYor::score_counts: before[k] = (non-empty groups, rows) ahead of k
 __global__ void k_py_score_counts(const int32_t * __restrict__ counts,
                                   const unsigned long long * __restrict__ before,

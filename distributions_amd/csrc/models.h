@@ -449,6 +449,26 @@ DIST_HD int scalar_mixture_score_terms(int kind, const float * p,
     }
 }
 
+// vector_sum (vector_math.cc:85-93) in the association of the reference's
+// release build: four lane accumulators (element i in lane i mod 4) over the
+// first 4*floor(n/4) elements, (lane1 + lane3) + (lane0 + lane2), then the
+// tail in order; fewer than four elements in order
+DIST_HD float vector_sum_as_built(size_t n, const float * x) {
+    if (n < 4) {
+        float s = 0.f;
+        for (size_t i = 0; i < n; ++i) s += x[i];
+        return s;
+    }
+    float l0 = 0.f, l1 = 0.f, l2 = 0.f, l3 = 0.f;
+    const size_t body = n & ~(size_t)3;
+    for (size_t i = 0; i < body; i += 4) {
+        l0 += x[i]; l1 += x[i + 1]; l2 += x[i + 2]; l3 += x[i + 3];
+    }
+    float s = (l1 + l3) + (l0 + l2);
+    for (size_t i = body; i < n; ++i) s += x[i];
+    return s;
+}
+
 // PitmanYor::score_counts (src/clustering.cc:152-183): the term of one
 // non-empty group given how many non-empty groups and rows precede it
 DIST_HD double py_score_counts_term(float alpha, float d, int count,

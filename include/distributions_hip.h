@@ -198,12 +198,16 @@ int dist_mixture_score_value(const dist_mixture_t * m, uint32_t value,
                              float * scores_accum, size_t size);
 
 /* score_data: log marginal likelihood of all groups' data    mixture.hpp:427-431
- * (float terms of the reference, summed in binary64; 1e-5 relative) */
+ * Accumulated in the reference's own float order (per-value chains closed by
+ * vector_sum for DirichletDiscrete, one chain over the groups otherwise):
+ * bit-exact against a float restatement of its loops.  DirichletProcessDiscrete
+ * walks a hash map in the reference: its terms are summed in binary64,
+ * 1e-5 relative. */
 int dist_mixture_score_data(const dist_mixture_t * m, float * out);
 /* score_data_grid: scores_out[i] = score_data under candidate shareds[i]
  * (hyper-parameter grid, mixture.hpp:433-438 / 238-247; DirichletDiscrete
  * carries alpha_sum from candidate to candidate like dd.hpp:259-284,320-344).
- * One launch scores every (candidate, group) pair; same tolerance. */
+ * Every candidate is scored in the same launches; same contract. */
 int dist_mixture_score_data_grid(const dist_mixture_t * m,
                                  const dist_shared_t * shareds, size_t n,
                                  float * scores_out);

@@ -301,8 +301,9 @@ def test_prob_from_scores():
 @pytest.mark.parametrize("module,EXAMPLE", examples())
 def test_mixture_score_data(module, EXAMPLE):
     """check_score_data of distributions/tests/test_models.py:559-562 on the
-    GPU, plus the oracle within the stated 1e-5 (terms are the reference's,
-    the device sums them in binary64)"""
+    GPU, plus the oracle: bit-exact (the device accumulates in the reference's
+    float order; small lgamma arguments come from the registered glibc
+    table), 1e-5 for DirichletProcessDiscrete"""
     L = ol.oracle()
     shared = module.Shared.from_dict(EXAMPLE['shared'])
     values = EXAMPLE['values']
@@ -324,7 +325,11 @@ def test_mixture_score_data(module, EXAMPLE):
         actual = mixture.score_data(shared)
         assert_close(actual, expected, msg='score_data')
         want = L.orc_mix_slave_score_data(orc.h, 0)
-        assert abs(actual - want) <= 1e-5 * (1 + abs(want)), (actual, want)
+        if module.NAME == 'DirichletProcessDiscrete':
+            # the reference walks a hash map there: order-free sum, 1e-5
+            assert abs(actual - want) <= 1e-5 * (1 + abs(want)), (actual, want)
+        else:   # the reference's float accumulation order, bit for bit
+            assert np.float32(actual) == np.float32(want), (actual, want)
         for g, group in enumerate(groups):
             wg = L.orc_group_score_data(ctypes.byref(osh), orc.get_group(0, g))
             assert np.float32(group.score_data(shared)) == np.float32(wg)
@@ -404,8 +409,11 @@ def test_mixture_score_data_grid(module, EXAMPLE):
         single.init(cand)
         assert abs(got[c] - single.score_data(cand)) <= 1e-6 * (
             1 + abs(got[c])), c
-        assert abs(got[c] - want[c]) <= 1e-5 * (1 + abs(want[c])), (
-            c, got[c], want[c])
+        if module.NAME == 'DirichletProcessDiscrete':
+            assert abs(got[c] - want[c]) <= 1e-5 * (1 + abs(want[c])), (
+                c, got[c], want[c])
+        else:
+            assert got[c] == want[c], (c, got[c], want[c])
     assert len(set(np.round(got, 3))) > 1      # the grid does vary the score
 
 
