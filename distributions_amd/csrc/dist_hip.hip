@@ -254,6 +254,11 @@ struct Slave {
             ys.push_back(sh.p[0] + sh.p[1]);
             register_small_lgamma(ys);
         }
+        if (sh.kind == DIST_NICH && sh.p[3] < 0.0625f) {
+            // fast_lgamma_nu's libm branch (special.hpp:226-229), reached
+            // by a group without members when nu itself is below 1/16
+            register_small_lgamma({(sh.p[3] + 1.0f) * 0.5f, sh.p[3] * 0.5f});
+        }
         if (sh.kind == DIST_DD) {
             // dd.hpp:403-406: alpha_sum_ accumulates in index order
             alpha_sum = 0.f;

@@ -373,3 +373,31 @@ def test_changing_the_batch_tiling_between_sweeps():
             gpu.sweep(0, n, batch, seed, draw_base=draw)
             draw += n
         assert_same_state(orc, gpu, "tiling step %d" % step)
+
+
+def test_nich_with_tiny_nu_uses_libm_values_for_empty_groups():
+    """fast_lgamma_nu(nu < 1/16) is two glibc lgammaf calls in the reference
+    (special.hpp:226-229); a NormalInverseChiSq prior with nu = 0.01 reaches
+    it for every group without members"""
+    from distributions_amd import engine
+    rng = np.random.default_rng(8)
+    n, k = 500, 30
+    vals = [rng.normal(0, 2, n).astype(np.float32)]
+    assign = (np.arange(n) % k).astype(np.uint32)
+    osh = [ol.make_shared(ol.NICH, mu=0.1, kappa=0.5, sigmasq=1.5, nu=0.01)]
+    orc = ol.OracleMixture(1.0, 0.1, osh)
+    orc.init_from_assignments(vals, assign, k, 3)
+    gpu = engine.Gibbs(1.0, 0.1, [engine.nich_shared(0.1, 0.5, 1.5, 0.01)])
+    gpu.load_rows(vals, assign, k, 3)
+    L = ol.oracle()
+    for row in [0, 250, 499]:
+        g = int(L.orc_mix_global_to_packed(orc.h, int(orc.assign[row])))
+        want = orc.row_scores(row, g)
+        got = gpu.row_scores(row)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    st = L.orc_rng_seed(3)
+    for sweep in range(2):
+        for b in range(0, n, 125):
+            orc.gibbs_batch(b, b + 125, st, sweep * n)
+        gpu.sweep(0, n, 125, 3, draw_base=sweep * n)
+        assert_same_state(orc, gpu, "tiny nu sweep %d" % sweep)
