@@ -80,7 +80,8 @@ struct DeviceBuf {
     // grows to at least n elements, keeping the first `keep` elements
     void reserve(size_t n, size_t keep) {
         if (n <= cap) return;
-        if (getenv("DIST_TRACE_ALLOC"))
+        static const bool trace_alloc = getenv("DIST_TRACE_ALLOC");
+        if (trace_alloc)
             fprintf(stderr, "[dist] device buffer grows %zu -> %zu elements of %zu B\n",
                     cap, n, sizeof(T));
         T * q = nullptr;

@@ -1312,7 +1312,8 @@ struct Gibbs {
         kernel_ms += ms;
         kernel_launches += 1;
         kernel_rows += batch_end - batch_begin;
-        if (batch_value_sorted && getenv("DIST_TRACE_DEFERRED")) {
+        static const bool trace_deferred = getenv("DIST_TRACE_DEFERRED");
+        if (batch_value_sorted && trace_deferred) {
             uint32_t n = 0;
             deferred_count.download(&n, 1);
             fprintf(stderr, "[dist] batch [%zu, %zu): %u rows handed over\n",
