@@ -728,6 +728,7 @@ struct Gibbs {
     bool batch_open = false;
     bool batch_value_sorted = false;
     bool moves_in_row_order = false;   // old_row/new_row hold the open batch
+    bool base_valid = false;           // base[], base_single[], scalars current
     bool timing_pending = false;
     int * pinned_counts = nullptr;
     size_t pinned_cap = 0;
@@ -920,6 +921,7 @@ struct Gibbs {
     }
 
     void rebuild_caches() {
+        base_valid = false;
         py.rebuild(alpha, d);
         for (auto & s : feats) s->init();
     }
@@ -1038,8 +1040,11 @@ struct Gibbs {
         base_single.reserve(grow_capacity((size_t)K()), 0);
         P.base = base.p;
         P.base_single = base_single.p;
-        LAUNCH(k_sweep_prepare, (size_t)K(), P, base.p, base_single.p,
-               scalars.p);
+        if (!base_valid) {   // batch_finish leaves them ready
+            LAUNCH(k_sweep_prepare, (size_t)K(), P, base.p, base_single.p,
+                   scalars.p);
+            base_valid = true;
+        }
         ktab.resize((size_t)F());
         for (int f = 0; f < F(); ++f) {
             int nv = ktab_values(f);
@@ -1552,17 +1557,51 @@ struct Gibbs {
             }
         }
         for (auto & s : feats) s->K = size;
+        const int k_new = size;
         if (created) {
-            const int k0 = size;
             py.counts.resize((size_t)(size + created), 0);
             py.reserve(K());
-            LAUNCH(k_py_zero_range, (size_t)created, py.d_counts.p, k0,
-                   k0 + created);
-            for (auto & s : feats) s->append_zero(created);
+            for (auto & s : feats) {
+                s->reserve(s->K + created);
+                s->K += created;
+            }
             for (int c = 0; c < created; ++c) tracker.add_group();
         }
         if (structural) maps_dirty = true;
-        rebuild_caches();
+        // appended groups zeroed, caches rebuilt, driver scores rebuilt: one
+        // launch (k_batch_finish)
+        py.n_empty = 0;
+        py.sample_size = 0;
+        for (int c : py.counts) {
+            py.sample_size += c;
+            py.n_empty += (c == 0);
+        }
+        FinishParams Q;
+        memset(&Q, 0, sizeof(Q));
+        Q.F = F();
+        size_t cells = (size_t)K();
+        for (int f = 0; f < F(); ++f) {
+            Q.feat[f] = feats[f]->view();
+            cells = std::max(cells, (size_t)K() * std::max(1, feats[f]->dim()));
+        }
+        Q.counts = py.d_counts.p;
+        Q.shifted = py.d_shifted.p;
+        Q.K = K();
+        Q.k_new = k_new;
+        Q.alpha = alpha;
+        Q.d = d;
+        Q.nonempty = K() - py.n_empty;
+        Q.empty = py.n_empty;
+        base.reserve(grow_capacity((size_t)K()), 0);
+        base_single.reserve(grow_capacity((size_t)K()), 0);
+        Q.prep = DriverPrep{alpha, d, cluster, dataset_size, py.sample_size,
+                            K(), py.n_empty, base.p, base_single.p, scalars.p};
+        base_valid = true;
+        hipLaunchKernelGGL(k_batch_finish,
+                           dim3((unsigned)((cells + kBlock - 1) / kBlock),
+                                (unsigned)(F() + 1)),
+                           dim3(kBlock), 0, stream(), Q);
+        HIP_CHECK(hipGetLastError());
     }
 
     void sweep(size_t r0, size_t r1, size_t batch, uint32_t seed,

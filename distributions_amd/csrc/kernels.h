@@ -212,6 +212,115 @@ __global__ void k_slave_move_group(SlaveView s, int dst, int src) {
     }
 }
 
+struct SweepScalars {
+    float shift;         // -fast_log(float(N - 1) + alpha)   (row removed)
+    float empty_single;  // empty-group score with one non-empty group fewer
+    float shift_full;    // -fast_log(float(N) + alpha)       (no removal)
+};
+
+// The driver's contribution to a row's scores in batch semantics (one row
+// taken out): base[k] for rows that leave their group non-empty, base_single[k]
+// for a row that was alone in its group (one non-empty group fewer in the
+// empty groups' prior, clustering.hpp:221-230), and the scalars.
+struct DriverPrep {
+    float alpha, d;
+    int cluster, dataset_size;   // see SweepParams::cluster
+    long long sample_size;
+    int K, n_empty;
+    float * base;
+    float * base_single;
+    SweepScalars * scalars;
+};
+__device__ __forceinline__ void driver_prepare_slot(const DriverPrep & P,
+                                                    size_t i, int count,
+                                                    float shifted) {
+    if (P.cluster == 1) {
+        // MixtureDriver<LowEntropy>::score_value with the row removed:
+        // sample_size - 1 rows; the score of a slot depends on its own size
+        // only, so a vanished singleton changes nothing else
+        if (i == 0) {
+            P.scalars->shift = 0.f;
+            P.scalars->shift_full = 0.f;
+            P.scalars->empty_single = le_score_add_value(
+                P.dataset_size, 0, (int)P.sample_size - 1, P.n_empty);
+        }
+        if (i >= (size_t)P.K) return;
+        const float s = le_score_add_value(P.dataset_size, count,
+                                           (int)P.sample_size - 1, P.n_empty);
+        P.base[i] = s;
+        P.base_single[i] = s;
+        return;
+    }
+    const float shift = py_shift(P.sample_size - 1, P.alpha);
+    const float empty_single =
+        py_empty_score(P.alpha, P.d, P.K - P.n_empty - 1, P.n_empty);
+    if (i == 0) {
+        P.scalars->shift = shift;
+        P.scalars->shift_full = py_shift(P.sample_size, P.alpha);
+        P.scalars->empty_single = empty_single;
+    }
+    if (i >= (size_t)P.K) return;
+    P.base[i] = shifted + shift;
+    P.base_single[i] = (count == 0 ? empty_single : shifted) + shift;
+}
+
+// The tail of a batch's normalisation in ONE launch (it sits between the
+// host's look at the group sizes and the next batch's first kernel, so every
+// launch here is idle time on the device): groups [k_new, K) are appended
+// empty (Group::init), every group's cache entries are rebuilt from its
+// statistics (update_all, dd.hpp:399-421 etc.), and the driver's shifted
+// scores are rebuilt (clustering.hpp:151-161).  blockIdx.y = feature, the
+// last y-slice is the driver.
+struct FinishParams {
+    int F;
+    SlaveView feat[kMaxF];
+    int32_t * counts;      // driver
+    float * shifted;
+    int K, k_new;
+    float alpha, d;
+    int nonempty, empty;
+    DriverPrep prep;       // the next batch's base scores, while we are here
+};
+__global__ void k_batch_finish(FinishParams P) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int K = P.K;
+    if ((int)blockIdx.y == P.F) {
+        if (i >= (size_t)K) return;
+        const int k = (int)i;
+        int n = P.counts[k];
+        if (k >= P.k_new) { n = 0; P.counts[k] = 0; }
+        const float shifted =
+            n ? py_nonempty_score(n, P.d)
+              : py_empty_score(P.alpha, P.d, P.nonempty, P.empty);
+        P.shifted[k] = shifted;
+        driver_prepare_slot(P.prep, i, n, shifted);
+        return;
+    }
+    const SlaveView & s = P.feat[blockIdx.y];
+    if (is_cat(s.kind)) {
+        if (i >= (size_t)K * s.dim) return;
+        const int v = (int)(i / K);
+        const int k = (int)(i % K);     // group fastest: S[v][k] coalesces
+        if (k >= P.k_new) {
+            s.cnt[(size_t)k * s.dim + v] = 0;
+            if (v == 0) { s.i0[k] = 0; s.i1[k] = 0; s.f0[k] = 0.f; s.f1[k] = 0.f; }
+            s.S[(size_t)v * s.cap + k] = fast_log(s.prior[v] + 0.f);
+            if (v == 0) s.c0[k] = fast_log(s.alpha_sum + 0.f);
+            return;
+        }
+        refresh_cat_cell(s, k, v);
+        if (v == 0) refresh_shift(s, k);
+    } else {
+        if (i >= (size_t)K) return;
+        const int k = (int)i;
+        if (k >= P.k_new) {
+            const Stats zero = {0, 0, 0.f, 0.f};
+            store_stats(s, k, zero);
+        }
+        refresh_scalar_entry(s, k);
+    }
+}
+
 // Many packed_remove steps at once: after a batch the host works out which
 // original group ends up in which slot (sources lie beyond the new end,
 // destinations inside it, so the copies are independent) and one launch per
@@ -402,11 +511,6 @@ __global__ void k_py_score_counts(const int32_t * __restrict__ counts,
 // ---------------------------------------------------------------------------
 // the batched row update
 
-struct SweepScalars {
-    float shift;         // -fast_log(float(N - 1) + alpha)   (row removed)
-    float empty_single;  // empty-group score with one non-empty group fewer
-    float shift_full;    // -fast_log(float(N) + alpha)       (no removal)
-};
 
 struct SweepParams {
     int F;
@@ -511,34 +615,11 @@ __global__ void k_sweep_prepare(SweepParams P, float * __restrict__ base,
                                 float * __restrict__ base_single,
                                 SweepScalars * scalars) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (P.cluster == 1) {
-        // MixtureDriver<LowEntropy>::score_value with the row removed:
-        // sample_size - 1 rows; the score of a slot depends on its own size
-        // only, so a vanished singleton changes nothing else
-        if (i == 0) {
-            scalars->shift = 0.f;
-            scalars->shift_full = 0.f;
-            scalars->empty_single = le_score_add_value(
-                P.dataset_size, 0, (int)P.sample_size - 1, P.n_empty);
-        }
-        if (i >= (size_t)P.K) return;
-        const float s = le_score_add_value(P.dataset_size, P.counts[i],
-                                           (int)P.sample_size - 1, P.n_empty);
-        base[i] = s;
-        base_single[i] = s;
-        return;
-    }
-    const float shift = py_shift(P.sample_size - 1, P.alpha);
-    const float empty_single =
-        py_empty_score(P.alpha, P.d, P.K - P.n_empty - 1, P.n_empty);
-    if (i == 0) {
-        scalars->shift = shift;
-        scalars->shift_full = py_shift(P.sample_size, P.alpha);
-        scalars->empty_single = empty_single;
-    }
-    if (i >= (size_t)P.K) return;
-    base[i] = P.shifted[i] + shift;
-    base_single[i] = (P.counts[i] == 0 ? empty_single : P.shifted[i]) + shift;
+    const DriverPrep D = {P.alpha, P.d, P.cluster, P.dataset_size,
+                          P.sample_size, P.K, P.n_empty, base, base_single,
+                          scalars};
+    const bool in = i < (size_t)P.K;
+    driver_prepare_slot(D, i, in ? P.counts[i] : 0, in ? P.shifted[i] : 0.f);
 }
 
 // k-major gather table of one feature (see SweepParams::ktab)
