@@ -706,6 +706,7 @@ struct Gibbs {
     std::vector<uint32_t> maps_host;
     const uint32_t * d_p2g_ptr = nullptr;
     const int32_t * d_g2p_ptr = nullptr;
+    size_t maps_pcap = 0;                   // slots reserved for p2g
     bool maps_dirty = true;
 
     DeviceBuf<uint32_t> old_packed, new_packed;
@@ -820,9 +821,13 @@ struct Gibbs {
         std::copy(tracker.p2g.begin(), tracker.p2g.end(), maps_host.begin());
         for (size_t i = 0; i < ng; ++i)
             maps_host[pcap + i] = (uint32_t)tracker.g2p[i];
+        // headroom for groups the device appends itself (k_batch_finish)
+        if (maps_host.size() + 1024 > d_maps.cap)
+            d_maps.reserve(grow_capacity(maps_host.size() + 1024), 0);
         d_maps.upload(maps_host.data(), maps_host.size());
         d_p2g_ptr = d_maps.p;
         d_g2p_ptr = reinterpret_cast<const int32_t *>(d_maps.p + pcap);
+        maps_pcap = pcap;
         maps_dirty = false;
     }
 
@@ -1558,6 +1563,13 @@ struct Gibbs {
         }
         for (auto & s : feats) s->K = size;
         const int k_new = size;
+        const uint32_t first_new_global = (uint32_t)tracker.g2p.size();
+        // groups that are only appended extend the device's id maps in place
+        // (k_batch_finish); anything else re-uploads them
+        const bool maps_on_device =
+            !maps_dirty && size == K0 && created > 0
+            && (size_t)(size + created) <= maps_pcap
+            && maps_pcap + tracker.g2p.size() + (size_t)created <= d_maps.cap;
         if (created) {
             py.counts.resize((size_t)(size + created), 0);
             py.reserve(K());
@@ -1567,7 +1579,7 @@ struct Gibbs {
             }
             for (int c = 0; c < created; ++c) tracker.add_group();
         }
-        if (structural) maps_dirty = true;
+        if (structural && !maps_on_device) maps_dirty = true;
         // appended groups zeroed, caches rebuilt, driver scores rebuilt: one
         // launch (k_batch_finish)
         py.n_empty = 0;
@@ -1597,6 +1609,11 @@ struct Gibbs {
         Q.prep = DriverPrep{alpha, d, cluster, dataset_size, py.sample_size,
                             K(), py.n_empty, base.p, base_single.p, scalars.p};
         base_valid = true;
+        if (maps_on_device) {
+            Q.p2g = d_maps.p;
+            Q.g2p = reinterpret_cast<int32_t *>(d_maps.p + maps_pcap);
+            Q.first_new_global = first_new_global;
+        }
         hipLaunchKernelGGL(k_batch_finish,
                            dim3((unsigned)((cells + kBlock - 1) / kBlock),
                                 (unsigned)(F() + 1)),

@@ -280,6 +280,12 @@ struct FinishParams {
     float alpha, d;
     int nonempty, empty;
     DriverPrep prep;       // the next batch's base scores, while we are here
+    // id maps of the appended groups (MixtureIdTracker::add_group,
+    // mixture.hpp:474-479): slot k gets global id first_new_global + k - k_new;
+    // nullptr when the host uploads the maps itself
+    uint32_t * p2g;
+    int32_t * g2p;
+    uint32_t first_new_global;
 };
 __global__ void k_batch_finish(FinishParams P) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -288,7 +294,15 @@ __global__ void k_batch_finish(FinishParams P) {
         if (i >= (size_t)K) return;
         const int k = (int)i;
         int n = P.counts[k];
-        if (k >= P.k_new) { n = 0; P.counts[k] = 0; }
+        if (k >= P.k_new) {
+            n = 0;
+            P.counts[k] = 0;
+            if (P.p2g) {
+                const uint32_t global = P.first_new_global + (uint32_t)(k - P.k_new);
+                P.p2g[k] = global;
+                P.g2p[global] = k;
+            }
+        }
         const float shifted =
             n ? py_nonempty_score(n, P.d)
               : py_empty_score(P.alpha, P.d, P.nonempty, P.empty);
