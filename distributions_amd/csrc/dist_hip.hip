@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cstring>
 #include <memory>
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <set>
@@ -733,6 +734,8 @@ struct Gibbs {
     bool timing_pending = false;
     int * pinned_counts = nullptr;
     size_t pinned_cap = 0;
+    unsigned * pinned_seq = nullptr;   // see k_publish_counts
+    unsigned publish_ticket = 0;
 
     // value-sorted path (single small-domain feature): rows of a batch range
     // sorted by value once, tiles of <= 64 equal-valued rows
@@ -807,6 +810,7 @@ struct Gibbs {
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
         if (pinned_counts) (void)hipHostFree(pinned_counts);
+        if (pinned_seq) (void)hipHostFree(pinned_seq);
     }
 
     int F() const { return (int)feats.size(); }
@@ -936,10 +940,28 @@ struct Gibbs {
             if (pinned_counts) (void)hipHostFree(pinned_counts);
             pinned_cap = grow_capacity(n);
             HIP_CHECK(hipHostMalloc((void **)&pinned_counts,
-                                    pinned_cap * sizeof(int), 0));
+                                    pinned_cap * sizeof(int),
+                                    hipHostMallocCoherent));
         }
         py.counts.resize(n);
-        py.d_counts.download(pinned_counts, n);   // synchronises the stream
+        if (!pinned_seq) {
+            HIP_CHECK(hipHostMalloc((void **)&pinned_seq, sizeof(unsigned),
+                                    hipHostMallocCoherent));
+            *pinned_seq = 0;
+        }
+        // one block writes the sizes into the pinned buffer, then the ticket
+        const unsigned ticket = ++publish_ticket;
+        hipLaunchKernelGGL(k_publish_counts, dim3(1), dim3(1024), 0, stream(),
+                           py.d_counts.p, (int)n, pinned_counts,
+                           (volatile unsigned *)pinned_seq, ticket);
+        HIP_CHECK(hipGetLastError());
+        bool seen = false;
+        for (long spin = 0; spin < 200000000L; ++spin) {
+            if (*(volatile unsigned *)pinned_seq == ticket) { seen = true; break; }
+        }
+        // (a failed kernel never writes the ticket: surface its error)
+        if (!seen) HIP_CHECK(hipStreamSynchronize(stream()));
+        std::atomic_thread_fence(std::memory_order_acquire);
         std::copy(pinned_counts, pinned_counts + n, py.counts.begin());
     }
 

@@ -335,6 +335,21 @@ __global__ void k_batch_finish(FinishParams P) {
     }
 }
 
+// The group sizes, straight into pinned host memory, then a sequence number:
+// the host polls the number instead of paying a copy engine round trip and a
+// stream-synchronise wake-up on the critical path of every batch.
+__global__ void k_publish_counts(const int32_t * __restrict__ counts, int K,
+                                 int * host_counts,
+                                 volatile unsigned int * host_seq,
+                                 unsigned int seq) {
+    // launched as ONE block: its barrier orders every store before the ticket
+    for (int k = threadIdx.x; k < K; k += blockDim.x)
+        host_counts[k] = counts[k];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) *host_seq = seq;
+}
+
 // Many packed_remove steps at once: after a batch the host works out which
 // original group ends up in which slot (sources lie beyond the new end,
 // destinations inside it, so the copies are independent) and one launch per
