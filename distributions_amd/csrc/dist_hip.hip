@@ -1261,7 +1261,7 @@ struct Gibbs {
         Q.row_list = deferred.p;
         Q.row_list_count = deferred_count.p;
         if (wave_rows_fit()) {
-            WaveRowsLaunch D{&Q, K(), 1024};
+            WaveRowsLaunch D{&Q, K(), 256};
             dispatch(D);
         } else {
             DeferredLaunch D{&Q};
