@@ -1442,7 +1442,7 @@ struct Gibbs {
         const size_t n = batch_end - batch_begin;
         SweepParams P = params(batch_begin, batch_end, 0, 0);
         const size_t lds_sort =
-            ((size_t)K() * 2 + kBlock + 2 * kVsApplyRows) * 4;
+            ((size_t)K() * 2 + kVsApplyBlock + 2 * kVsApplyRows) * 4;
         const size_t lds_plain = (size_t)K() * 4;
         if (batch_value_sorted && lds_plain <= 60 * 1024) {
             VsCache & c = vs_get(batch_begin, batch_end);
@@ -1450,7 +1450,7 @@ struct Gibbs {
             const bool bb = feats[0]->sh.kind == DIST_BB;
             const bool gp = feats[0]->sh.kind == DIST_GP;
             const bool bnb = feats[0]->sh.kind == DIST_BNB;
-            const dim3 grid(c.n_chunks), block(kBlock);
+            const dim3 grid(c.n_chunks), block(kVsApplyBlock);
             // float statistics replay in ROW order: un-sort the moves first
             // (before the kernel below permutes sorted_rows)
             if (any_float_stats()) {

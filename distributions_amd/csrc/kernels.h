@@ -1534,6 +1534,7 @@ __global__ __launch_bounds__(kBlock) void k_vs_sample(
 //   BB: (x ? heads : tails)[k] += d[k]
 // (6 global atomics per moved row become <= 3 per touched group and chunk).
 constexpr int kVsApplyRows = 4096;
+constexpr int kVsApplyBlock = 1024;   // one workgroup per chunk: keep the CU busy
 
 // SORT: also reorder the chunk's rows by their NEW group (LDS counting sort),
 // in place in sorted_rows.  Next time this batch range is sampled, the 64
@@ -1542,7 +1543,7 @@ constexpr int kVsApplyRows = 4096;
 // vs_sum_and_scan).  The order is a performance hint only: results do not
 // depend on it.
 template <int KIND, bool SORT>
-__global__ __launch_bounds__(kBlock) void k_vs_apply(
+__global__ __launch_bounds__(kVsApplyBlock) void k_vs_apply(
         SweepParams P, StatImage img, const VsTile * __restrict__ chunks,
         uint32_t * __restrict__ sorted_rows,
         const uint32_t * __restrict__ p2g, uint32_t * __restrict__ assign_pos) {
@@ -1550,18 +1551,18 @@ __global__ __launch_bounds__(kBlock) void k_vs_apply(
     const int K = P.K;
     int * delta = vs_lds;                 // [K]
     int * hist = vs_lds + K;              // [K]           (SORT)
-    int * part = hist + K;                // [kBlock]      (SORT)
-    uint32_t * rows_l = (uint32_t *)(part + kBlock);       // [kVsApplyRows]
+    int * part = hist + K;                // [kVsApplyBlock]      (SORT)
+    uint32_t * rows_l = (uint32_t *)(part + kVsApplyBlock);       // [kVsApplyRows]
     uint32_t * gn_l = rows_l + kVsApplyRows;               // [kVsApplyRows]
     const uint32_t x = chunks[blockIdx.x].x;
     const uint32_t pos = chunks[blockIdx.x].pos;
     const uint32_t n = chunks[blockIdx.x].n;
-    for (int k = threadIdx.x; k < K; k += kBlock) {
+    for (int k = threadIdx.x; k < K; k += kVsApplyBlock) {
         delta[k] = 0;
         if (SORT) hist[k] = 0;
     }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < n; i += kBlock) {
+    for (uint32_t i = threadIdx.x; i < n; i += kVsApplyBlock) {
         const uint32_t go = P.old_packed[pos + i], gn = P.new_packed[pos + i];
         if (go != gn) {
             atomicAdd(&delta[go], -1);
@@ -1577,7 +1578,7 @@ __global__ __launch_bounds__(kBlock) void k_vs_apply(
     }
     __syncthreads();
     const int dim = P.feat[0].dim;
-    for (int k = threadIdx.x; k < K; k += kBlock) {
+    for (int k = threadIdx.x; k < K; k += kVsApplyBlock) {
         const int dlt = delta[k];
         if (dlt == 0) continue;
         atomicAdd(&img.counts[k], dlt);
@@ -1593,14 +1594,14 @@ __global__ __launch_bounds__(kBlock) void k_vs_apply(
     }
     if (!SORT) return;
     // exclusive scan of hist over k (each thread owns a contiguous slice)
-    const int per = (K + kBlock - 1) / kBlock;
+    const int per = (K + kVsApplyBlock - 1) / kVsApplyBlock;
     const int lo = threadIdx.x * per;
     const int hi = lo + per < K ? lo + per : K;
     int sum = 0;
     for (int k = lo; k < hi; ++k) sum += hist[k];
     part[threadIdx.x] = sum;
     __syncthreads();
-    for (int off = 1; off < kBlock; off <<= 1) {
+    for (int off = 1; off < kVsApplyBlock; off <<= 1) {
         const int add = (int)threadIdx.x >= off ? part[threadIdx.x - off] : 0;
         __syncthreads();
         part[threadIdx.x] += add;
@@ -1613,7 +1614,7 @@ __global__ __launch_bounds__(kBlock) void k_vs_apply(
         run += c;
     }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < n; i += kBlock) {
+    for (uint32_t i = threadIdx.x; i < n; i += kVsApplyBlock) {
         const int p = atomicAdd(&hist[gn_l[i]], 1);
         sorted_rows[pos + p] = rows_l[i];
         assign_pos[pos + p] = p2g[gn_l[i]];
