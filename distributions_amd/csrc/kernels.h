@@ -952,6 +952,11 @@ template <int KIND0, int KIND1, int NF>
 __global__ __launch_bounds__(kBlock) void k_rows_wave(SweepParams P) {
     extern __shared__ float wave_lds[];
     __shared__ uint32_t s_exp[1024];
+    {   // most launches find few rows or none: workgroups without one leave
+        const size_t n = P.row_list ? (size_t)*P.row_list_count
+                                    : P.row_end - P.row_begin;
+        if ((size_t)blockIdx.x * (kBlock / 64) >= n) return;
+    }
     for (int i = threadIdx.x; i < 1024; i += kBlock)
         s_exp[i] = g_tables_dev.exp_table[i];
     __syncthreads();
