@@ -1444,9 +1444,11 @@ struct Gibbs {
         const size_t lds_sort =
             ((size_t)K() * 2 + kVsApplyBlock + 2 * kVsApplyRows) * 4;
         const size_t lds_plain = (size_t)K() * 4;
-        if (batch_value_sorted && lds_plain <= 60 * 1024) {
+        // a 1024-thread workgroup may take most of the CU's 160 KiB of LDS
+        const size_t lds_limit = 144 * 1024;
+        if (batch_value_sorted && lds_plain <= lds_limit) {
             VsCache & c = vs_get(batch_begin, batch_end);
-            const bool sort = lds_sort <= 60 * 1024;
+            const bool sort = lds_sort <= lds_limit;
             const bool bb = feats[0]->sh.kind == DIST_BB;
             const bool gp = feats[0]->sh.kind == DIST_GP;
             const bool bnb = feats[0]->sh.kind == DIST_BNB;
@@ -1464,9 +1466,18 @@ struct Gibbs {
             }
             c.dirty = true;
 #define VS_APPLY(KIND, SORT, LDS)                                            \
-            hipLaunchKernelGGL((k_vs_apply<KIND, SORT>), grid, block, LDS,   \
-                               stream(), P, img, c.chunks.p,                 \
-                               c.sorted_rows.p, d_p2g_ptr, c.assign_pos.p)
+            do {                                                             \
+                if ((LDS) > 64 * 1024)   /* beyond the default opt-in */     \
+                    HIP_CHECK(hipFuncSetAttribute(                           \
+                        reinterpret_cast<const void *>(                      \
+                            &k_vs_apply<KIND, SORT>),                        \
+                        hipFuncAttributeMaxDynamicSharedMemorySize,          \
+                        (int)(LDS)));                                        \
+                hipLaunchKernelGGL((k_vs_apply<KIND, SORT>), grid, block,    \
+                                   LDS, stream(), P, img, c.chunks.p,        \
+                                   c.sorted_rows.p, d_p2g_ptr,               \
+                                   c.assign_pos.p);                          \
+            } while (0)
             if (bb && sort) VS_APPLY(DIST_BB, true, lds_sort);
             else if (bb) VS_APPLY(DIST_BB, false, lds_plain);
             else if (gp && sort) VS_APPLY(DIST_GP, true, lds_sort);
