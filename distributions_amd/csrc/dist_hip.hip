@@ -994,16 +994,37 @@ struct Gibbs {
             packed_dev = own_assign.p;
             assign = own_assign.p;
         }
-        // largest value of each count-valued feature (sizes the value tables)
+        if (vals_on_device && n) {   // the host-pointer form checked above
+            DeviceBuf<uint32_t> mx;
+            mx.reserve(1, 0);
+            LAUNCH(k_max_value, n, packed_dev, n, mx.p);
+            uint32_t top = 0;
+            mx.download(&top, 1);
+            DIST_REQUIRE(top < (uint32_t)nonempty, "bad groupid in assignments");
+        }
+        // largest value of each discrete feature (validation; sizes the
+        // value tables of the count-valued ones)
         max_value.assign((size_t)F(), 0);
         vs_cache.clear();
         for (int f = 0; f < F(); ++f) {
             const int kind = feats[f]->sh.kind;
-            if ((kind != DIST_GP && kind != DIST_BNB) || !n) continue;
+            if (kind == DIST_NICH || !n) continue;
             DeviceBuf<uint32_t> mx;
             mx.reserve(1, 0);
             LAUNCH(k_max_value, n, values[f], n, mx.p);
             mx.download(&max_value[f], 1);
+            // the reference asserts these in its debug builds (dd.hpp:125,
+            // bb.hpp value is a bool); here an out-of-range value would
+            // index outside the statistics
+            if (is_cat(kind))
+                DIST_REQUIRE(max_value[f] < (uint32_t)feats[f]->sh.dim,
+                             "value out of bounds in feature "
+                                 + std::to_string(f) + ": "
+                                 + std::to_string(max_value[f]));
+            if (kind == DIST_BB)
+                DIST_REQUIRE(max_value[f] <= 1u,
+                             "BetaBernoulli value is not 0/1 in feature "
+                                 + std::to_string(f));
         }
         // empty statistics for all groups
         py.counts.assign((size_t)Kt, 0);
@@ -1476,7 +1497,7 @@ struct Gibbs {
                 hipLaunchKernelGGL((k_vs_apply<KIND, SORT>), grid, block,    \
                                    LDS, stream(), P, img, c.chunks.p,        \
                                    c.sorted_rows.p, d_p2g_ptr,               \
-                                   c.assign_pos.p);                          \
+                                   c.assign_pos.p, (uint32_t)vs_nvals());    \
             } while (0)
             if (bb && sort) VS_APPLY(DIST_BB, true, lds_sort);
             else if (bb) VS_APPLY(DIST_BB, false, lds_plain);

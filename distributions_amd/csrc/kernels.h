@@ -1551,7 +1551,8 @@ template <int KIND, bool SORT>
 __global__ __launch_bounds__(kVsApplyBlock) void k_vs_apply(
         SweepParams P, StatImage img, const VsTile * __restrict__ chunks,
         uint32_t * __restrict__ sorted_rows,
-        const uint32_t * __restrict__ p2g, uint32_t * __restrict__ assign_pos) {
+        const uint32_t * __restrict__ p2g, uint32_t * __restrict__ assign_pos,
+        uint32_t nvals) {
     extern __shared__ int vs_lds[];
     const int K = P.K;
     int * delta = vs_lds;                 // [K]
@@ -1572,6 +1573,14 @@ __global__ __launch_bounds__(kVsApplyBlock) void k_vs_apply(
         if (go != gn) {
             atomicAdd(&delta[go], -1);
             atomicAdd(&delta[gn], 1);
+            if ((KIND == DIST_GP || KIND == DIST_BNB) && x >= nvals) {
+                // the chunk of counts beyond the value table: every row
+                // brings its own value to the sums
+                const int32_t v = (int32_t)P.values[0][P.row_begin
+                                                      + sorted_rows[pos + i]];
+                atomicAdd(&img.i1[0][go], -v);
+                atomicAdd(&img.i1[0][gn], v);
+            }
         }
         if (SORT) {
             rows_l[i] = sorted_rows[pos + i];
@@ -1591,7 +1600,8 @@ __global__ __launch_bounds__(kVsApplyBlock) void k_vs_apply(
             atomicAdd(x ? &img.i0[0][k] : &img.i1[0][k], dlt);
         } else if (KIND == DIST_GP || KIND == DIST_BNB) {
             atomicAdd(&img.i0[0][k], dlt);                    // count
-            atomicAdd(&img.i1[0][k], dlt * (int32_t)x);       // sum
+            if (x < nvals)
+                atomicAdd(&img.i1[0][k], dlt * (int32_t)x);   // sum
         } else {
             atomicAdd(&img.i0[0][k], dlt);
             atomicAdd(&img.cnt[0][(size_t)k * dim + x], dlt);
