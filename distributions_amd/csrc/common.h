@@ -87,6 +87,7 @@ struct DeviceBuf {
         T * q = nullptr;
         HIP_CHECK(hipMalloc(&q, n * sizeof(T)));
         HIP_CHECK(hipMemsetAsync(q, 0, n * sizeof(T), stream()));
+        if (keep > cap) keep = cap;   // no more than the old buffer holds
         if (p && keep)
             HIP_CHECK(hipMemcpyAsync(q, p, keep * sizeof(T),
                                      hipMemcpyDeviceToDevice, stream()));

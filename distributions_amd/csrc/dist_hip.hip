@@ -1231,7 +1231,9 @@ struct Gibbs {
             // likelihood tables beyond a few MiB stream from HBM: vector loads
             const bool vec = (size_t)nv * T.Kpad * 4 > ((size_t)4 << 20);
             const dim3 grid((c->n_tiles + 3) / 4), block(kBlock);
-            if (vec)
+            if (!c->n_tiles) {
+                // every row's value lies beyond the table: all handed over
+            } else if (vec)
                 hipLaunchKernelGGL((k_vs_sample<KIND, true>), grid, block, 0,
                                    stream(), *P, T, c->tiles.p, c->n_tiles,
                                    c->sorted_rows.p, self->deferred.p,

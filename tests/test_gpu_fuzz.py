@@ -1,0 +1,20 @@
+"""A slice of tools/fuzz.py in the suite: random feature lists, clustering
+models, group sets, batch tilings, kernel choices and interleaved sequential
+stretches against the oracle (bit-exact)."""
+import os
+import sys
+
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(
+    os.path.abspath(__file__))), "tools"))
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("first", [0, 1000, 2000])
+def test_differential_fuzz(first):
+    import fuzz
+    failures = [err for err in (fuzz.trial(seed)
+                                for seed in range(first, first + 40)) if err]
+    assert not failures, failures
