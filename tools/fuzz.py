@@ -128,13 +128,64 @@ def trial(seed):
     return None
 
 
+def trial_collective(seed):
+    """the multi-GPU driver (integer deltas + all-reduce, ordered statistics
+    gathered and replayed) on ONE rank against the oracle's plain batches;
+    needs an initialised process group"""
+    import torch
+    rng = np.random.default_rng(seed)
+    L = ol.oracle()
+    n = int(rng.choice([64, 500, 3000]))
+    k = int(rng.choice([2, 9, 40]))
+    config = str(rng.choice(["dd", "bb", "gp", "nich", "gp_nich", "bnb",
+                             "dd_bb_gp"]))
+    import workloads
+    osh, gsh, vals, assign = workloads.make(config, n, k, seed=seed)
+    alpha, d = float(rng.uniform(0.2, 5)), float(rng.uniform(0, 0.8))
+    orc = ol.OracleMixture(alpha, d, osh)
+    orc.init_from_assignments(vals, assign, k, 2)
+    dev = torch.device("cuda", 0)
+    cols = [torch.from_numpy(ol.value_words(s.kind, v).view(np.int32)).to(dev)
+            for s, v in zip(osh, vals)]
+    a = torch.from_numpy(assign.view(np.int32)).to(dev)
+    gpu = engine.Gibbs(alpha, d, gsh)
+    gpu.set_option("value_sorted", int(rng.choice([0, 1, 2])))
+    gpu.load_rows_torch(cols, a.clone(), k, 2)
+    sharded = engine.ShardedGibbs(gpu.core, n, 0, device=dev,
+                                  force_collective=True, columns=cols,
+                                  assign_packed=a)
+    sharded.sync_initial_stats()
+    what = "collective seed %d: %s n=%d k=%d" % (seed, config, n, k)
+    err = same_state(orc, gpu)
+    if err:
+        return what + " after the initial exchange: " + err
+    eng_seed = int(rng.integers(1, 2 ** 31 - 1))
+    st = L.orc_rng_seed(eng_seed)
+    for sweep in range(3):
+        batch = int(rng.choice([50, 400, n]))
+        for b0 in range(0, n, batch):
+            orc.gibbs_batch(b0, min(n, b0 + batch), st, sweep * n)
+        sharded.sweep(batch, eng_seed, draw_base=sweep * n)
+        torch.cuda.synchronize()
+        err = same_state(orc, gpu)
+        if err:
+            return what + " sweep %d batch %d: %s" % (sweep, batch, err)
+    return None
+
+
 def main():
     trials = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    collective = len(sys.argv) > 3 and sys.argv[3] == "collective"
+    if collective:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29544")
+        dist.init_process_group("nccl", rank=0, world_size=1)
     failures = 0
     for seed in range(first, first + trials):
         try:
-            err = trial(seed)
+            err = trial_collective(seed) if collective else trial(seed)
         except Exception as e:   # noqa: BLE001
             err = "seed %d: exception %r" % (seed, e)
         if err:
