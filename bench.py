@@ -130,7 +130,17 @@ def main():
     args = parse()
     import torch
     import torch.distributed as dist
-    from distributions_amd import _core, engine
+    try:
+        from distributions_amd import _core, engine
+    except (ImportError, OSError):
+        # a checkout without the built libraries: compile them, then go on
+        # (there is no other way to run: the product has no CPU path)
+        import __graft_entry__
+        if int(os.environ.get("LOCAL_RANK", "0")) == 0:
+            __graft_entry__.build()
+        else:
+            time.sleep(240)
+        from distributions_amd import _core, engine
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
