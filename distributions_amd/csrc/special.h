@@ -126,8 +126,11 @@ DIST_HD float fast_exp_nonpos(float x, const uint32_t * exp_table, float a,
 // calls glibc's lgammaf there (special.hpp:121-123); this evaluates lgamma in
 // binary64 and rounds once, which is exact for y = 1, 2 and within 1 ulp of
 // glibc elsewhere (DESIGN.md "Known numeric gaps").
-DIST_HD float libm_lgammaf(float y) {
 #if defined(__HIP_DEVICE_COMPILE__)
+// Out of line on purpose: the branch is rare (groups of at most two members)
+// and its table search plus binary64 lgamma would otherwise be inlined into
+// every scoring loop and cost them their registers.
+static __device__ __noinline__ float libm_lgammaf_device(float y) {
     // registered arguments: glibc's value, bit for bit
     int lo = 0, hi = g_lgamma_lut.n;
     while (lo < hi) {
@@ -137,6 +140,11 @@ DIST_HD float libm_lgammaf(float y) {
     if (lo < g_lgamma_lut.n && g_lgamma_lut.y[lo] == y)
         return g_lgamma_lut.v[lo];
     return (float)::lgamma((double)y);
+}
+#endif
+DIST_HD float libm_lgammaf(float y) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return libm_lgammaf_device(y);
 #else
     return ::lgammaf(y);   // host side: the very libm call of the reference
 #endif
