@@ -1077,7 +1077,8 @@ struct Gibbs {
     int ktab_values(int f) const {
         const dist_shared_t & sh = feats[f]->sh;
         size_t nv = 0;
-        if (sh.kind == DIST_GP) nv = std::min<size_t>(max_value[f] + 1, 64);
+        if (sh.kind == DIST_GP || sh.kind == DIST_BNB)
+            nv = std::min<size_t>(max_value[f] + 1, 64);
         if (is_cat(sh.kind)) nv = (size_t)sh.dim;
         if (nv * (size_t)K() > ((size_t)256 << 20)) return 0;   // > 1 GiB
         return (int)nv;

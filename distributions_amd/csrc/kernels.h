@@ -722,8 +722,9 @@ struct RowScorer {
             const int kind = kind_of(f);
             const float * tab = P.ktab[f];
             const int nv = P.ktab_nv[f];
-            if (tab != nullptr && kind == DIST_GP) {
-                // acc += term (gp.cc:62-65); values beyond the table compute it
+            if (tab != nullptr && (kind == DIST_GP || kind == DIST_BNB)) {
+                // acc += term (gp.cc:62-65, bnb.hpp:316-327); values beyond
+                // the table compute it
                 const float term =
                     x[f] < (uint32_t)nv
                         ? tab[(size_t)k * nv + x[f]]
