@@ -79,33 +79,67 @@ void ensure_device_ready() {
 hipStream_t stream() { return nullptr; }   // the per-thread default stream
 
 // (y, glibc lgammaf(y)) pairs for the current device's table, sorted by y
-static std::map<int, std::map<float, float>> g_lgamma_registered;
-// Adds the arguments below 2.5 among `ys` to the device's table (see
-// special.h: the reference evaluates libm's lgammaf there).
-static void register_small_lgamma(const std::vector<float> & ys) {
-    std::lock_guard<std::mutex> lock(g_init_mutex);
-    int dev = 0;
-    HIP_CHECK(hipGetDevice(&dev));
-    std::map<float, float> & table = g_lgamma_registered[dev];
-    bool grew = false;
-    for (float y : ys) {
-        if (!(y > 0.f && y < 2.5f) || table.count(y)) continue;
-        if ((int)table.size() >= kLgammaLutCap) break;
-        table[y] = ::lgammaf(y);
-        grew = true;
-    }
-    if (!grew) return;
+// (y -> glibc lgammaf(y), users) per device.  lgammaf is a pure function, so
+// an entry is right whoever put it there; `users` only decides what may be
+// dropped when the table is full (entries of features that are gone).
+struct LgammaEntry {
+    float value;
+    int users;
+};
+static std::map<int, std::map<float, LgammaEntry>> g_lgamma_registered;
+
+static void upload_lgamma_table(const std::map<float, LgammaEntry> & table) {
     static LgammaLut staging;
     staging.n = 0;
     for (auto & kv : table) {
         staging.y[staging.n] = kv.first;
-        staging.v[staging.n] = kv.second;
+        staging.v[staging.n] = kv.second.value;
         staging.n += 1;
     }
     HIP_CHECK(hipDeviceSynchronize());   // no kernel may be reading the table
     HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_lgamma_lut), &staging,
                                 sizeof(LgammaLut)));
     HIP_CHECK(hipDeviceSynchronize());
+}
+// Adds the arguments below 2.5 among `ys` to the device's table (see
+// special.h: the reference evaluates libm's lgammaf there).  `hold`: the
+// caller keeps them in use until release_small_lgamma(ys).
+static void register_small_lgamma(const std::vector<float> & ys,
+                                  bool hold = false) {
+    std::lock_guard<std::mutex> lock(g_init_mutex);
+    int dev = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    std::map<float, LgammaEntry> & table = g_lgamma_registered[dev];
+    bool changed = false;
+    for (float y : ys) {
+        if (!(y > 0.f && y < 2.5f)) continue;
+        auto it = table.find(y);
+        if (it == table.end()) {
+            if ((int)table.size() >= kLgammaLutCap) {
+                // full: entries nobody holds any more make room
+                for (auto d = table.begin(); d != table.end();)
+                    d = d->second.users == 0 ? table.erase(d) : std::next(d);
+                changed = true;
+                if ((int)table.size() >= kLgammaLutCap) continue;
+            }
+            it = table.emplace(y, LgammaEntry{::lgammaf(y), 0}).first;
+            changed = true;
+        }
+        if (hold) it->second.users += 1;
+    }
+    if (changed) upload_lgamma_table(table);
+}
+static void release_small_lgamma(const std::vector<float> & ys) {
+    std::lock_guard<std::mutex> lock(g_init_mutex);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return;
+    auto t = g_lgamma_registered.find(dev);
+    if (t == g_lgamma_registered.end()) return;
+    for (float y : ys) {
+        auto it = t->second.find(y);
+        if (it != t->second.end() && it->second.users > 0)
+            it->second.users -= 1;
+    }
 }
 
 // the arguments below 2.5 that MixtureDataScorer::score_data hands to
@@ -213,6 +247,10 @@ struct Slave {
     DeviceBuf<float> f0, f1, c0, c1, c2, c3, S, prior, other;
     float other_host = 0.f;
     float gp_lut[12] = {0};   // see gp_lgamma (models.h)
+    std::vector<float> held_lgamma;   // see register_small_lgamma
+    ~Slave() { release_small_lgamma(held_lgamma); }
+    Slave(const Slave &) = delete;
+    Slave & operator=(const Slave &) = delete;
 
     explicit Slave(const dist_shared_t & shared) : sh(shared) {
         check_shared(sh);
@@ -253,13 +291,18 @@ struct Slave {
                 }
             }
             ys.push_back(sh.p[0] + sh.p[1]);
-            register_small_lgamma(ys);
+            held_lgamma.insert(held_lgamma.end(), ys.begin(), ys.end());
         }
         if (sh.kind == DIST_NICH && sh.p[3] < 0.0625f) {
             // fast_lgamma_nu's libm branch (special.hpp:226-229), reached
             // by a group without members when nu itself is below 1/16
-            register_small_lgamma({(sh.p[3] + 1.0f) * 0.5f, sh.p[3] * 0.5f});
+            held_lgamma.push_back((sh.p[3] + 1.0f) * 0.5f);
+            held_lgamma.push_back(sh.p[3] * 0.5f);
         }
+        // ... and what score_data reaches under this Shared; held in the
+        // device's table for as long as this feature lives
+        score_data_small_args(sh, held_lgamma);
+        register_small_lgamma(held_lgamma, true);
         if (sh.kind == DIST_DD) {
             // dd.hpp:403-406: alpha_sum_ accumulates in index order
             alpha_sum = 0.f;
@@ -497,11 +540,16 @@ struct Slave {
             for (size_t c = 0; c < n; ++c) scores_out[c] = 0.f;
             return;
         }
-        {   // glibc's lgammaf for the small arguments these candidates reach
-            std::vector<float> ys;
-            for (size_t c = 0; c < n; ++c) score_data_small_args(shareds[c], ys);
-            register_small_lgamma(ys);
-        }
+        // glibc's lgammaf for the small arguments these candidates reach,
+        // held for the duration of the call
+        std::vector<float> grid_args;
+        for (size_t c = 0; c < n; ++c)
+            score_data_small_args(shareds[c], grid_args);
+        register_small_lgamma(grid_args, true);
+        struct Release {
+            const std::vector<float> & ys;
+            ~Release() { release_small_lgamma(ys); }
+        } release_at_exit{grid_args};
         DeviceBuf<float> dp, dprior, dsum;
         dp.upload(cp.data(), cp.size());
         dprior.upload(cprior.data(), cprior.size());

@@ -41,7 +41,7 @@ extern const Tables * g_tables_host;     // host copy
 // so one table of (y, lgammaf(y)) pairs, sorted by y, serves every feature
 // on the device.  The host registers a model's reachable arguments when the
 // feature is created (register_small_lgamma, dist_hip.hip).
-constexpr int kLgammaLutCap = 2048;
+constexpr int kLgammaLutCap = 16384;
 struct LgammaLut {
     int n;
     float y[kLgammaLutCap];
