@@ -29,13 +29,16 @@ def same_state(orc, gpu):
     return None
 
 
-def trial(seed):
+def trial(seed, large=False):
     rng = np.random.default_rng(seed)
     L = ol.oracle()
     L.orc_mix_set_low_entropy.restype = None
     L.orc_mix_set_low_entropy.argtypes = [ctypes.c_void_p, ctypes.c_int]
     n = int(rng.choice([1, 2, 63, 64, 65, 500, 2000, 5000]))
     k = int(min(n, rng.choice([1, 2, 7, 33, 150])))
+    if large:   # group sets that cross the kernels' capacity steps
+        n = int(rng.choice([20000, 60000]))
+        k = int(rng.choice([250, 1000, 3000]))
     empty = int(rng.integers(1, 4))
     nf = int(rng.choice([1, 1, 1, 2, 3]))
     feats_o, feats_g, vals, desc = [], [], [], []
@@ -118,6 +121,8 @@ def trial(seed):
             # the chain consumed its own stream; batches keep theirs
         else:
             batch = int(rng.choice([1, 7, 64, 333, 4096, n]))
+            if large:
+                batch = int(rng.choice([4096, 20000, n]))
             for b0 in range(0, n, batch):
                 orc.gibbs_batch(b0, min(n, b0 + batch), st, draw)
             gpu.sweep(0, n, batch, eng_seed, draw_base=draw)
@@ -177,6 +182,7 @@ def main():
     trials = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     collective = len(sys.argv) > 3 and sys.argv[3] == "collective"
+    large = len(sys.argv) > 3 and sys.argv[3] == "large"
     if collective:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -185,7 +191,8 @@ def main():
     failures = 0
     for seed in range(first, first + trials):
         try:
-            err = trial_collective(seed) if collective else trial(seed)
+            err = (trial_collective(seed) if collective
+                   else trial(seed, large=large))
         except Exception as e:   # noqa: BLE001
             err = "seed %d: exception %r" % (seed, e)
         if err:
