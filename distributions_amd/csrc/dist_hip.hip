@@ -1277,18 +1277,9 @@ struct Gibbs {
                                c->n_other);
             HIP_CHECK(hipGetLastError());
             HIP_CHECK(hipEventRecord(self->ev0, stream()));
-            // likelihood tables beyond a few MiB stream from HBM: vector loads
-            const bool vec = (size_t)nv * T.Kpad * 4 > ((size_t)4 << 20);
             const dim3 grid((c->n_tiles + 3) / 4), block(kBlock);
-            if (!c->n_tiles) {
-                // every row's value lies beyond the table: all handed over
-            } else if (vec)
-                hipLaunchKernelGGL((k_vs_sample<KIND, true>), grid, block, 0,
-                                   stream(), *P, T, c->tiles.p, c->n_tiles,
-                                   c->sorted_rows.p, self->deferred.p,
-                                   self->deferred_count.p);
-            else
-                hipLaunchKernelGGL((k_vs_sample<KIND, false>), grid, block, 0,
+            if (c->n_tiles)   // else every row's value lies beyond the table
+                hipLaunchKernelGGL((k_vs_sample<KIND>), grid, block, 0,
                                    stream(), *P, T, c->tiles.p, c->n_tiles,
                                    c->sorted_rows.p, self->deferred.p,
                                    self->deferred_count.p);

@@ -1351,25 +1351,14 @@ constexpr int kVsR = 1;
 // each lane crosses zero in exactly one chunk; the scan only records that
 // chunk and the value of t on entry, and the lane then replays its 16
 // subtractions to get the exact index.
-// VEC: the vector does not fit the scalar cache (large value tables stream
-// from HBM): lanes fetch the chunk with one coalesced vector load and its
-// entries are broadcast with v_readlane instead of arriving by scalar loads.
-template <bool VEC>
-__device__ __forceinline__ void vs_fetch_chunk(uniform_fp lp,
-                                               const float * lp_vec, int k0,
+// Tables far larger than the scalar cache (C5: 328 MB) stream through the same
+// scalar loads: a coalesced-vector-load + v_readlane variant measured 1.2-1.7x
+// slower at every table size and was dropped.
+__device__ __forceinline__ void vs_fetch_chunk(uniform_fp lp, int k0,
                                                float (&l)[kVsUnroll]) {
-    if (VEC) {
-        const float mine = lp_vec[k0 + (threadIdx.x & (kVsUnroll - 1))];
 #pragma unroll
-        for (int j = 0; j < kVsUnroll; ++j)
-            l[j] = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(mine), j));
-    } else {
-#pragma unroll
-        for (int j = 0; j < kVsUnroll; ++j) l[j] = lp[k0 + j];
-    }
+    for (int j = 0; j < kVsUnroll; ++j) l[j] = lp[k0 + j];
 }
-
-template <bool VEC>
 __device__ __forceinline__ void vs_sum_and_scan(
         uniform_fp lp, const float * lp_vec, int K, const int (&g)[kVsR],
         const float (&l_own)[kVsR], const float (&u)[kVsR],
@@ -1383,7 +1372,7 @@ __device__ __forceinline__ void vs_sum_and_scan(
     }
     for (int c = 0, k0 = 0; k0 < K; ++c, k0 += kVsUnroll) {
         float l[kVsUnroll];
-        vs_fetch_chunk<VEC>(lp, lp_vec, k0, l);
+        vs_fetch_chunk(lp, k0, l);
 #pragma unroll
         for (int r = 0; r < kVsR; ++r) {
             if (__any(gchunk[r] == c)) {
@@ -1406,7 +1395,7 @@ __device__ __forceinline__ void vs_sum_and_scan(
     }
     for (int c = 0, k0 = 0; k0 < K; ++c, k0 += kVsUnroll) {
         float l[kVsUnroll];
-        vs_fetch_chunk<VEC>(lp, lp_vec, k0, l);
+        vs_fetch_chunk(lp, k0, l);
         bool more = false;
 #pragma unroll
         for (int r = 0; r < kVsR; ++r) {
@@ -1446,7 +1435,7 @@ __device__ __forceinline__ void vs_sum_and_scan(
     }
 }
 
-template <int KIND, bool VEC>
+template <int KIND>
 __global__ __launch_bounds__(kBlock) void k_vs_sample(
         SweepParams P, VsTables T, const VsTile * __restrict__ tiles,
         uint32_t n_tiles, const uint32_t * __restrict__ sorted_rows,
@@ -1512,14 +1501,14 @@ __global__ __launch_bounds__(kBlock) void k_vs_sample(
     if (__any(anyA)) {
         const float * vec = T.LA + (size_t)x * T.Kpad;
         int f[kVsR];
-        vs_sum_and_scan<VEC>(as_uniform(vec), vec, K, g, l_own, u, inA, f);
+        vs_sum_and_scan(as_uniform(vec), vec, K, g, l_own, u, inA, f);
 #pragma unroll
         for (int r = 0; r < kVsR; ++r) g2[r] = inA[r] ? f[r] : g2[r];
     }
     if (__any(anyB)) {
         const float * vec = T.LB + (size_t)x * T.Kpad;
         int f[kVsR];
-        vs_sum_and_scan<VEC>(as_uniform(vec), vec, K, g, l_own, u, inB, f);
+        vs_sum_and_scan(as_uniform(vec), vec, K, g, l_own, u, inB, f);
 #pragma unroll
         for (int r = 0; r < kVsR; ++r) g2[r] = inB[r] ? f[r] : g2[r];
     }
