@@ -779,6 +779,7 @@ struct Gibbs {
     bool batch_value_sorted = false;
     bool moves_in_row_order = false;   // old_row/new_row hold the open batch
     bool base_valid = false;           // base[], base_single[], scalars current
+    bool cells_fresh = false;          // set by apply_ints, used by batch_finish
     bool timing_pending = false;
     int * pinned_counts = nullptr;
     size_t pinned_cap = 0;
@@ -794,6 +795,7 @@ struct Gibbs {
         uint32_t n_tiles = 0;
         DeviceBuf<VsTile> chunks;          // apply work items, one value each
         uint32_t n_chunks = 0;
+        bool one_chunk_per_value = false;
         DeviceBuf<uint32_t> other_pos;    // positions the tiles do not cover
         uint32_t n_other = 0;
         // the rows' current assignment (global ids) in sorted-position
@@ -1242,6 +1244,9 @@ struct Gibbs {
                                         std::min<uint32_t>(kVsApplyRows,
                                                            h[x] - off)});
         c->n_chunks = (uint32_t)chunks.size();
+        c->one_chunk_per_value = true;
+        for (uint32_t x = 0; x <= nv; ++x)
+            if (h[x] > (uint32_t)kVsApplyRows) c->one_chunk_per_value = false;
         c->chunks.upload(chunks.data(), chunks.size());
         // rows whose value is outside the table: generic kernel, by position
         c->n_other = h[nv];
@@ -1516,6 +1521,13 @@ struct Gibbs {
             const bool gp = feats[0]->sh.kind == DIST_GP;
             const bool bnb = feats[0]->sh.kind == DIST_BNB;
             const dim3 grid(c.n_chunks), block(kVsApplyBlock);
+            // one chunk per value and live statistics: the kernel keeps the
+            // touched cache cells current and batch_finish skips the rebuild
+            // (worth it when the full rebuild is the bigger cost: wide tables)
+            const int refresh = (c.one_chunk_per_value && is_cat(
+                feats[0]->sh.kind) && img.counts == py.d_counts.p
+                && (size_t)K() * feats[0]->dim() > ((size_t)1 << 22)) ? 1 : 0;
+            cells_fresh = refresh != 0;
             // float statistics replay in ROW order: un-sort the moves first
             // (before the kernel below permutes sorted_rows)
             if (any_float_stats()) {
@@ -1539,7 +1551,8 @@ struct Gibbs {
                 hipLaunchKernelGGL((k_vs_apply<KIND, SORT>), grid, block,    \
                                    LDS, stream(), P, img, c.chunks.p,        \
                                    c.sorted_rows.p, d_p2g_ptr,               \
-                                   c.assign_pos.p, (uint32_t)vs_nvals());    \
+                                   c.assign_pos.p, (uint32_t)vs_nvals(),     \
+                                   refresh);                                 \
             } while (0)
             if (bb && sort) VS_APPLY(DIST_BB, true, lds_sort);
             else if (bb) VS_APPLY(DIST_BB, false, lds_plain);
@@ -1688,14 +1701,20 @@ struct Gibbs {
         memset(&Q, 0, sizeof(Q));
         Q.F = F();
         size_t cells = (size_t)K();
+        const bool fresh = cells_fresh;
         for (int f = 0; f < F(); ++f) {
             Q.feat[f] = feats[f]->view();
-            cells = std::max(cells, (size_t)K() * std::max(1, feats[f]->dim()));
+            // with current cells only the appended groups need a full column
+            const size_t groups = fresh ? (size_t)(K() - k_new) : (size_t)K();
+            cells = std::max(cells, groups * std::max(1, feats[f]->dim()));
         }
         Q.counts = py.d_counts.p;
         Q.shifted = py.d_shifted.p;
         Q.K = K();
         Q.k_new = k_new;
+        // (moved groups carry their cache entries with them)
+        Q.cells_fresh = cells_fresh ? 1 : 0;
+        cells_fresh = false;
         Q.alpha = alpha;
         Q.d = d;
         Q.nonempty = K() - py.n_empty;

@@ -277,6 +277,7 @@ struct FinishParams {
     int32_t * counts;      // driver
     float * shifted;
     int K, k_new;
+    int cells_fresh;       // categorical cells of old groups are current
     float alpha, d;
     int nonempty, empty;
     DriverPrep prep;       // the next batch's base scores, while we are here
@@ -312,9 +313,21 @@ __global__ void k_batch_finish(FinishParams P) {
     }
     const SlaveView & s = P.feat[blockIdx.y];
     if (is_cat(s.kind)) {
-        if (i >= (size_t)K * s.dim) return;
-        const int v = (int)(i / K);
-        const int k = (int)(i % K);     // group fastest: S[v][k] coalesces
+        int v, k;
+        if (P.cells_fresh) {
+            // only the appended groups' cells and every group's shift
+            const int n_new = K - P.k_new;
+            if (i < (size_t)K) {
+                if ((int)i < P.k_new) refresh_shift(s, (int)i);
+            }
+            if (i >= (size_t)n_new * s.dim) return;
+            v = (int)(i / n_new);
+            k = P.k_new + (int)(i % n_new);
+        } else {
+            if (i >= (size_t)K * s.dim) return;
+            v = (int)(i / K);
+            k = (int)(i % K);     // group fastest: S[v][k] coalesces
+        }
         if (k >= P.k_new) {
             s.cnt[(size_t)k * s.dim + v] = 0;
             if (v == 0) { s.i0[k] = 0; s.i1[k] = 0; s.f0[k] = 0.f; s.f1[k] = 0.f; }
@@ -1542,7 +1555,7 @@ __global__ __launch_bounds__(kVsApplyBlock) void k_vs_apply(
         SweepParams P, StatImage img, const VsTile * __restrict__ chunks,
         uint32_t * __restrict__ sorted_rows,
         const uint32_t * __restrict__ p2g, uint32_t * __restrict__ assign_pos,
-        uint32_t nvals) {
+        uint32_t nvals, int refresh_cells) {
     extern __shared__ int vs_lds[];
     const int K = P.K;
     int * delta = vs_lds;                 // [K]
@@ -1594,7 +1607,16 @@ __global__ __launch_bounds__(kVsApplyBlock) void k_vs_apply(
                 atomicAdd(&img.i1[0][k], dlt * (int32_t)x);   // sum
         } else {
             atomicAdd(&img.i0[0][k], dlt);
-            atomicAdd(&img.cnt[0][(size_t)k * dim + x], dlt);
+            const int before = atomicAdd(&img.cnt[0][(size_t)k * dim + x], dlt);
+            if (refresh_cells) {
+                // this workgroup is the only one that touches cell (k, x)
+                // (one chunk per value, live statistics): leave its cache
+                // entry current (dd.hpp:458-467) and spare the batch's tail
+                // a rebuild of all K * dim cells
+                const SlaveView & s = P.feat[0];
+                s.S[(size_t)x * s.cap + k] =
+                    fast_log(s.prior[x] + (float)(before + dlt));
+            }
         }
     }
     if (!SORT) return;
