@@ -1047,7 +1047,7 @@ struct Gibbs {
         if (vals_on_device && n) {   // the host-pointer form checked above
             DeviceBuf<uint32_t> mx;
             mx.reserve(1, 0);
-            LAUNCH(k_max_value, n, packed_dev, n, mx.p);
+            LAUNCH(k_max_value, std::min<size_t>(n, (size_t)2048 * kBlock), packed_dev, n, mx.p);
             uint32_t top = 0;
             mx.download(&top, 1);
             DIST_REQUIRE(top < (uint32_t)nonempty, "bad groupid in assignments");
@@ -1061,7 +1061,7 @@ struct Gibbs {
             if (kind == DIST_NICH || !n) continue;
             DeviceBuf<uint32_t> mx;
             mx.reserve(1, 0);
-            LAUNCH(k_max_value, n, values[f], n, mx.p);
+            LAUNCH(k_max_value, std::min<size_t>(n, (size_t)2048 * kBlock), values[f], n, mx.p);
             mx.download(&max_value[f], 1);
             // the reference asserts these in its debug builds (dd.hpp:125,
             // bb.hpp value is a bool); here an out-of-range value would

@@ -1648,12 +1648,15 @@ __global__ __launch_bounds__(kVsApplyBlock) void k_vs_apply(
     }
 }
 
+// (grid-stride: a bounded number of atomics on the one result word)
 __global__ void k_max_value(const uint32_t * __restrict__ values, size_t n,
                             uint32_t * out) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t v = i < n ? values[i] : 0u;
+    uint32_t v = 0u;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (size_t)gridDim.x * blockDim.x)
+        v = max(v, values[i]);
     for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off));
-    if ((threadIdx.x & 63) == 0) atomicMax(out, v);
+    if ((threadIdx.x & 63) == 0 && v) atomicMax(out, v);
 }
 
 // row order <-> value-sorted position order
