@@ -38,6 +38,7 @@ cdef extern from "distributions_hip.h" nogil:
     int dist_device_count(int *)
     int dist_set_device(int)
     int dist_synchronize()
+    int dist_set_stream(void *)
     uint32_t dist_rng_seed(uint64_t)
     uint32_t dist_rng_next(uint32_t *)
     float dist_rng_unif01(uint32_t *)
@@ -220,6 +221,12 @@ def set_device(int device):
 
 def synchronize():
     check(dist_synchronize())
+
+
+def set_stream(size_t hip_stream):
+    """the calling thread's HIP stream (0 = default), e.g.
+    torch.cuda.Stream().cuda_stream"""
+    check(dist_set_stream(<void *> hip_stream))
 
 
 # ---------------------------------------------------------------------------

@@ -76,7 +76,11 @@ void ensure_device_ready() {
     g_ready_devices.insert(dev);
 }
 
-hipStream_t stream() { return nullptr; }   // the per-thread default stream
+// Every launch and copy of the calling thread goes to this stream: the
+// default (null) stream unless dist_set_stream gave the thread its own, which
+// lets independent engines -- one per host thread -- overlap on the device.
+static thread_local hipStream_t t_stream = nullptr;
+hipStream_t stream() { return t_stream; }
 
 // (y, glibc lgammaf(y)) pairs for the current device's table, sorted by y
 // (y -> glibc lgammaf(y), users) per device.  lgammaf is a pure function, so
@@ -425,17 +429,19 @@ struct Slave {
         check_group(g);
         int32_t a, b;
         float x, y;
-        HIP_CHECK(hipMemcpy(&a, i0.p + g, 4, hipMemcpyDeviceToHost));
-        HIP_CHECK(hipMemcpy(&b, i1.p + g, 4, hipMemcpyDeviceToHost));
-        HIP_CHECK(hipMemcpy(&x, f0.p + g, 4, hipMemcpyDeviceToHost));
-        HIP_CHECK(hipMemcpy(&y, f1.p + g, 4, hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpyAsync(&a, i0.p + g, 4, hipMemcpyDeviceToHost, stream()));
+        HIP_CHECK(hipMemcpyAsync(&b, i1.p + g, 4, hipMemcpyDeviceToHost, stream()));
+        HIP_CHECK(hipMemcpyAsync(&x, f0.p + g, 4, hipMemcpyDeviceToHost, stream()));
+        HIP_CHECK(hipMemcpyAsync(&y, f1.p + g, 4, hipMemcpyDeviceToHost, stream()));
+        HIP_CHECK(hipStreamSynchronize(stream()));
         out[0] = (uint32_t)a;
         switch (sh.kind) {
         case DIST_DD:
         case DIST_DPD:
-            HIP_CHECK(hipMemcpy(out + 1, cnt.p + g * sh.dim,
-                                sizeof(int32_t) * sh.dim,
-                                hipMemcpyDeviceToHost));
+            HIP_CHECK(hipMemcpyAsync(out + 1, cnt.p + g * sh.dim,
+                                     sizeof(int32_t) * sh.dim,
+                                     hipMemcpyDeviceToHost, stream()));
+            HIP_CHECK(hipStreamSynchronize(stream()));
             break;
         case DIST_BB:
         case DIST_BNB:
@@ -1866,6 +1872,9 @@ int dist_set_device(int device) {
 int dist_synchronize(void) {
     return guarded([&] { HIP_CHECK(hipDeviceSynchronize()); });
 }
+int dist_set_stream(void * hip_stream) {
+    return guarded([&] { t_stream = static_cast<hipStream_t>(hip_stream); });
+}
 size_t dist_group_words(const dist_shared_t * shared) {
     return group_words(*shared);
 }
@@ -2616,9 +2625,12 @@ int dist_gibbs_assignments(const dist_gibbs_t * g, uint32_t * global_out) {
     return guarded([&] {
         g->impl->flush_assign_pos();
         sync();
-        if (g->impl->n_rows)
-            HIP_CHECK(hipMemcpy(global_out, g->impl->assign,
-                                g->impl->n_rows * 4, hipMemcpyDeviceToHost));
+        if (g->impl->n_rows) {
+            HIP_CHECK(hipMemcpyAsync(global_out, g->impl->assign,
+                                     g->impl->n_rows * 4,
+                                     hipMemcpyDeviceToHost, stream()));
+            sync();
+        }
     });
 }
 int dist_gibbs_get_group(const dist_gibbs_t * g, int feature, size_t groupid,

@@ -72,6 +72,12 @@ const char * dist_last_error(void);
 int dist_device_count(int * count);
 int dist_set_device(int device);
 int dist_synchronize(void);
+/* The HIP stream (hipStream_t, NULL = the default stream) that carries every
+ * launch and copy the CALLING THREAD makes from now on.  Independent engines
+ * driven from different host threads on different streams overlap on the
+ * device; objects must be used on the stream they were created on (or after
+ * the caller has synchronised the two). */
+int dist_set_stream(void * hip_stream);
 
 /* ---- entropy: rng_t = std::default_random_engine (random_fwd.hpp:34) ----
  * The engine state is one word; sample_unif01 (random.hpp:47-50) consumes

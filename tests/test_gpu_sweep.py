@@ -401,3 +401,49 @@ def test_nich_with_tiny_nu_uses_libm_values_for_empty_groups():
             orc.gibbs_batch(b, b + 125, st, sweep * n)
         gpu.sweep(0, n, 125, 3, draw_base=sweep * n)
         assert_same_state(orc, gpu, "tiny nu sweep %d" % sweep)
+
+
+def test_independent_engines_on_their_own_streams():
+    """dist_set_stream: two host threads, each with its own HIP stream and
+    engine, run sequential chains concurrently; both reproduce the oracle"""
+    import threading
+    import torch
+    from distributions_amd import _core, engine
+    n, k = 1500, 20
+    results = {}
+
+    def worker(tag, config, seed):
+        stream = torch.cuda.Stream()
+        _core.set_stream(stream.cuda_stream)
+        try:
+            osh, gsh, vals, assign = workloads.make(config, n, k)
+            gpu = engine.Gibbs(1.0, 0.2, gsh)
+            gpu.load_rows(vals, assign, k, 1)
+            st = gpu.sweep_sequential(0, n, _core.rng_seed(seed))
+            gpu.sweep(0, n, 500, seed, draw_base=0)
+            results[tag] = (st, gpu.assignments().copy(), gpu.counts().copy())
+        except Exception as e:   # noqa: BLE001
+            results[tag] = e
+        finally:
+            _core.set_stream(0)
+
+    jobs = [("a", "dd", 3), ("b", "gp_nich", 4)]
+    threads = [threading.Thread(target=worker, args=j) for j in jobs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    L = ol.oracle()
+    for tag, config, seed in jobs:
+        assert not isinstance(results[tag], Exception), results[tag]
+        osh, gsh, vals, assign = workloads.make(config, n, k)
+        orc = ol.OracleMixture(1.0, 0.2, osh)
+        orc.init_from_assignments(vals, assign, k, 1)
+        st = L.orc_rng_seed(seed)
+        state = orc.gibbs_sequential(0, n, st)
+        for b in range(0, n, 500):
+            orc.gibbs_batch(b, b + 500, st, 0)
+        got_state, got_assign, got_counts = results[tag]
+        assert got_state == state
+        np.testing.assert_array_equal(got_assign, orc.assign)
+        np.testing.assert_array_equal(got_counts, orc.counts())
