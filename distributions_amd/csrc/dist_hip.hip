@@ -1637,7 +1637,6 @@ struct Gibbs {
         const std::vector<int> snap = py.counts;
         const int K0 = K();
         refresh_host_counts();
-        collect_timing();
         int created = 0;
         for (int k = 0; k < K0; ++k)
             if (snap[k] == 0 && py.counts[k] > 0) created += 1;
@@ -1740,6 +1739,9 @@ struct Gibbs {
                                 (unsigned)(F() + 1)),
                            dim3(kBlock), 0, stream(), Q);
         HIP_CHECK(hipGetLastError());
+        // (reading the batch's kernel timer waits on nothing by now, and the
+        // device already has its next launch)
+        collect_timing();
     }
 
     void sweep(size_t r0, size_t r1, size_t batch, uint32_t seed,
