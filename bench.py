@@ -51,7 +51,7 @@ def parse():
     ap.add_argument("--cpu-rows", type=int, default=1_000_000,
                     help="rows of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--config", default="dd",
-                    choices=["dd", "gp_nich", "dpd", "bb", "gp", "nich"],
+                    choices=["dd", "gp_nich", "dpd", "bb", "gp", "nich", "mixed"],
                     help="dd = the headline workload (BASELINE configs[1]); "
                          "the others are the remaining BASELINE configs, for "
                          "DESIGN.md's table (not the bench line of record)")
@@ -192,6 +192,20 @@ def main():
         columns = [normal()]
         shareds = [engine.nich_shared(0.0, 1.0, 1.0, 1.0)]
         bytes_per_row = 20 * k + 12
+    elif args.config == "mixed":
+        # a row of mixed type, the shape of real tables: two categoricals, a
+        # boolean, a count and a real (run-time feature list in the kernel)
+        columns = [torch.randint(0, 16, (n,), generator=gen, device=dev,
+                                 dtype=torch.int32),
+                   torch.randint(0, 4, (n,), generator=gen, device=dev,
+                                 dtype=torch.int32),
+                   (torch.rand((n,), generator=gen, device=dev) < 0.3).to(
+                       torch.int32),
+                   poisson(5.0), normal()]
+        shareds = [engine.dd_shared([0.5] * 16), engine.dd_shared([0.5] * 4),
+                   engine.bb_shared(0.5, 2.0), engine.gp_shared(1.0, 1.0),
+                   engine.nich_shared(0.0, 1.0, 1.0, 1.0)]
+        bytes_per_row = (1 + 2 + 2 + 1 + 3 + 4) * 4 * k + 28
     else:   # gp_nich: BASELINE configs[2]
         columns = [poisson(5.0), normal()]
         shareds = [engine.gp_shared(1.0, 1.0),
@@ -260,7 +274,9 @@ def main():
                                         % args.dim,
                                  "bb": "BetaBernoulli", "gp": "GammaPoisson",
                                  "nich": "NormalInverseChiSq",
-                                 "gp_nich": "GammaPoisson+NormalInverseChiSq"
+                                 "gp_nich": "GammaPoisson+NormalInverseChiSq",
+                                 "mixed": "DD(16)+DD(4)+BetaBernoulli+"
+                                          "GammaPoisson+NormalInverseChiSq",
                                  }[args.config],
                                 n, k, args.alpha, args.d, args.batch),
                 "rows_per_gpu": n, "groups": k, "dim": args.dim,

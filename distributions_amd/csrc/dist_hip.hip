@@ -841,6 +841,7 @@ struct Gibbs {
     std::vector<std::unique_ptr<VsCache>> vs_cache;
     DeviceBuf<float> vsLA, vsLB, vsM, vsmB;
     DeviceBuf<ChainResult> chain_result;
+    DeviceBuf<float> own_score;             // k_row_prepass
     int sequential_mode = 1;   // 0: every row as a batch of one (diagnostic)
     DeviceBuf<int> vsArg;
     DeviceBuf<uint32_t> deferred, deferred_count;
@@ -1135,6 +1136,7 @@ struct Gibbs {
         size_t nv = 0;
         if (sh.kind == DIST_GP || sh.kind == DIST_BNB)
             nv = std::min<size_t>(max_value[f] + 1, 64);
+        if (sh.kind == DIST_BB) nv = 2;
         if (is_cat(sh.kind)) nv = (size_t)sh.dim;
         if (nv * (size_t)K() > ((size_t)256 << 20)) return 0;   // > 1 GiB
         return (int)nv;
@@ -1165,6 +1167,74 @@ struct Gibbs {
         }
     }
 
+    // feature lists without a compile-time instance of the sampling kernel
+    bool uses_runtime_kernel() const {
+        const int k0 = F() > 0 ? feats[0]->sh.kind : -1;
+        const int k1 = F() > 1 ? feats[1]->sh.kind : -1;
+        if (F() == 1) return false;
+        if (F() == 2 && k0 == DIST_GP && k1 == DIST_NICH) return false;
+        return F() >= 2;
+    }
+    // Rows of mixed type: compile the feature list into a ScoreProgram over
+    // this batch's tables (kernels.h) and sample with k_sweep_program; rows it
+    // hands over go to the wave-per-row kernel.  false: a table is missing
+    // (a categorical feature too wide to tabulate), take the model-code kernel.
+    bool sample_by_program(SweepParams & P) {
+        prepare(P);   // base[], and every feature's k-major table
+        ScoreProgram prog;
+        memset(&prog, 0, sizeof(prog));
+        for (int f = 0; f < F(); ++f) {
+            const int kind = feats[f]->sh.kind;
+            const SlaveView v = feats[f]->view();
+            ScoreOp & op = prog.op[prog.n];
+            op.f = f;
+            if (kind == DIST_NICH) {
+                op.type = OP_NICH;
+                op.p0 = v.c0; op.p1 = v.c1; op.p2 = v.c2; op.p3 = v.c3;
+                prog.n += 1;
+                continue;
+            }
+            if (!P.ktab[f]) return false;
+            op.type = OP_GATHER_ADD;
+            op.nv = (uint32_t)P.ktab_nv[f];
+            op.p0 = P.ktab[f];
+            prog.n += 1;
+            if (is_cat(kind)) {
+                ScoreOp & sub = prog.op[prog.n];
+                sub.type = OP_VEC_SUB;
+                sub.f = f;
+                sub.p0 = v.c0;
+                prog.n += 1;
+            }
+        }
+        const size_t n = P.row_end - P.row_begin;
+        own_score.reserve(std::max<size_t>(n, 1), 0);
+        deferred.reserve(std::max<size_t>(n, 1), 0);
+        deferred_count.reserve(1, 0);
+        HIP_CHECK(hipMemsetAsync(deferred_count.p, 0, 4, stream()));
+        HIP_CHECK(hipEventRecord(ev0, stream()));
+        LAUNCH(k_row_prepass, n, P, prog, own_score.p, deferred.p,
+               deferred_count.p);
+        const unsigned blocks = (unsigned)std::min<size_t>(
+            (n + kBlock - 1) / kBlock, 256 * 16);
+        hipLaunchKernelGGL(k_sweep_program, dim3(blocks), dim3(kBlock), 0,
+                           stream(), P, prog, own_score.p);
+        HIP_CHECK(hipGetLastError());
+        // the handed-over rows (listed by batch row, in row order)
+        SweepParams Q = P;
+        Q.row_list = deferred.p;
+        Q.row_list_count = deferred_count.p;
+        Q.sorted_rows = nullptr;
+        if (wave_rows_fit()) {
+            WaveRowsLaunch D{&Q, K(), 256};
+            dispatch(D);
+        } else {
+            DeferredLaunch D{&Q};
+            dispatch(D);
+        }
+        HIP_CHECK(hipEventRecord(ev1, stream()));
+        return true;
+    }
     struct SampleLaunch {
         Gibbs * self;
         SweepParams * P;
@@ -1398,6 +1468,8 @@ struct Gibbs {
                                         / (kBlock / 64))};
             dispatch(L);
             HIP_CHECK(hipEventRecord(ev1, stream()));
+            generic_batches += 1;
+        } else if (uses_runtime_kernel() && sample_by_program(P)) {
             generic_batches += 1;
         } else {
             prepare(P);

@@ -853,10 +853,14 @@ __global__ __launch_bounds__(kBlock) void k_sweep_sample(SweepParams P) {
         size_t out = live ? item : 0;
         size_t row = P.row_begin + out;
         uint32_t global_id;
-        if (P.row_list) {
+        if (P.row_list && P.sorted_rows) {
             out = live ? (size_t)P.row_list[item] : 0;
             row = P.row_begin + P.sorted_rows[out];
             global_id = P.assign_pos[out];
+        } else if (P.row_list) {   // a list of batch rows, in row order
+            out = live ? (size_t)P.row_list[item] : 0;
+            row = P.row_begin + out;
+            global_id = P.assign[row];
         } else {
             global_id = P.assign[row];
         }
@@ -901,6 +905,172 @@ __global__ __launch_bounds__(kBlock) void k_sweep_sample(SweepParams P) {
             P.old_packed[out] = (uint32_t)rs.g;
             P.new_packed[out] = (uint32_t)g2;
         }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Rows of mixed type (any feature list).  Scoring a row against a group is a
+// short PROGRAM over per-batch tables, so the loop over groups has no
+// model-specific code:
+//   OP_GATHER_ADD  s += tab[k][x]     DD/DPD: the transposed cache column
+//                                     (dd.hpp:433-445, first half); BB: the
+//                                     head/tail score; GP/BNB: the whole
+//                                     additive term (gp.cc:62-65)
+//   OP_VEC_SUB     s -= vec[k]        DD/DPD shift (second half of the above)
+//   OP_NICH        s += c0[k] + c1[k] * fast_log(1 + c2[k] * (x - c3[k])^2)
+// in feature order, which is the reference's order of float operations.  A
+// row's own slot takes a precomputed score (k_row_prepass: the statistics
+// minus the row, by the model code); rows alone in their group and rows with a
+// value outside a table are handed to the wave-per-row kernel.
+enum { OP_GATHER_ADD = 0, OP_VEC_SUB = 1, OP_NICH = 2 };
+constexpr int kMaxOps = 2 * kMaxF;
+struct ScoreOp {
+    int type;
+    int f;               // feature whose value the op reads
+    uint32_t nv;         // OP_GATHER_ADD: table width
+    const float * p0;    // table / vector / NICH c0
+    const float * p1;    // NICH c1..c3
+    const float * p2;
+    const float * p3;
+};
+struct ScoreProgram {
+    int n;
+    ScoreOp op[kMaxOps];
+};
+
+// own-slot score and hand-over flag of every batch row, by the model code
+__global__ void k_row_prepass(SweepParams P, ScoreProgram prog,
+                              float * __restrict__ own,
+                              uint32_t * __restrict__ handed,
+                              uint32_t * handed_count) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.row_end - P.row_begin) return;
+    const size_t row = P.row_begin + i;
+    const RowScorer<-1, -1, 0> rs(P, row, P.assign[row]);
+    bool hand = rs.singleton != 0;
+    for (int j = 0; j < prog.n; ++j)
+        if (prog.op[j].type == OP_GATHER_ADD
+            && P.values[prog.op[j].f][row] >= prog.op[j].nv)
+            hand = true;
+    own[i] = rs.s_own;
+    if (hand) {
+        handed[atomicAdd(handed_count, 1u)] = (uint32_t)i;
+        P.old_packed[i] = 0xFFFFFFFFu;   // mark: not ours
+    } else {
+        P.old_packed[i] = (uint32_t)rs.g;
+    }
+}
+
+// kProgramBlock consecutive groups are scored at a time into registers: an
+// op's parameters are fetched once per block and feature, not once per group.
+constexpr int kProgramBlock = 16;
+
+__device__ __forceinline__ void program_score_block(
+        const SweepParams & P, const ScoreProgram & prog,
+        const uint32_t (&xv)[kMaxOps], int k0, int g, float s_own,
+        float (&s)[kProgramBlock]) {
+    const int K = P.K;
+#pragma unroll
+    for (int j = 0; j < kProgramBlock; ++j) s[j] = as_uniform(P.base)[k0 + j];
+#pragma unroll
+    for (int o = 0; o < kMaxOps; ++o) {
+        if (o >= prog.n) break;
+        const int type = prog.op[o].type;
+        if (type == OP_GATHER_ADD) {
+            const uint32_t nv = prog.op[o].nv;
+            const float * tab = prog.op[o].p0 + xv[o];
+#pragma unroll
+            for (int j = 0; j < kProgramBlock; ++j) {
+                const int k = k0 + j < K ? k0 + j : K - 1;   // stay in the table
+                s[j] = s[j] + tab[(size_t)k * nv];
+            }
+        } else if (type == OP_VEC_SUB) {
+            uniform_fp vec = as_uniform(prog.op[o].p0);
+#pragma unroll
+            for (int j = 0; j < kProgramBlock; ++j) s[j] = s[j] - vec[k0 + j];
+        } else {
+            uniform_fp c0 = as_uniform(prog.op[o].p0);
+            uniform_fp c1 = as_uniform(prog.op[o].p1);
+            uniform_fp c2 = as_uniform(prog.op[o].p2);
+            uniform_fp c3 = as_uniform(prog.op[o].p3);
+            const float x = u2f(xv[o]);
+#pragma unroll
+            for (int j = 0; j < kProgramBlock; ++j) {
+                const float d = x - c3[k0 + j];
+                const float temp = 1.f + c2[k0 + j] * (d * d);
+                s[j] = s[j] + (c0[k0 + j] + c1[k0 + j] * fast_log(temp));
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < kProgramBlock; ++j)
+        if (k0 + j == g) s[j] = s_own;
+}
+
+__global__ __launch_bounds__(kBlock) void k_sweep_program(
+        SweepParams P, ScoreProgram prog, const float * __restrict__ own) {
+    __shared__ uint32_t s_exp[1024];
+    for (int i = threadIdx.x; i < 1024; i += kBlock)
+        s_exp[i] = g_tables_dev.exp_table[i];
+    __syncthreads();
+    const float ea = u2f(g_tables_dev.exp_ab[0]);
+    const float eb = u2f(g_tables_dev.exp_ab[1]);
+    const int K = P.K;
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    const size_t n_items = P.row_end - P.row_begin;
+    const size_t n_round = (n_items + 63) / 64 * 64;
+    for (size_t item = (size_t)blockIdx.x * kBlock + threadIdx.x;
+         item < n_round; item += stride) {
+        const bool in = item < n_items;
+        const size_t out = in ? item : 0;
+        const size_t row = P.row_begin + out;
+        const uint32_t slot = P.old_packed[out];   // k_row_prepass
+        const bool live = in && slot != 0xFFFFFFFFu;
+        const int g = live ? (int)slot : -1;
+        const float s_own = own[out];
+        // (a handed-over row idles along on value 0: its own values may lie
+        // outside the tables)
+        uint32_t xv[kMaxOps];
+#pragma unroll
+        for (int o = 0; o < kMaxOps; ++o) {
+            xv[o] = 0;
+            if (o < prog.n && prog.op[o].type != OP_VEC_SUB && live)
+                xv[o] = P.values[prog.op[o].f][row];
+        }
+        float s[kProgramBlock];
+        // vector_max (vector_math.cc:74-83)
+        float m = -INFINITY;
+        for (int k0 = 0; k0 < K; k0 += kProgramBlock) {
+            program_score_block(P, prog, xv, k0, g, s_own, s);
+#pragma unroll
+            for (int j = 0; j < kProgramBlock; ++j)
+                m = (k0 + j < K && s[j] > m) ? s[j] : m;
+        }
+        // scores_to_likelihoods: total in index order (random.cc:100-103)
+        float total = 0.f;
+        for (int k0 = 0; k0 < K; k0 += kProgramBlock) {
+            program_score_block(P, prog, xv, k0, g, s_own, s);
+#pragma unroll
+            for (int j = 0; j < kProgramBlock; ++j) {
+                const float l = fast_exp_nonpos(s[j] - m, s_exp, ea, eb);
+                total += k0 + j < K ? l : 0.f;
+            }
+        }
+        // sample_from_likelihoods (random.hpp:316-333): t never increases
+        float t = total * batch_row_unif01(P, row);
+        int steps = 0;
+        for (int k0 = 0; k0 < K; k0 += kProgramBlock) {
+            program_score_block(P, prog, xv, k0, g, s_own, s);
+#pragma unroll
+            for (int j = 0; j < kProgramBlock; ++j) {
+                if (k0 + j < K) {
+                    t -= fast_exp_nonpos(s[j] - m, s_exp, ea, eb);
+                    steps += t > 0.f ? 1 : 0;
+                }
+            }
+            if (!__any(live && t > 0.f)) break;
+        }
+        if (live) P.new_packed[out] = (uint32_t)(steps < K - 1 ? steps : K - 1);
     }
 }
 
@@ -989,10 +1159,14 @@ __global__ __launch_bounds__(kBlock) void k_rows_wave(SweepParams P) {
         size_t out = item;
         size_t row = P.row_begin + item;
         uint32_t global_id;
-        if (P.row_list) {
+        if (P.row_list && P.sorted_rows) {
             out = (size_t)P.row_list[item];
             row = P.row_begin + P.sorted_rows[out];
             global_id = P.assign_pos[out];
+        } else if (P.row_list) {   // a list of batch rows, in row order
+            out = (size_t)P.row_list[item];
+            row = P.row_begin + out;
+            global_id = P.assign[row];
         } else {
             global_id = P.assign[row];
         }
