@@ -946,18 +946,38 @@ __global__ void k_row_prepass(SweepParams P, ScoreProgram prog,
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P.row_end - P.row_begin) return;
     const size_t row = P.row_begin + i;
-    const RowScorer<-1, -1, 0> rs(P, row, P.assign[row]);
-    bool hand = rs.singleton != 0;
-    for (int j = 0; j < prog.n; ++j)
+    const int g = P.g2p[P.assign[row]];
+    const int n_g = P.counts[g];
+    bool hand = n_g == 1;   // the group would vanish: wave-per-row kernel
+#pragma unroll
+    for (int j = 0; j < kMaxOps; ++j) {
+        if (j >= prog.n) break;
         if (prog.op[j].type == OP_GATHER_ADD
             && P.values[prog.op[j].f][row] >= prog.op[j].nv)
             hand = true;
-    own[i] = rs.s_own;
+    }
+    // the own slot as remove_value + the cache refresh would leave it
+    // (RowScorer's own-slot score; feature loop unrolled so that the row's
+    // values and the feature views stay in registers)
+    float s_own = 0.f;
+    if (!hand) {
+        s_own = cluster_own_score(P, n_g - 1, P.scalars->shift);
+#pragma unroll
+        for (int f = 0; f < kMaxF; ++f) {
+            if (f >= P.F) break;
+            const SlaveView & v = P.feat[f];
+            const uint32_t x = P.values[f][row];
+            const float lf = v.kind == DIST_GP ? fast_log_factorial(x) : 0.f;
+            s_own = accumulate(v.kind, s_own, entry_after_remove(v, g, x), x,
+                               lf, v.p);
+        }
+    }
+    own[i] = s_own;
     if (hand) {
         handed[atomicAdd(handed_count, 1u)] = (uint32_t)i;
         P.old_packed[i] = 0xFFFFFFFFu;   // mark: not ours
     } else {
-        P.old_packed[i] = (uint32_t)rs.g;
+        P.old_packed[i] = (uint32_t)g;
     }
 }
 
