@@ -531,3 +531,19 @@ def test_low_entropy_sample_assignments_matches_score_counts():
         got = by_shape[shape] / n_samples
         assert abs(got - p) < 4 * np.sqrt(p * (1 - p) / n_samples) + 2e-3, (
             shape, got, p)
+
+
+def test_low_entropy_table_headers_are_what_the_generator_writes():
+    """le_table.h (product and oracle copies) == tools/gen_le_table.py's
+    output: the table in the build is the independently derived one"""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location(
+        "gen_le_table", os.path.join(root, "tools", "gen_le_table.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    text = gen.render()
+    for rel in ("distributions_amd/csrc/le_table.h", "oracle/le_table.h"):
+        with open(os.path.join(root, rel)) as f:
+            assert f.read() == text, rel
