@@ -170,9 +170,15 @@ class ShardedGibbs(object):
                 pack[i, :t.numel()] = t.view(torch.int32)
         if self.world == 1:
             return [pack[i] for i in range(len(arrays))]
-        out = torch.empty((self.world,) + tuple(pack.shape), dtype=torch.int32,
-                          device=self.device)
-        self.dist.all_gather(list(out.unbind(0)), pack, group=self.group)
+        if self._stage_through_host(pack):
+            host = pack.cpu()
+            parts = [torch.empty_like(host) for _ in range(self.world)]
+            self.dist.all_gather(parts, host, group=self.group)
+            out = torch.stack(parts).to(pack.device)
+        else:
+            out = torch.empty((self.world,) + tuple(pack.shape),
+                              dtype=torch.int32, device=self.device)
+            self.dist.all_gather(list(out.unbind(0)), pack, group=self.group)
         return [out[:, i, :].reshape(-1).contiguous()
                 for i in range(len(arrays))]
 
@@ -198,10 +204,21 @@ class ShardedGibbs(object):
     def _is_ordered(self, f):
         return self.backend.feature_is_ordered(f)
 
-    def _all_reduce(self, tensor):
-        if self.collective:
-            self.dist.all_reduce(tensor, op=self.dist.ReduceOp.SUM,
-                                 group=self.group)
+    def _stage_through_host(self, tensor):
+        """device tensors under a host-only backend (gloo): the multi-rank
+        tests on a single GPU run the real engine this way"""
+        return tensor.is_cuda and self.dist.get_backend(self.group) == "gloo"
+
+    def _all_reduce(self, tensor, op=None):
+        if not self.collective:
+            return
+        op = op if op is not None else self.dist.ReduceOp.SUM
+        if self._stage_through_host(tensor):
+            host = tensor.cpu()
+            self.dist.all_reduce(host, op=op, group=self.group)
+            tensor.copy_(host)
+        else:
+            self.dist.all_reduce(tensor, op=op, group=self.group)
 
     def sync_initial_stats(self):
         """After every rank loaded ITS rows: make the statistics global."""
@@ -220,8 +237,7 @@ class ShardedGibbs(object):
                 raise ValueError("sync_initial_stats needs assign_packed")
             nmax = torch.tensor([self.n_local], dtype=torch.int64,
                                 device=self.device)
-            self.dist.all_reduce(nmax, op=self.dist.ReduceOp.MAX,
-                                 group=self.group)
+            self._all_reduce(nmax, op=self.dist.ReduceOp.MAX)
             cols = [c if self._is_ordered(f) else None
                     for f, c in enumerate(self.columns)]
             self._replay(None, self.assign_packed, cols, int(nmax.item()),
@@ -235,8 +251,7 @@ class ShardedGibbs(object):
         if self.collective:
             nb = torch.tensor([n_batches], dtype=torch.int64,
                               device=self.device)
-            self.dist.all_reduce(nb, op=self.dist.ReduceOp.MAX,
-                                 group=self.group)
+            self._all_reduce(nb, op=self.dist.ReduceOp.MAX)
             n_batches = int(nb.item())
         for b in range(n_batches):
             r0 = min(self.n_local, b * batch_rows)
