@@ -173,3 +173,13 @@ def test_bad_arguments_are_reported():
         engine.Gibbs(-1.0, 0.2, gsh)                          # alpha <= 0
     with pytest.raises(RuntimeError):
         engine.Gibbs(1.0, 1.0, gsh)                           # d >= 1
+
+
+def test_no_features_clustering_prior_only():
+    """a mixture without component models: rows move under the clustering
+    prior alone (the driver's scores, clustering.hpp:195-208)"""
+    from distributions_amd import engine
+    n, k = 800, 10
+    assign = (np.arange(n) % k).astype(np.uint32)
+    for batches in ([200], [1]):
+        run([], [], [], assign, k, 1, batches, alpha=2.0, d=0.3, sweeps=2)
