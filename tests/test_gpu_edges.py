@@ -183,3 +183,31 @@ def test_no_features_clustering_prior_only():
     assign = (np.arange(n) % k).astype(np.uint32)
     for batches in ([200], [1]):
         run([], [], [], assign, k, 1, batches, alpha=2.0, d=0.3, sweeps=2)
+
+
+def test_the_widest_feature_list():
+    """DIST_MAX_FEATURES = 8 features: eight categoricals fill the score
+    program (two ops each); a ninth feature is refused"""
+    from distributions_amd import engine
+    rng = np.random.default_rng(11)
+    n, k = 1500, 9
+    osh = [ol.make_shared(ol.DD, alphas=[0.3, 0.6, 0.9]) for _ in range(8)]
+    gsh = [engine.dd_shared([0.3, 0.6, 0.9]) for _ in range(8)]
+    vals = [rng.integers(0, 3, n).astype(np.uint32) for _ in range(8)]
+    run(osh, gsh, vals, (np.arange(n) % k).astype(np.uint32), k, 1, [400, 1])
+    with pytest.raises(RuntimeError):
+        engine.Gibbs(1.0, 0.2, gsh + [engine.bb_shared(1.0, 1.0)])
+    # a list of mixed kinds at the limit
+    osh = osh[:4] + [ol.make_shared(ol.BB, alpha=0.5, beta=0.5),
+                     ol.make_shared(ol.GP, alpha=1.0, inv_beta=2.0),
+                     ol.make_shared(ol.NICH, mu=0.0, kappa=1.0, sigmasq=1.0,
+                                    nu=2.0),
+                     ol.make_shared(ol.BNB, alpha=1.0, beta=2.0, r=2)]
+    gsh = gsh[:4] + [engine.bb_shared(0.5, 0.5), engine.gp_shared(1.0, 2.0),
+                     engine.nich_shared(0.0, 1.0, 1.0, 2.0),
+                     engine.bnb_shared(1.0, 2.0, 2)]
+    vals = vals[:4] + [(rng.random(n) < 0.5).astype(np.uint32),
+                       rng.poisson(3.0, n).astype(np.uint32),
+                       rng.normal(size=n).astype(np.float32),
+                       rng.negative_binomial(2, 0.4, n).astype(np.uint32)]
+    run(osh, gsh, vals, (np.arange(n) % k).astype(np.uint32), k, 1, [500])
