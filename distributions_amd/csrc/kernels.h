@@ -1592,21 +1592,24 @@ __device__ __forceinline__ void vs_sum_and_scan(
             }
         }
     }
+    // t never increases, so the number of chunks that END with t > 0 is the
+    // chunk in which the lane crosses zero, and the last such end value is
+    // the value it enters that chunk with: three operations per chunk
     float t[kVsR], t_start[kVsR];
-    int cross[kVsR];
+    int npos[kVsR];
 #pragma unroll
     for (int r = 0; r < kVsR; ++r) {
         t[r] = total[r] * u[r];
-        t_start[r] = 0.f;
-        cross[r] = -1;
+        t_start[r] = t[r];
+        npos[r] = 0;
     }
+    const int nchunks = (K + kVsUnroll - 1) / kVsUnroll;
     for (int c = 0, k0 = 0; k0 < K; ++c, k0 += kVsUnroll) {
         float l[kVsUnroll];
         vs_fetch_chunk(lp, k0, l);
         bool more = false;
 #pragma unroll
         for (int r = 0; r < kVsR; ++r) {
-            const float t0 = t[r];
             if (__any(gchunk[r] == c)) {
 #pragma unroll
                 for (int j = 0; j < kVsUnroll; ++j)
@@ -1615,28 +1618,28 @@ __device__ __forceinline__ void vs_sum_and_scan(
 #pragma unroll
                 for (int j = 0; j < kVsUnroll; ++j) t[r] -= l[j];
             }
-            // the walk starts "above zero" by definition: a first t <= 0 at
-            // k = 0 is index 0 (random.hpp:326-329)
-            const bool crossed = (c == 0 || t0 > 0.f) && !(t[r] > 0.f);
-            cross[r] = crossed ? c : cross[r];
-            t_start[r] = crossed ? t0 : t_start[r];
-            more = more || (active[r] && t[r] > 0.f);
+            const bool pos = t[r] > 0.f;
+            t_start[r] = pos ? t[r] : t_start[r];
+            npos[r] += pos ? 1 : 0;
+            more = more || (active[r] && pos);
         }
         if (!__any(more)) break;
     }
 #pragma unroll
     for (int r = 0; r < kVsR; ++r) {
         int f = K - 1;
-        if (active[r] && cross[r] >= 0) {
+        if (active[r] && npos[r] < nchunks) {
+            // replay the crossing chunk: a first t <= 0 at its entry j is
+            // index k0 + j (random.hpp:326-329)
             float tt = t_start[r];
             int steps = 0;
 #pragma unroll
             for (int j = 0; j < kVsUnroll; ++j) {
-                const int k = cross[r] * kVsUnroll + j;
+                const int k = npos[r] * kVsUnroll + j;
                 tt -= (k == g[r]) ? l_own[r] : lp_vec[k];
                 steps += (tt > 0.f) ? 1 : 0;
             }
-            f = cross[r] * kVsUnroll + steps;
+            f = npos[r] * kVsUnroll + steps;
         }
         found[r] = f < K - 1 ? f : K - 1;
     }
