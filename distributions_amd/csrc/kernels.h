@@ -1631,13 +1631,24 @@ __device__ __forceinline__ void vs_sum_and_scan(
         if (active[r] && npos[r] < nchunks) {
             // replay the crossing chunk: a first t <= 0 at its entry j is
             // index k0 + j (random.hpp:326-329)
+            // (the chunk is 128 contiguous, aligned bytes of the padded
+            // vector: eight 16-byte loads, then selects -- no branches)
+            const float4 * chunk = reinterpret_cast<const float4 *>(
+                lp_vec + npos[r] * kVsUnroll);
+            float4 v[kVsUnroll / 4];
+#pragma unroll
+            for (int q = 0; q < kVsUnroll / 4; ++q) v[q] = chunk[q];
+            const int own = g[r] - npos[r] * kVsUnroll;   // in 0..31 or not
             float tt = t_start[r];
             int steps = 0;
 #pragma unroll
-            for (int j = 0; j < kVsUnroll; ++j) {
-                const int k = npos[r] * kVsUnroll + j;
-                tt -= (k == g[r]) ? l_own[r] : lp_vec[k];
-                steps += (tt > 0.f) ? 1 : 0;
+            for (int q = 0; q < kVsUnroll / 4; ++q) {
+                const float e[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    tt -= (own == 4 * q + i) ? l_own[r] : e[i];
+                    steps += (tt > 0.f) ? 1 : 0;
+                }
             }
             f = npos[r] * kVsUnroll + steps;
         }
