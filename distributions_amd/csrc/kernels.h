@@ -1570,11 +1570,12 @@ __device__ __forceinline__ void vs_sum_and_scan(
         uniform_fp lp, const float * lp_vec, int K, const int (&g)[kVsR],
         const float (&l_own)[kVsR], const float (&u)[kVsR],
         const bool (&active)[kVsR], int (&found)[kVsR]) {
-    int gchunk[kVsR];
+    int gchunk[kVsR], gpiece[kVsR];
     float total[kVsR];
 #pragma unroll
     for (int r = 0; r < kVsR; ++r) {
         gchunk[r] = active[r] ? (g[r] / kVsUnroll) : -1;
+        gpiece[r] = active[r] ? (g[r] >> 3) : -1;
         total[r] = 0.f;
     }
     for (int c = 0, k0 = 0; k0 < K; ++c, k0 += kVsUnroll) {
@@ -1583,9 +1584,20 @@ __device__ __forceinline__ void vs_sum_and_scan(
 #pragma unroll
         for (int r = 0; r < kVsR; ++r) {
             if (__any(gchunk[r] == c)) {
+                // own slots of a group-sorted tile are neighbours: only the
+                // eight-entry pieces that hold one take the per-lane select
 #pragma unroll
-                for (int j = 0; j < kVsUnroll; ++j)
-                    total[r] += (k0 + j == g[r]) ? l_own[r] : l[j];
+                for (int b = 0; b < kVsUnroll / 8; ++b) {
+                    if (__any(gpiece[r] == (k0 >> 3) + b)) {
+#pragma unroll
+                        for (int j = 8 * b; j < 8 * b + 8; ++j)
+                            total[r] += (k0 + j == g[r]) ? l_own[r] : l[j];
+                    } else {
+#pragma unroll
+                        for (int j = 8 * b; j < 8 * b + 8; ++j)
+                            total[r] += l[j];
+                    }
+                }
             } else {
 #pragma unroll
                 for (int j = 0; j < kVsUnroll; ++j) total[r] += l[j];
@@ -1612,8 +1624,17 @@ __device__ __forceinline__ void vs_sum_and_scan(
         for (int r = 0; r < kVsR; ++r) {
             if (__any(gchunk[r] == c)) {
 #pragma unroll
-                for (int j = 0; j < kVsUnroll; ++j)
-                    t[r] -= (k0 + j == g[r]) ? l_own[r] : l[j];
+                for (int b = 0; b < kVsUnroll / 8; ++b) {
+                    if (__any(gpiece[r] == (k0 >> 3) + b)) {
+#pragma unroll
+                        for (int j = 8 * b; j < 8 * b + 8; ++j)
+                            t[r] -= (k0 + j == g[r]) ? l_own[r] : l[j];
+                    } else {
+#pragma unroll
+                        for (int j = 8 * b; j < 8 * b + 8; ++j)
+                            t[r] -= l[j];
+                    }
+                }
             } else {
 #pragma unroll
                 for (int j = 0; j < kVsUnroll; ++j) t[r] -= l[j];
