@@ -57,6 +57,9 @@ def parse():
                          "DESIGN.md's table (not the bench line of record)")
     ap.add_argument("--value-sorted", type=int, default=1,
                     help="0 generic kernel only, 1 auto, 2 force")
+    ap.add_argument("--torch-collectives", action="store_true",
+                    help="keep the per-batch all-reduce on torch.distributed "
+                         "instead of the library's own RCCL communicator")
     ap.add_argument("--force-collective", action="store_true",
                     help="diagnostic: run the N>1 code path (statistic "
                          "deltas + RCCL all-reduce) with a single rank")
@@ -219,6 +222,7 @@ def main():
                                   force_collective=args.force_collective,
                                   columns=columns, assign_packed=initial)
     sharded.sync_initial_stats()
+    native_comm = (not args.torch_collectives) and sharded.use_native_comm()
     seed_state = _core.rng_seed(args.seed)
 
     def step(i):
@@ -283,6 +287,9 @@ def main():
                 "batch_rows": args.batch,
                 "parallelism": "rows sharded over %d GPU(s), all-reduce of "
                                "statistic deltas per sub-sweep" % world,
+                "collectives": ("none" if not sharded.collective else
+                                "library RCCL communicator" if native_comm
+                                else "torch.distributed (RCCL)"),
             },
             "roofline": {
                 "bound": "hbm",

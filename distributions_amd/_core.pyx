@@ -151,6 +151,14 @@ cdef extern from "distributions_hip.h" nogil:
     dist_gibbs_t * dist_gibbs_create(float, float, int, const dist_shared_t *)
     dist_gibbs_t * dist_gibbs_create_low_entropy(int, int,
                                                  const dist_shared_t *)
+    ctypedef struct dist_comm_t:
+        pass
+    int dist_comm_available()
+    int dist_comm_unique_id(uint8_t *)
+    dist_comm_t * dist_comm_create(const uint8_t *, int, int)
+    void dist_comm_destroy(dist_comm_t *)
+    int dist_gibbs_sweep_sharded(dist_gibbs_t *, dist_comm_t *, size_t, size_t,
+                                 uint32_t, uint64_t)
     void dist_gibbs_destroy(dist_gibbs_t *)
     int dist_gibbs_load_rows(dist_gibbs_t *, size_t, const uint32_t * const *,
                              const uint32_t *, int, int, uint64_t)
@@ -796,6 +804,38 @@ def value_words(int kind, values):
     return np.ascontiguousarray(values).astype(np.uint32)
 
 
+def comm_available():
+    """True if RCCL can be bound at run time"""
+    return bool(dist_comm_available())
+
+
+def comm_unique_id():
+    """128 bytes for rank 0 to hand to the other ranks"""
+    cdef cnp.ndarray[cnp.uint8_t, ndim=1] out = np.zeros(128, np.uint8)
+    check(dist_comm_unique_id(<uint8_t *> out.data))
+    return out
+
+
+cdef class Comm:
+    """the library's own RCCL communicator (collective constructor)"""
+    cdef dist_comm_t * ptr
+
+    def __cinit__(self, unique_id, int rank, int world):
+        cdef cnp.ndarray[cnp.uint8_t, ndim=1] uid = np.ascontiguousarray(
+            unique_id, dtype=np.uint8)
+        if uid.shape[0] != 128:
+            raise ValueError("the unique id is 128 bytes")
+        cdef const uint8_t * p = <const uint8_t *> uid.data
+        with nogil:
+            self.ptr = dist_comm_create(p, rank, world)
+        if self.ptr == NULL:
+            raise RuntimeError(dist_last_error().decode())
+
+    def __dealloc__(self):
+        if self.ptr != NULL:
+            dist_comm_destroy(self.ptr)
+
+
 cdef class GibbsEngine:
     cdef dist_gibbs_t * ptr
     cdef list shareds
@@ -899,6 +939,15 @@ cdef class GibbsEngine:
             rc = dist_gibbs_sweep_sequential(self.ptr, row_begin, row_end, &s)
         check(rc)
         return s
+
+    def sweep_sharded(self, Comm comm, size_t n_batches, size_t batch_rows,
+                      uint32_t seed_state, draw_base=0):
+        cdef uint64_t db = <uint64_t> draw_base
+        cdef int rc
+        with nogil:
+            rc = dist_gibbs_sweep_sharded(self.ptr, comm.ptr, n_batches,
+                                          batch_rows, seed_state, db)
+        check(rc)
 
     def batch_sample(self, size_t row_begin, size_t row_end,
                      uint32_t seed_state, draw_base=0):

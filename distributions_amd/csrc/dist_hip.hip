@@ -17,6 +17,9 @@
 #include <set>
 
 #include "common.h"
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // declarations only: RCCL is bound with dlopen
+
 #include "kernels.h"
 #include "le_table.h"
 
@@ -841,6 +844,7 @@ struct Gibbs {
     std::vector<std::unique_ptr<VsCache>> vs_cache;
     DeviceBuf<float> vsLA, vsLB, vsM, vsmB;
     DeviceBuf<ChainResult> chain_result;
+    DeviceBuf<int32_t> delta_image;         // dist_gibbs_sweep_sharded
     DeviceBuf<float> own_score;             // k_row_prepass
     int sequential_mode = 1;   // 0: every row as a batch of one (diagnostic)
     DeviceBuf<int> vsArg;
@@ -2625,6 +2629,119 @@ int dist_gibbs_sweep(dist_gibbs_t * g, size_t row_begin, size_t row_end,
         g->impl->sweep(row_begin, row_end, batch_rows, seed_state, draw_base);
     });
 }
+// ---- RCCL, bound at run time ----------------------------------------------
+namespace {
+struct Rccl {
+    void * handle = nullptr;
+    decltype(&ncclGetUniqueId) get_unique_id = nullptr;
+    decltype(&ncclCommInitRank) comm_init_rank = nullptr;
+    decltype(&ncclCommDestroy) comm_destroy = nullptr;
+    decltype(&ncclAllReduce) all_reduce = nullptr;
+    decltype(&ncclGetErrorString) error_string = nullptr;
+    bool ok = false;
+};
+Rccl & rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        // the copy that is already in the process wins (PyTorch ships its own)
+        const char * names[] = {"librccl.so.1", "librccl.so",
+                                "/opt/rocm/lib/librccl.so.1"};
+        for (const char * name : names) {
+            r.handle = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
+            if (r.handle) break;
+        }
+        for (const char * name : names) {
+            if (r.handle) break;
+            r.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        }
+        if (!r.handle) return;
+#define DIST_SYM(field, symbol)                                              \
+        r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.handle, symbol))
+        DIST_SYM(get_unique_id, "ncclGetUniqueId");
+        DIST_SYM(comm_init_rank, "ncclCommInitRank");
+        DIST_SYM(comm_destroy, "ncclCommDestroy");
+        DIST_SYM(all_reduce, "ncclAllReduce");
+        DIST_SYM(error_string, "ncclGetErrorString");
+#undef DIST_SYM
+        r.ok = r.get_unique_id && r.comm_init_rank && r.comm_destroy
+            && r.all_reduce && r.error_string;
+    });
+    return r;
+}
+#define RCCL_CHECK(expr)                                                     \
+    do {                                                                     \
+        ncclResult_t rc_ = (expr);                                           \
+        if (rc_ != ncclSuccess)                                              \
+            throw Error(std::string("RCCL error: ")                          \
+                        + rccl().error_string(rc_) + " at " #expr);          \
+    } while (0)
+}  // namespace
+
+struct dist_comm {
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 1;
+};
+
+int dist_comm_available(void) { return rccl().ok ? 1 : 0; }
+int dist_comm_unique_id(uint8_t id_out[128]) {
+    return guarded([&] {
+        DIST_REQUIRE(rccl().ok, "RCCL could not be bound");
+        static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+        ncclUniqueId id;
+        RCCL_CHECK(rccl().get_unique_id(&id));
+        memcpy(id_out, &id, 128);
+    });
+}
+dist_comm_t * dist_comm_create(const uint8_t id[128], int rank, int world) {
+    dist_comm_t * c = nullptr;
+    guarded([&] {
+        DIST_REQUIRE(rccl().ok, "RCCL could not be bound");
+        DIST_REQUIRE(world >= 1 && rank >= 0 && rank < world, "bad rank/world");
+        ensure_device_ready();
+        std::unique_ptr<dist_comm> p(new dist_comm());
+        ncclUniqueId uid;
+        memcpy(&uid, id, 128);
+        RCCL_CHECK(rccl().comm_init_rank(&p->comm, world, uid, rank));
+        p->rank = rank;
+        p->world = world;
+        c = p.release();
+    });
+    return c;
+}
+void dist_comm_destroy(dist_comm_t * c) {
+    if (!c) return;
+    if (c->comm && rccl().ok) (void)rccl().comm_destroy(c->comm);
+    delete c;
+}
+int dist_gibbs_sweep_sharded(dist_gibbs_t * g, dist_comm_t * c,
+                             size_t n_batches, size_t batch_rows,
+                             uint32_t seed_state, uint64_t draw_base) {
+    return guarded([&] {
+        Gibbs & e = *g->impl;
+        DIST_REQUIRE(c && c->comm, "no communicator");
+        DIST_REQUIRE(batch_rows > 0, "batch_rows must be positive");
+        DIST_REQUIRE(!e.any_float_stats(),
+                     "order-dependent statistics are exchanged as rows "
+                     "(dist_gibbs_batch_moves_dev / replay_ordered_dev)");
+        for (size_t b = 0; b < n_batches; ++b) {
+            const size_t r0 = std::min(e.n_rows, b * batch_rows);
+            const size_t r1 = std::min(e.n_rows, r0 + batch_rows);
+            e.batch_sample(r0, r1, seed_state, draw_base);
+            const size_t words = e.stat_words();
+            e.delta_image.reserve(grow_capacity(words), 0);
+            e.batch_delta(e.delta_image.p);
+            // in place, on the engine's stream: no hop to another stream
+            RCCL_CHECK(rccl().all_reduce(e.delta_image.p, e.delta_image.p,
+                                         words, ncclInt32, ncclSum, c->comm,
+                                         stream()));
+            e.batch_apply_delta(e.delta_image.p);
+            e.batch_finish();
+        }
+        sync();
+    });
+}
+
 int dist_gibbs_sweep_sequential(dist_gibbs_t * g, size_t row_begin,
                                 size_t row_end, uint32_t * rng_state) {
     return guarded(

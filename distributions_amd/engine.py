@@ -151,6 +151,8 @@ class ShardedGibbs(object):
         self.collective = self.world > 1 or (force_collective
                                              and dist.is_initialized())
         self._delta = None
+        self._comm = None
+        self._n_batches = {}    # batch_rows -> sub-sweeps per pass (all ranks)
         self.ordered = self.collective and backend.ordered_features() > 0
         self.columns = columns
         self.assign_packed = assign_packed
@@ -243,16 +245,58 @@ class ShardedGibbs(object):
             self._replay(None, self.assign_packed, cols, int(nmax.item()),
                          reset=True)
 
+    def use_native_comm(self):
+        """Give the library its own RCCL communicator: the sub-sweep loop then
+        runs inside it, the all-reduce on the engine's stream (no Python and
+        no stream hop per sub-sweep).  Collective.  Returns False -- and the
+        torch.distributed path stays in use -- when the backend is not RCCL,
+        the engine has order-dependent statistics, or RCCL cannot be bound."""
+        import numpy as np
+        import torch
+        core = self.backend
+        if not (self.collective and not self.ordered
+                and hasattr(core, "sweep_sharded")
+                and self.dist.get_backend(self.group) == "nccl"):
+            return False
+        from . import _core
+        ok = torch.tensor([1 if _core.comm_available() else 0],
+                          dtype=torch.int32, device=self.device)
+        self._all_reduce(ok, op=self.dist.ReduceOp.MIN)
+        if not int(ok.item()):
+            return False
+        rank = self.dist.get_rank(self.group)
+        uid = torch.zeros(128, dtype=torch.uint8, device=self.device)
+        if rank == 0:
+            uid.copy_(torch.from_numpy(_core.comm_unique_id()))
+        self.dist.broadcast(uid, src=self.dist.get_global_rank(
+            self.group, 0) if self.group is not None else 0, group=self.group)
+        try:
+            comm = _core.Comm(uid.cpu().numpy(), rank, self.world)
+        except RuntimeError:
+            comm = None
+        ok.fill_(0 if comm is None else 1)   # all ranks or none
+        self._all_reduce(ok, op=self.dist.ReduceOp.MIN)
+        if not int(ok.item()):
+            return False
+        self._comm = comm
+        return True
+
     def sweep(self, batch_rows, seed_state, draw_base=0):
         """One pass over the local shard; all ranks take the same number of
         sub-sweeps (shards are equal up to one batch of padding)."""
         import torch
         n_batches = (self.n_local + batch_rows - 1) // batch_rows
         if self.collective:
-            nb = torch.tensor([n_batches], dtype=torch.int64,
-                              device=self.device)
-            self._all_reduce(nb, op=self.dist.ReduceOp.MAX)
-            n_batches = int(nb.item())
+            if self._n_batches.get(batch_rows) is None:
+                nb = torch.tensor([n_batches], dtype=torch.int64,
+                                  device=self.device)
+                self._all_reduce(nb, op=self.dist.ReduceOp.MAX)
+                self._n_batches[batch_rows] = int(nb.item())
+            n_batches = self._n_batches[batch_rows]
+        if self._comm is not None:
+            self.backend.sweep_sharded(self._comm, n_batches, batch_rows,
+                                       seed_state, draw_base)
+            return
         for b in range(n_batches):
             r0 = min(self.n_local, b * batch_rows)
             r1 = min(self.n_local, r0 + batch_rows)

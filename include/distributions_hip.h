@@ -345,6 +345,28 @@ int dist_gibbs_replay_ordered_dev(dist_gibbs_t * g,
                                   const uint32_t * const * values_dev,
                                   size_t n_rows, int reset);
 
+/* ---- the library's own RCCL communicator ----------------------------------
+ * Optional: with it the whole multi-GPU sweep (sample -> delta -> all-reduce
+ * -> apply -> finish, per sub-sweep) runs inside the library, the all-reduce
+ * on the engine's own stream.  RCCL is bound at run time (the librccl.so.1
+ * already in the process, e.g. PyTorch's, else ROCm's).  One process per GPU:
+ * rank 0 calls dist_comm_unique_id and hands the 128 bytes to the other ranks
+ * by whatever channel the application has (torch.distributed broadcast, MPI,
+ * a file); every rank then calls dist_comm_create (collective).  Engines with
+ * order-dependent statistics (NormalInverseChiSq, GammaPoisson's log_prod) are
+ * refused by dist_gibbs_sweep_sharded: they exchange rows (see above). */
+typedef struct dist_comm dist_comm_t;
+int dist_comm_available(void);                       /* 1 if RCCL can be bound */
+int dist_comm_unique_id(uint8_t id_out[128]);
+dist_comm_t * dist_comm_create(const uint8_t id[128], int rank, int world);
+void dist_comm_destroy(dist_comm_t * c);
+/* n_batches sub-sweeps over the local rows in batches of batch_rows (ranks
+ * whose shard is exhausted take part with empty batches: pass the same
+ * n_batches on every rank) */
+int dist_gibbs_sweep_sharded(dist_gibbs_t * g, dist_comm_t * c,
+                             size_t n_batches, size_t batch_rows,
+                             uint32_t seed_state, uint64_t draw_base);
+
 /* batch-semantics scores of one resident row (length written to *size_out;
  * scores_out needs dist_gibbs_group_count() floats) */
 int dist_gibbs_row_scores(dist_gibbs_t * g, size_t row, float * scores_out,

@@ -1,0 +1,95 @@
+"""The library's own RCCL communicator (dist_comm_*, dist_gibbs_sweep_sharded):
+the sub-sweep loop runs inside the library with the all-reduce of the integer
+delta image on the engine's stream.  One GPU on the test box, so the
+communicator has one rank; what is checked is that the native loop is the same
+function of the data as the host-driven loop: bit-identical assignments, group
+sizes and statistics to the CPU oracle's batched sweep."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+pytestmark = pytest.mark.gpu
+
+K, BATCH, SWEEPS, SEED = 24, 1500, 2, 4242
+
+
+def worker(rank, port, out, config, mode, N):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    import oracle_lib as ol
+    import workloads
+    from distributions_amd import _core, engine
+    dev = torch.device("cuda", 0)
+    osh, gsh, vals, assign = workloads.make(config, N, K)
+    cols = [torch.from_numpy(ol.value_words(s.kind, v).view(np.int32)
+                             .copy()).to(dev) for s, v in zip(osh, vals)]
+    packed = torch.from_numpy(assign.view(np.int32).copy()).to(dev)
+    gpu = engine.Gibbs(1.0, 0.2, gsh)
+    gpu.set_option("value_sorted", mode)
+    gpu.load_rows_torch(cols, packed.clone(), K, 2)
+    sharded = engine.ShardedGibbs(gpu.core, N, 0, device=dev,
+                                  force_collective=True,
+                                  columns=cols, assign_packed=packed)
+    sharded.sync_initial_stats()
+    native = sharded.use_native_comm()
+    for s in range(SWEEPS):
+        sharded.sweep(BATCH, _core.rng_seed(SEED), draw_base=s * N)
+    torch.cuda.synchronize()
+    np.save(os.path.join(out, "native.npy"), np.array([int(native)]))
+    np.save(os.path.join(out, "assign.npy"), gpu.assignments())
+    np.save(os.path.join(out, "counts.npy"), gpu.counts())
+    np.save(os.path.join(out, "groups.npy"), np.stack([
+        np.concatenate([gpu.get_group(f, g) for f in range(len(gsh))])
+        for g in range(len(gpu))]))
+    dist.destroy_process_group()
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+@pytest.mark.parametrize("config,mode,N", [
+    ("dd", 2, 9001), ("dd", 0, 9001), ("bb", 1, 9001),
+    ("dd_bb_gp", 1, 6000)])
+def test_native_loop_equals_oracle(tmp_path, config, mode, N):
+    import oracle_lib as ol
+    import workloads
+    mp.spawn(worker, args=(free_port(), str(tmp_path), config, mode, N),
+             nprocs=1, join=True)
+    osh, gsh, vals, assign = workloads.make(config, N, K)
+    native = bool(np.load(tmp_path / "native.npy")[0])
+    # NormalInverseChiSq statistics and GammaPoisson's log-product depend on
+    # the order of the adds: such engines exchange rows, not an integer image,
+    # and the native loop must decline them (torch.distributed path is used)
+    ordered = any(s.kind in (ol.NICH, ol.GP) for s in osh)
+    assert native == (not ordered)
+    m = ol.OracleMixture(1.0, 0.2, osh)
+    m.init_from_assignments(vals, assign, K, 2)
+    for s in range(SWEEPS):
+        for b in range(0, N, BATCH):
+            m.gibbs_batch(b, min(N, b + BATCH), ol.oracle().orc_rng_seed(SEED),
+                          s * N)
+    assert np.array_equal(np.load(tmp_path / "assign.npy"), m.assign)
+    assert np.array_equal(np.load(tmp_path / "counts.npy"), m.counts())
+    want = np.stack([np.concatenate([m.get_group(f, g)
+                                     for f in range(len(osh))])
+                     for g in range(len(m))])
+    assert np.array_equal(np.load(tmp_path / "groups.npy"), want)
