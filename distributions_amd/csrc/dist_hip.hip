@@ -842,7 +842,7 @@ struct Gibbs {
         }
     }
     std::vector<std::unique_ptr<VsCache>> vs_cache;
-    DeviceBuf<float> vsLA, vsLB, vsM, vsmB;
+    DeviceBuf<float> vsLA, vsLB, vsM, vsmB, vsPA, vsPB;
     DeviceBuf<ChainResult> chain_result;
     DeviceBuf<int32_t> delta_image;         // dist_gibbs_sweep_sharded
     DeviceBuf<float> own_score;             // k_row_prepass
@@ -1357,12 +1357,15 @@ struct Gibbs {
         template <int KIND>
         void go() {
             const uint32_t nv = (uint32_t)self->vs_nvals();
-            hipLaunchKernelGGL((k_vs_prepare<KIND>), dim3(nv), dim3(kBlock), 0,
+            hipLaunchKernelGGL((k_vs_prepare<KIND>), dim3(nv), dim3(kBlock),
+                               T.PA ? (size_t)T.Kpad * 8 : 0,
                                stream(), *P, T, self->deferred_count.p,
                                c->n_other);
             HIP_CHECK(hipGetLastError());
             HIP_CHECK(hipEventRecord(self->ev0, stream()));
-            const dim3 grid((c->n_tiles + 3) / 4), block(kBlock);
+            const int per = kVsSampleBlock / 64;   // tiles per workgroup
+            const dim3 grid((c->n_tiles + per - 1) / per),
+                block(kVsSampleBlock);
             if (c->n_tiles)   // else every row's value lies beyond the table
                 hipLaunchKernelGGL((k_vs_sample<KIND>), grid, block, 0,
                                    stream(), *P, T, c->tiles.p, c->n_tiles,
@@ -1384,6 +1387,13 @@ struct Gibbs {
         vsM.reserve(nv, 0);
         vsmB.reserve(nv, 0);
         vsArg.reserve(nv, 0);
+        // chunk-boundary running sums: worth their serial pass in
+        // k_vs_prepare once the sampling kernel is throughput-bound
+        const bool prefix = c.n_tiles >= 2048 && Kpad <= 8192;
+        if (prefix) {
+            vsPA.reserve(grow_capacity((size_t)nv * (Kpad / kVsUnroll)), 0);
+            vsPB.reserve(grow_capacity((size_t)nv * (Kpad / kVsUnroll)), 0);
+        }
         deferred.reserve(std::max<size_t>(n, 1), 0);
         deferred_count.reserve(1, 0);
         // base[], base_single[] and the scalars; the few handed-over rows
@@ -1396,7 +1406,9 @@ struct Gibbs {
         P.sorted_rows = c.sorted_rows.p;
         P.assign_pos = c.assign_pos.p;
         VsLaunch L{this, &P, &c,
-                   VsTables{vsLA.p, vsLB.p, vsM.p, vsmB.p, vsArg.p, Kpad}};
+                   VsTables{vsLA.p, vsLB.p, vsM.p, vsmB.p, vsArg.p, Kpad,
+                            prefix ? vsPA.p : nullptr,
+                            prefix ? vsPB.p : nullptr}};
         switch (feats[0]->sh.kind) {
         case DIST_DD: L.go<DIST_DD>(); break;
         case DIST_DPD: L.go<DIST_DPD>(); break;

@@ -1436,6 +1436,7 @@ __global__ void k_score_rows(SweepParams P, float * __restrict__ out,
 // shortcut does not cover exactly (group of one member; own-slot score above
 // M[x] through table rounding; DPD OTHER) are handed to the generic kernel.
 
+constexpr int kVsUnroll = 32;   // entries per scalar-loaded chunk
 struct VsTables {
     float * LA;      // [nvals][Kpad]
     float * LB;
@@ -1443,6 +1444,10 @@ struct VsTables {
     float * mB;
     int * argmax;    // [nvals], first index attaining the maximum
     int Kpad;
+    // running sums of LA / LB at the chunk boundaries, in index order:
+    // P[x][c] = ((l_0 + l_1) + ...) + l_{32c-1}; null = not built
+    float * PA;      // [nvals][Kpad / kVsUnroll]
+    float * PB;
 };
 struct VsTile {
     uint32_t x;      // the tile's value
@@ -1477,6 +1482,7 @@ __global__ __launch_bounds__(kBlock) void k_vs_prepare(
     __shared__ float r_m1[kBlock], r_m2[kBlock];
     __shared__ int r_i1[kBlock];
     __shared__ float sh_M, sh_mB;
+    extern __shared__ float s_l[];   // [2][Kpad] when the running sums are built
     const uint32_t x = blockIdx.x;
     SlaveView v = P.feat[0];
     v.kind = KIND;
@@ -1537,15 +1543,61 @@ __global__ __launch_bounds__(kBlock) void k_vs_prepare(
         }
         la[k] = a;
         lb[k] = b;
+        if (T.PA) {
+            s_l[k] = a;
+            s_l[T.Kpad + k] = b;
+        }
+    }
+    if (T.PA == nullptr) return;
+    // The likelihood total of a row is the index-order sum with the row's own
+    // slot replaced (random.cc:100-103), so up to the first own slot of a
+    // tile it is the same number for every row of the value: one lane per
+    // table walks the vector once (a dependent chain of Kpad adds, ~7 cycles
+    // each, fed from the copy in LDS one chunk ahead) and leaves the running
+    // sum at each chunk boundary; k_vs_sample starts there.
+    __syncthreads();
+    if ((threadIdx.x & 63) != 0 || threadIdx.x >= 128) return;
+    const int w = threadIdx.x >> 6;
+    const float4 * src = reinterpret_cast<const float4 *>(s_l + w * T.Kpad);
+    const int nchunks = T.Kpad / kVsUnroll;
+    float * dst = (w ? T.PB : T.PA) + (size_t)x * nchunks;
+    constexpr int Q = kVsUnroll / 4;
+    float4 even[Q], odd[Q];   // ping-pong: no register copies in the chain
+#pragma unroll
+    for (int q = 0; q < Q; ++q) even[q] = src[q];
+    float run = 0.f;
+    auto add_chunk = [&run](const float4 (&v)[Q]) {
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            run += v[q].x;
+            run += v[q].y;
+            run += v[q].z;
+            run += v[q].w;
+        }
+    };
+    for (int c = 0; c < nchunks; c += 2) {
+        const int c1 = c + 1 < nchunks ? c + 1 : c;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) odd[q] = src[c1 * Q + q];
+        __builtin_amdgcn_sched_barrier(0);   // loads first: a chunk ahead
+        dst[c] = run;
+        add_chunk(even);
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 1 >= nchunks) break;
+        const int c2 = c + 2 < nchunks ? c + 2 : c;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) even[q] = src[c2 * Q + q];
+        __builtin_amdgcn_sched_barrier(0);
+        dst[c + 1] = run;
+        add_chunk(odd);
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
-
-constexpr int kVsUnroll = 32;
 
 // rows per wave = 64 * kVsR: R consecutive tiles of one value share every
 // scalar load of the likelihood vector, so a 16-entry chunk feeds 16*R vector
 // ops and the scalar-load latency hides behind them
-constexpr int kVsR = 1;
+constexpr int kVsR = 2;
 
 // The two order-sensitive recurrences for the lanes whose likelihood vector
 // is `lp` (wave-uniform), own slot replaced by the lane's l_own:
@@ -1566,81 +1618,99 @@ __device__ __forceinline__ void vs_fetch_chunk(uniform_fp lp, int k0,
 #pragma unroll
     for (int j = 0; j < kVsUnroll; ++j) l[j] = lp[k0 + j];
 }
+typedef float v2f __attribute__((ext_vector_type(2)));
+static_assert(kVsR == 2, "the recurrences below are written for two rows per "
+                         "lane (one v_pk_add_f32 per entry)");
+__device__ __forceinline__ v2f vs_splat(float x) { return (v2f){x, x}; }
 __device__ __forceinline__ void vs_sum_and_scan(
-        uniform_fp lp, const float * lp_vec, int K, const int (&g)[kVsR],
+        uniform_fp lp, const float * lp_vec, uniform_fp prefix, int K,
+        const int (&g)[kVsR],
         const float (&l_own)[kVsR], const float (&u)[kVsR],
         const bool (&active)[kVsR], int (&found)[kVsR]) {
     int gchunk[kVsR], gpiece[kVsR];
-    float total[kVsR];
 #pragma unroll
     for (int r = 0; r < kVsR; ++r) {
         gchunk[r] = active[r] ? (g[r] / kVsUnroll) : -1;
         gpiece[r] = active[r] ? (g[r] >> 3) : -1;
-        total[r] = 0.f;
     }
-    for (int c = 0, k0 = 0; k0 < K; ++c, k0 += kVsUnroll) {
+    // a lane's two rows advance together: .x is tile row 2*lane, .y the next
+    // one (neighbours in the group-sorted tile, so they share own-slot pieces)
+    // no own slot before the tile's first own chunk: start from the value's
+    // running sum at that boundary (k_vs_prepare)
+    int c_first = 0;
+    float start = 0.f;
+    if (prefix) {
+        const int nchunks = (K + kVsUnroll - 1) / kVsUnroll;
+        int m = min(active[0] ? gchunk[0] : nchunks,
+                    active[1] ? gchunk[1] : nchunks);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = min(m, __shfl_xor(m, off));
+        c_first = __builtin_amdgcn_readfirstlane(m);
+        if (c_first >= nchunks) c_first = 0;   // (no active lane)
+        start = prefix[c_first];
+    }
+    v2f total = {start, start};
+    for (int c = c_first, k0 = c_first * kVsUnroll; k0 < K;
+         ++c, k0 += kVsUnroll) {
         float l[kVsUnroll];
         vs_fetch_chunk(lp, k0, l);
+        if (__any(gchunk[0] == c || gchunk[1] == c)) {
+            // own slots of a group-sorted tile are neighbours: only the
+            // eight-entry pieces that hold one take the per-lane select
 #pragma unroll
-        for (int r = 0; r < kVsR; ++r) {
-            if (__any(gchunk[r] == c)) {
-                // own slots of a group-sorted tile are neighbours: only the
-                // eight-entry pieces that hold one take the per-lane select
+            for (int b = 0; b < kVsUnroll / 8; ++b) {
+                const int piece = (k0 >> 3) + b;
+                if (__any(gpiece[0] == piece || gpiece[1] == piece)) {
 #pragma unroll
-                for (int b = 0; b < kVsUnroll / 8; ++b) {
-                    if (__any(gpiece[r] == (k0 >> 3) + b)) {
+                    for (int j = 8 * b; j < 8 * b + 8; ++j)
+                        total += (v2f){(k0 + j == g[0]) ? l_own[0] : l[j],
+                                       (k0 + j == g[1]) ? l_own[1] : l[j]};
+                } else {
 #pragma unroll
-                        for (int j = 8 * b; j < 8 * b + 8; ++j)
-                            total[r] += (k0 + j == g[r]) ? l_own[r] : l[j];
-                    } else {
-#pragma unroll
-                        for (int j = 8 * b; j < 8 * b + 8; ++j)
-                            total[r] += l[j];
-                    }
+                    for (int j = 8 * b; j < 8 * b + 8; ++j)
+                        total += vs_splat(l[j]);
                 }
-            } else {
-#pragma unroll
-                for (int j = 0; j < kVsUnroll; ++j) total[r] += l[j];
             }
+        } else {
+#pragma unroll
+            for (int j = 0; j < kVsUnroll; ++j) total += vs_splat(l[j]);
         }
     }
     // t never increases, so the number of chunks that END with t > 0 is the
     // chunk in which the lane crosses zero, and the last such end value is
     // the value it enters that chunk with: three operations per chunk
-    float t[kVsR], t_start[kVsR];
-    int npos[kVsR];
-#pragma unroll
-    for (int r = 0; r < kVsR; ++r) {
-        t[r] = total[r] * u[r];
-        t_start[r] = t[r];
-        npos[r] = 0;
-    }
+    v2f t = total * (v2f){u[0], u[1]};
+    float t_start[kVsR] = {t.x, t.y};
+    int npos[kVsR] = {0, 0};
     const int nchunks = (K + kVsUnroll - 1) / kVsUnroll;
     for (int c = 0, k0 = 0; k0 < K; ++c, k0 += kVsUnroll) {
         float l[kVsUnroll];
         vs_fetch_chunk(lp, k0, l);
+        if (__any(gchunk[0] == c || gchunk[1] == c)) {
+#pragma unroll
+            for (int b = 0; b < kVsUnroll / 8; ++b) {
+                const int piece = (k0 >> 3) + b;
+                if (__any(gpiece[0] == piece || gpiece[1] == piece)) {
+#pragma unroll
+                    for (int j = 8 * b; j < 8 * b + 8; ++j)
+                        t -= (v2f){(k0 + j == g[0]) ? l_own[0] : l[j],
+                                   (k0 + j == g[1]) ? l_own[1] : l[j]};
+                } else {
+#pragma unroll
+                    for (int j = 8 * b; j < 8 * b + 8; ++j)
+                        t -= vs_splat(l[j]);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < kVsUnroll; ++j) t -= vs_splat(l[j]);
+        }
+        const float tr[kVsR] = {t.x, t.y};
         bool more = false;
 #pragma unroll
         for (int r = 0; r < kVsR; ++r) {
-            if (__any(gchunk[r] == c)) {
-#pragma unroll
-                for (int b = 0; b < kVsUnroll / 8; ++b) {
-                    if (__any(gpiece[r] == (k0 >> 3) + b)) {
-#pragma unroll
-                        for (int j = 8 * b; j < 8 * b + 8; ++j)
-                            t[r] -= (k0 + j == g[r]) ? l_own[r] : l[j];
-                    } else {
-#pragma unroll
-                        for (int j = 8 * b; j < 8 * b + 8; ++j)
-                            t[r] -= l[j];
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < kVsUnroll; ++j) t[r] -= l[j];
-            }
-            const bool pos = t[r] > 0.f;
-            t_start[r] = pos ? t[r] : t_start[r];
+            const bool pos = tr[r] > 0.f;
+            t_start[r] = pos ? tr[r] : t_start[r];
             npos[r] += pos ? 1 : 0;
             more = more || (active[r] && pos);
         }
@@ -1677,14 +1747,17 @@ __device__ __forceinline__ void vs_sum_and_scan(
     }
 }
 
+constexpr int kVsSampleBlock = 1024;
 template <int KIND>
-__global__ __launch_bounds__(kBlock) void k_vs_sample(
+__global__ __launch_bounds__(kVsSampleBlock)
+__attribute__((amdgpu_waves_per_eu(8, 8)))
+void k_vs_sample(
         SweepParams P, VsTables T, const VsTile * __restrict__ tiles,
         uint32_t n_tiles, const uint32_t * __restrict__ sorted_rows,
         uint32_t * __restrict__ deferred, uint32_t * deferred_count) {
     const int lane = threadIdx.x & 63;
     const uint32_t tile_id = __builtin_amdgcn_readfirstlane(
-        blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6));
+        blockIdx.x * (kVsSampleBlock / 64) + (threadIdx.x >> 6));
     if (tile_id >= n_tiles) return;
     const uint32_t x = __builtin_amdgcn_readfirstlane(tiles[tile_id].x);
     const uint32_t pos = __builtin_amdgcn_readfirstlane(tiles[tile_id].pos);
@@ -1706,7 +1779,7 @@ __global__ __launch_bounds__(kBlock) void k_vs_sample(
     bool anyA = false, anyB = false;
 #pragma unroll
     for (int r = 0; r < kVsR; ++r) {
-        valid[r] = (uint32_t)(lane + 64 * r) < n;
+        valid[r] = (uint32_t)(kVsR * lane + r) < n;
         row[r] = 0;
         g[r] = -1;
         g2[r] = 0;
@@ -1714,7 +1787,7 @@ __global__ __launch_bounds__(kBlock) void k_vs_sample(
         u[r] = 0.f;
         bool classB = false;
         if (valid[r]) {
-            const uint32_t at = pos + lane + 64 * r;
+            const uint32_t at = pos + kVsR * lane + r;
             row[r] = P.row_begin + sorted_rows[at];
             g[r] = P.g2p[P.assign_pos[at]];
             const int n_g = P.counts[g[r]];
@@ -1727,7 +1800,7 @@ __global__ __launch_bounds__(kBlock) void k_vs_sample(
                 defer = !classB && s_own > M;   // table rounding lifted it
             }
             if (defer) {
-                deferred[atomicAdd(deferred_count, 1u)] = pos + lane + 64 * r;
+                deferred[atomicAdd(deferred_count, 1u)] = pos + kVsR * lane + r;
                 valid[r] = false;
             } else {
                 l_own[r] = fast_exp_nonpos(s_own - m, g_tables_dev.exp_table,
@@ -1743,21 +1816,27 @@ __global__ __launch_bounds__(kBlock) void k_vs_sample(
     if (__any(anyA)) {
         const float * vec = T.LA + (size_t)x * T.Kpad;
         int f[kVsR];
-        vs_sum_and_scan(as_uniform(vec), vec, K, g, l_own, u, inA, f);
+        vs_sum_and_scan(as_uniform(vec), vec,
+                        T.PA ? as_uniform(T.PA + (size_t)x
+                                          * (T.Kpad / kVsUnroll)) : nullptr,
+                        K, g, l_own, u, inA, f);
 #pragma unroll
         for (int r = 0; r < kVsR; ++r) g2[r] = inA[r] ? f[r] : g2[r];
     }
     if (__any(anyB)) {
         const float * vec = T.LB + (size_t)x * T.Kpad;
         int f[kVsR];
-        vs_sum_and_scan(as_uniform(vec), vec, K, g, l_own, u, inB, f);
+        vs_sum_and_scan(as_uniform(vec), vec,
+                        T.PB ? as_uniform(T.PB + (size_t)x
+                                          * (T.Kpad / kVsUnroll)) : nullptr,
+                        K, g, l_own, u, inB, f);
 #pragma unroll
         for (int r = 0; r < kVsR; ++r) g2[r] = inB[r] ? f[r] : g2[r];
     }
 #pragma unroll
     for (int r = 0; r < kVsR; ++r) {
         if (valid[r]) {
-            const uint32_t at = pos + lane + 64 * r;
+            const uint32_t at = pos + kVsR * lane + r;
             P.old_packed[at] = (uint32_t)g[r];
             P.new_packed[at] = (uint32_t)g2[r];
         }
