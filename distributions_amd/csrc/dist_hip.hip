@@ -843,6 +843,7 @@ struct Gibbs {
     }
     std::vector<std::unique_ptr<VsCache>> vs_cache;
     DeviceBuf<float> vsLA, vsLB, vsM, vsmB, vsPA, vsPB;
+    DeviceBuf<int32_t> vs_stage;   // [chunks][K] deltas of the open batch
     DeviceBuf<ChainResult> chain_result;
     DeviceBuf<int32_t> delta_image;         // dist_gibbs_sweep_sharded
     DeviceBuf<float> own_score;             // k_row_prepass
@@ -1604,7 +1605,7 @@ struct Gibbs {
         const size_t n = batch_end - batch_begin;
         SweepParams P = params(batch_begin, batch_end, 0, 0);
         const size_t lds_sort =
-            ((size_t)K() * 2 + kVsApplyBlock + 2 * kVsApplyRows) * 4;
+            ((size_t)K() * 2 + kVsApplyBlock / 64 + 4 * kVsApplyRows) * 4;
         const size_t lds_plain = (size_t)K() * 4;
         // a 1024-thread workgroup may take most of the CU's 160 KiB of LDS
         const size_t lds_limit = 144 * 1024;
@@ -1634,6 +1635,17 @@ struct Gibbs {
                 moves_in_row_order = true;
             }
             c.dirty = true;
+            // the chunks' per-group deltas meet in a staging matrix instead
+            // of in contended atomics (unless that matrix would be huge)
+            const size_t stage_words = (size_t)c.n_chunks * K();
+            int32_t * stage = nullptr;
+            if (stage_words <= ((size_t)1 << 22)) {
+                vs_stage.reserve(grow_capacity(stage_words), 0);
+                stage = vs_stage.p;
+            }
+            const int sole = c.one_chunk_per_value ? 1 : 0;
+            const dim3 rgrid((K() + kVsReduceGroups - 1) / kVsReduceGroups),
+                rblock(kVsReduceGroups * kVsReduceSlices);
 #define VS_APPLY(KIND, SORT, LDS)                                            \
             do {                                                             \
                 if ((LDS) > 64 * 1024)   /* beyond the default opt-in */     \
@@ -1646,7 +1658,12 @@ struct Gibbs {
                                    LDS, stream(), P, img, c.chunks.p,        \
                                    c.sorted_rows.p, d_p2g_ptr,               \
                                    c.assign_pos.p, (uint32_t)vs_nvals(),     \
-                                   refresh);                                 \
+                                   refresh, sole, stage);                    \
+                if (stage)                                                   \
+                    hipLaunchKernelGGL((k_vs_reduce<KIND>), rgrid, rblock,   \
+                                       0, stream(), img, stage, c.chunks.p,  \
+                                       c.n_chunks, K(),                      \
+                                       (uint32_t)vs_nvals());                \
             } while (0)
             if (bb && sort) VS_APPLY(DIST_BB, true, lds_sort);
             else if (bb) VS_APPLY(DIST_BB, false, lds_plain);

@@ -1844,18 +1844,24 @@ void k_vs_sample(
 }
 
 // Applying a batch's moves in value-sorted order: one workgroup takes up to
-// kVsApplyRows rows of ONE value x, accumulates the per-group change in LDS
-// and flushes each non-zero entry with one global atomic per statistic:
-//   counts[k] += d[k];  DD/DPD: count_sum[k] += d[k], cnt[k][x] += d[k];
-//   BB: (x ? heads : tails)[k] += d[k]
-// (6 global atomics per moved row become <= 3 per touched group and chunk).
+// kVsApplyRows rows of ONE value x and accumulates the per-group change d[k]
+// in LDS.  What every chunk changes alike -- counts[k], and the per-group
+// totals of the feature -- is NOT added with atomics (every workgroup on every
+// XCD would hit the same K addresses; such device-scope atomics serialise at
+// the memory side): the chunk leaves its d[] as one row of a staging matrix
+// and k_vs_reduce sums the rows per group.  What only this chunk touches --
+// the categorical cell (k, x) -- is updated in place:
+//   DD/DPD: cnt[k][x] += d[k]            (reduce: counts, count_sum += sum_c d)
+//   BB:     reduce: counts += sum_c d, (x ? heads : tails) += sum_{c: x} d
+//   GP/BNB: reduce: counts, count += sum_c d, sum += sum_c x_c d
+// `stage` null (matrix too large: wide value tables): the atomics as before.
 constexpr int kVsApplyRows = 4096;
 constexpr int kVsApplyBlock = 1024;   // one workgroup per chunk: keep the CU busy
 
-// SORT: also reorder the chunk's rows by their NEW group (LDS counting sort),
-// in place in sorted_rows.  Next time this batch range is sampled, the 64
-// rows of a tile then sit in a narrow band of groups, so almost every
-// 16-entry chunk of the likelihood vector is free of own slots (see
+// SORT: also reorder the chunk's rows by their NEW group (counting sort in
+// LDS, written out coalesced), in place in sorted_rows.  Next time this batch
+// range is sampled, the rows of a tile then sit in a narrow band of groups,
+// so almost every chunk of the likelihood vector is free of own slots (see
 // vs_sum_and_scan).  The order is a performance hint only: results do not
 // depend on it.
 template <int KIND, bool SORT>
@@ -1863,14 +1869,17 @@ __global__ __launch_bounds__(kVsApplyBlock) void k_vs_apply(
         SweepParams P, StatImage img, const VsTile * __restrict__ chunks,
         uint32_t * __restrict__ sorted_rows,
         const uint32_t * __restrict__ p2g, uint32_t * __restrict__ assign_pos,
-        uint32_t nvals, int refresh_cells) {
+        uint32_t nvals, int refresh_cells, int sole_owner,
+        int32_t * __restrict__ stage) {
     extern __shared__ int vs_lds[];
     const int K = P.K;
     int * delta = vs_lds;                 // [K]
     int * hist = vs_lds + K;              // [K]           (SORT)
-    int * part = hist + K;                // [kVsApplyBlock]      (SORT)
-    uint32_t * rows_l = (uint32_t *)(part + kVsApplyBlock);       // [kVsApplyRows]
+    int * part = hist + K;                // [kVsApplyBlock / 64]  (SORT)
+    uint32_t * rows_l = (uint32_t *)(part + kVsApplyBlock / 64);  // [kVsApplyRows]
     uint32_t * gn_l = rows_l + kVsApplyRows;               // [kVsApplyRows]
+    uint32_t * rows_s = gn_l + kVsApplyRows;               // sorted copies
+    uint32_t * gid_s = rows_s + kVsApplyRows;
     const uint32_t x = chunks[blockIdx.x].x;
     const uint32_t pos = chunks[blockIdx.x].pos;
     const uint32_t n = chunks[blockIdx.x].n;
@@ -1905,17 +1914,27 @@ __global__ __launch_bounds__(kVsApplyBlock) void k_vs_apply(
     const int dim = P.feat[0].dim;
     for (int k = threadIdx.x; k < K; k += kVsApplyBlock) {
         const int dlt = delta[k];
+        if (stage) stage[(size_t)blockIdx.x * K + k] = dlt;
         if (dlt == 0) continue;
-        atomicAdd(&img.counts[k], dlt);
-        if (KIND == DIST_BB) {
-            atomicAdd(x ? &img.i0[0][k] : &img.i1[0][k], dlt);
-        } else if (KIND == DIST_GP || KIND == DIST_BNB) {
-            atomicAdd(&img.i0[0][k], dlt);                    // count
-            if (x < nvals)
-                atomicAdd(&img.i1[0][k], dlt * (int32_t)x);   // sum
-        } else {
-            atomicAdd(&img.i0[0][k], dlt);
-            const int before = atomicAdd(&img.cnt[0][(size_t)k * dim + x], dlt);
+        if (!stage) {
+            atomicAdd(&img.counts[k], dlt);
+            if (KIND == DIST_BB) {
+                atomicAdd(x ? &img.i0[0][k] : &img.i1[0][k], dlt);
+            } else {
+                atomicAdd(&img.i0[0][k], dlt);     // count_sum / count
+                if ((KIND == DIST_GP || KIND == DIST_BNB) && x < nvals)
+                    atomicAdd(&img.i1[0][k], dlt * (int32_t)x);   // sum
+            }
+        }
+        if (KIND == DIST_DD || KIND == DIST_DPD) {
+            int32_t * cell = &img.cnt[0][(size_t)k * dim + x];
+            int before;
+            if (sole_owner) {   // one chunk per value: nobody else is here
+                before = *cell;
+                *cell = before + dlt;
+            } else {
+                before = atomicAdd(cell, dlt);
+            }
             if (refresh_cells) {
                 // this workgroup is the only one that touches cell (k, x)
                 // (one chunk per value, live statistics): leave its cache
@@ -1928,21 +1947,25 @@ __global__ __launch_bounds__(kVsApplyBlock) void k_vs_apply(
         }
     }
     if (!SORT) return;
-    // exclusive scan of hist over k (each thread owns a contiguous slice)
+    // exclusive scan of hist over k: each thread owns a contiguous slice,
+    // the slices are scanned within the wave by shuffles and the 16 wave
+    // totals by every thread for itself (two barriers in all)
     const int per = (K + kVsApplyBlock - 1) / kVsApplyBlock;
     const int lo = threadIdx.x * per;
     const int hi = lo + per < K ? lo + per : K;
     int sum = 0;
     for (int k = lo; k < hi; ++k) sum += hist[k];
-    part[threadIdx.x] = sum;
-    __syncthreads();
-    for (int off = 1; off < kVsApplyBlock; off <<= 1) {
-        const int add = (int)threadIdx.x >= off ? part[threadIdx.x - off] : 0;
-        __syncthreads();
-        part[threadIdx.x] += add;
-        __syncthreads();
+    int incl = sum;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int up = __shfl_up(incl, off);
+        if (lane >= off) incl += up;
     }
-    int run = part[threadIdx.x] - sum;
+    if (lane == 63) part[wave] = incl;
+    __syncthreads();
+    int run = incl - sum;
+    for (int w = 0; w < wave; ++w) run += part[w];
     for (int k = lo; k < hi; ++k) {
         const int c = hist[k];
         hist[k] = run;
@@ -1950,9 +1973,60 @@ __global__ __launch_bounds__(kVsApplyBlock) void k_vs_apply(
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < n; i += kVsApplyBlock) {
-        const int p = atomicAdd(&hist[gn_l[i]], 1);
-        sorted_rows[pos + p] = rows_l[i];
-        assign_pos[pos + p] = p2g[gn_l[i]];
+        const uint32_t gn = gn_l[i];
+        const int p = atomicAdd(&hist[gn], 1);
+        rows_s[p] = rows_l[i];
+        gid_s[p] = p2g[gn];
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += kVsApplyBlock) {
+        sorted_rows[pos + i] = rows_s[i];
+        assign_pos[pos + i] = gid_s[i];
+    }
+}
+
+// The per-group sums of the staged chunk deltas (see k_vs_apply): thread
+// (k, slice) adds up a slice of the chunks, the slices meet in LDS, and the
+// owner of k updates the statistics without atomics.
+constexpr int kVsReduceGroups = 16;    // groups per workgroup
+constexpr int kVsReduceSlices = 32;
+template <int KIND>
+__global__ __launch_bounds__(kVsReduceGroups * kVsReduceSlices)
+void k_vs_reduce(StatImage img, const int32_t * __restrict__ stage,
+                 const VsTile * __restrict__ chunks, uint32_t n_chunks, int K,
+                 uint32_t nvals) {
+    __shared__ int s_a[kVsReduceSlices][kVsReduceGroups];
+    __shared__ int s_b[kVsReduceSlices][kVsReduceGroups];
+    const int kk = threadIdx.x % kVsReduceGroups;
+    const int slice = threadIdx.x / kVsReduceGroups;
+    const int k = blockIdx.x * kVsReduceGroups + kk;
+    int a = 0, b = 0;   // a: plain sum; b: BB heads part / GP value-weighted
+    if (k < K) {
+        for (uint32_t c = slice; c < n_chunks; c += kVsReduceSlices) {
+            const int d = stage[(size_t)c * K + k];
+            const uint32_t x = chunks[c].x;
+            a += d;
+            if (KIND == DIST_BB) b += x ? d : 0;
+            if (KIND == DIST_GP || KIND == DIST_BNB)
+                b += x < nvals ? d * (int32_t)x : 0;
+        }
+    }
+    s_a[slice][kk] = a;
+    s_b[slice][kk] = b;
+    __syncthreads();
+    if (slice != 0 || k >= K) return;
+    for (int q = 1; q < kVsReduceSlices; ++q) {
+        a += s_a[q][kk];
+        b += s_b[q][kk];
+    }
+    if (a == 0 && b == 0) return;
+    img.counts[k] += a;
+    if (KIND == DIST_BB) {
+        img.i0[0][k] += b;        // heads
+        img.i1[0][k] += a - b;    // tails
+    } else {
+        img.i0[0][k] += a;        // count_sum / count
+        if (KIND == DIST_GP || KIND == DIST_BNB) img.i1[0][k] += b;   // sum
     }
 }
 
