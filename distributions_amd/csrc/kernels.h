@@ -1479,8 +1479,8 @@ __global__ __launch_bounds__(kBlock) void k_vs_prepare(
         SweepParams P, VsTables T, uint32_t * deferred_count,
         uint32_t deferred_initial) {
     if (blockIdx.x == 0 && threadIdx.x == 0) *deferred_count = deferred_initial;
-    __shared__ float r_m1[kBlock], r_m2[kBlock];
-    __shared__ int r_i1[kBlock];
+    __shared__ float r_m1[kBlock / 64], r_m2[kBlock / 64];
+    __shared__ int r_i1[kBlock / 64];
     __shared__ float sh_M, sh_mB;
     extern __shared__ float s_l[];   // [2][Kpad] when the running sums are built
     const uint32_t x = blockIdx.x;
@@ -1500,22 +1500,34 @@ __global__ __launch_bounds__(kBlock) void k_vs_prepare(
         if (s > m1) { m2 = m1; m1 = s; i1 = k; }
         else if (s > m2) m2 = s;
     }
-    r_m1[threadIdx.x] = m1; r_m2[threadIdx.x] = m2; r_i1[threadIdx.x] = i1;
-    __syncthreads();
-    for (int off = kBlock / 2; off > 0; off >>= 1) {
-        if ((int)threadIdx.x < off) {
-            const float a1 = r_m1[threadIdx.x], a2 = r_m2[threadIdx.x];
-            const float b1 = r_m1[threadIdx.x + off], b2 = r_m2[threadIdx.x + off];
-            const int ai = r_i1[threadIdx.x], bi = r_i1[threadIdx.x + off];
-            float c1, c2; int ci;
-            if (a1 > b1 || (a1 == b1 && ai < bi)) {
-                c1 = a1; ci = ai; c2 = fmaxf(a2, b1);
-            } else {
-                c1 = b1; ci = bi; c2 = fmaxf(b2, a1);
-            }
-            r_m1[threadIdx.x] = c1; r_m2[threadIdx.x] = c2; r_i1[threadIdx.x] = ci;
+    // (max, first arg-max, max of the rest): shuffles within the wave, then
+    // the first lane folds the waves' results
+    auto fold = [](float & a1, float & a2, int & ai, float b1, float b2,
+                   int bi) {
+        if (a1 > b1 || (a1 == b1 && ai < bi)) {
+            a2 = fmaxf(a2, b1);
+        } else {
+            a2 = fmaxf(b2, a1);
+            a1 = b1;
+            ai = bi;
         }
-        __syncthreads();
+    };
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float b1 = __shfl_xor(m1, off), b2 = __shfl_xor(m2, off);
+        const int bi = __shfl_xor(i1, off);
+        fold(m1, m2, i1, b1, b2, bi);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        r_m1[threadIdx.x >> 6] = m1;
+        r_m2[threadIdx.x >> 6] = m2;
+        r_i1[threadIdx.x >> 6] = i1;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kBlock / 64; ++w)
+            fold(m1, m2, i1, r_m1[w], r_m2[w], r_i1[w]);
+        r_m1[0] = m1; r_m2[0] = m2; r_i1[0] = i1;
     }
     if (threadIdx.x == 0) {
         const float M = r_m1[0];
