@@ -245,8 +245,9 @@ class ShardedGibbs(object):
             self._replay(None, self.assign_packed, cols, int(nmax.item()),
                          reset=True)
 
-    def use_native_comm(self):
-        """Give the library its own RCCL communicator: the sub-sweep loop then
+    def use_native_comm(self, comm=None):
+        """Give the library its own RCCL communicator (or share `comm`, the
+        `native_comm` of another engine of this process group): the sub-sweep loop then
         runs inside it, the all-reduce on the engine's stream (no Python and
         no stream hop per sub-sweep).  Collective.  Returns False -- and the
         torch.distributed path stays in use -- when the backend is not RCCL,
@@ -259,6 +260,9 @@ class ShardedGibbs(object):
                 and self.dist.get_backend(self.group) == "nccl"):
             return False
         from . import _core
+        if comm is not None:
+            self._comm = comm
+            return True
         ok = torch.tensor([1 if _core.comm_available() else 0],
                           dtype=torch.int32, device=self.device)
         self._all_reduce(ok, op=self.dist.ReduceOp.MIN)
@@ -280,6 +284,10 @@ class ShardedGibbs(object):
             return False
         self._comm = comm
         return True
+
+    @property
+    def native_comm(self):
+        return self._comm
 
     def sweep(self, batch_rows, seed_state, draw_base=0):
         """One pass over the local shard; all ranks take the same number of

@@ -160,7 +160,16 @@ def trial_collective(seed):
                                   force_collective=True, columns=cols,
                                   assign_packed=a)
     sharded.sync_initial_stats()
-    what = "collective seed %d: %s n=%d k=%d" % (seed, config, n, k)
+    # half of the trials run the sub-sweep loop inside the library, on its
+    # own RCCL communicator (one per process, shared by the engines)
+    global _NATIVE_COMM
+    native = False
+    if rng.integers(0, 2):
+        native = sharded.use_native_comm(_NATIVE_COMM)
+        if native:
+            _NATIVE_COMM = sharded.native_comm
+    what = "collective seed %d: %s n=%d k=%d native=%d" % (seed, config, n, k,
+                                                          native)
     err = same_state(orc, gpu)
     if err:
         return what + " after the initial exchange: " + err
@@ -176,6 +185,9 @@ def trial_collective(seed):
         if err:
             return what + " sweep %d batch %d: %s" % (sweep, batch, err)
     return None
+
+
+_NATIVE_COMM = None
 
 
 def main():
