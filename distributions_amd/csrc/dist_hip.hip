@@ -794,6 +794,11 @@ struct Gibbs {
     size_t pinned_cap = 0;
     unsigned * pinned_seq = nullptr;   // see k_publish_counts
     unsigned publish_ticket = 0;
+    // (size, ticket) pairs written by k_vs_reduce; pairs_ticket != 0: the
+    // sizes of the open batch are on their way there
+    unsigned long long * pinned_pairs = nullptr;
+    size_t pinned_pairs_cap = 0;
+    unsigned pairs_ticket = 0;
 
     // value-sorted path (single small-domain feature): rows of a batch range
     // sorted by value once, tiles of <= 64 equal-valued rows
@@ -873,6 +878,7 @@ struct Gibbs {
         if (ev1) (void)hipEventDestroy(ev1);
         if (pinned_counts) (void)hipHostFree(pinned_counts);
         if (pinned_seq) (void)hipHostFree(pinned_seq);
+        if (pinned_pairs) (void)hipHostFree(pinned_pairs);
     }
 
     int F() const { return (int)feats.size(); }
@@ -1006,6 +1012,27 @@ struct Gibbs {
                                     hipHostMallocCoherent));
         }
         py.counts.resize(n);
+        if (pairs_ticket != 0 && pairs_ticket == publish_ticket) {
+            // k_vs_reduce is publishing them: wait for the ticket in every slot
+            const unsigned long long want = pairs_ticket;
+            pairs_ticket = 0;
+            const volatile unsigned long long * pairs = pinned_pairs;
+            bool seen = false;
+            size_t k = 0;
+            for (long spin = 0; spin < 200000000L && !seen; ++spin) {
+                while (k < n && (pairs[k] >> 32) == want) ++k;
+                seen = k == n;
+            }
+            if (!seen) {   // (a failed kernel never writes: surface its error)
+                HIP_CHECK(hipStreamSynchronize(stream()));
+                DIST_REQUIRE(false, "group sizes were not published");
+            }
+            std::atomic_thread_fence(std::memory_order_acquire);
+            for (size_t i = 0; i < n; ++i)
+                py.counts[i] = (int32_t)(uint32_t)pairs[i];
+            return;
+        }
+        pairs_ticket = 0;
         if (!pinned_seq) {
             HIP_CHECK(hipHostMalloc((void **)&pinned_seq, sizeof(unsigned),
                                     hipHostMallocCoherent));
@@ -1644,6 +1671,20 @@ struct Gibbs {
                 stage = vs_stage.p;
             }
             const int sole = c.one_chunk_per_value ? 1 : 0;
+            unsigned long long * pairs = nullptr;
+            unsigned pairs_seq = 0;
+            if (stage && img.counts == py.d_counts.p) {   // live statistics
+                if ((size_t)K() > pinned_pairs_cap) {
+                    if (pinned_pairs) (void)hipHostFree(pinned_pairs);
+                    pinned_pairs_cap = grow_capacity((size_t)K());
+                    HIP_CHECK(hipHostMalloc((void **)&pinned_pairs,
+                                            pinned_pairs_cap * 8,
+                                            hipHostMallocCoherent));
+                    memset(pinned_pairs, 0, pinned_pairs_cap * 8);
+                }
+                pairs = pinned_pairs;
+                pairs_seq = pairs_ticket = ++publish_ticket;
+            }
             const dim3 rgrid((K() + kVsReduceGroups - 1) / kVsReduceGroups),
                 rblock(kVsReduceGroups * kVsReduceSlices);
 #define VS_APPLY(KIND, SORT, LDS)                                            \
@@ -1663,7 +1704,8 @@ struct Gibbs {
                     hipLaunchKernelGGL((k_vs_reduce<KIND>), rgrid, rblock,   \
                                        0, stream(), img, stage, c.chunks.p,  \
                                        c.n_chunks, K(),                      \
-                                       (uint32_t)vs_nvals());                \
+                                       (uint32_t)vs_nvals(), pairs,          \
+                                       pairs_seq);                           \
             } while (0)
             if (bb && sort) VS_APPLY(DIST_BB, true, lds_sort);
             else if (bb) VS_APPLY(DIST_BB, false, lds_plain);
@@ -2646,6 +2688,7 @@ int dist_gibbs_export_stats_dev(const dist_gibbs_t * g, int32_t * stats_dev) {
 int dist_gibbs_import_stats_dev(dist_gibbs_t * g, const int32_t * stats_dev) {
     return guarded([&] {
         g->impl->copy_stats(const_cast<int32_t *>(stats_dev), false);
+        g->impl->pairs_ticket = 0;   // whatever a batch published is stale now
         g->impl->refresh_host_counts();
         g->impl->rebuild_caches();
         sync();

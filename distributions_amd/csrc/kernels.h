@@ -2006,7 +2006,8 @@ template <int KIND>
 __global__ __launch_bounds__(kVsReduceGroups * kVsReduceSlices)
 void k_vs_reduce(StatImage img, const int32_t * __restrict__ stage,
                  const VsTile * __restrict__ chunks, uint32_t n_chunks, int K,
-                 uint32_t nvals) {
+                 uint32_t nvals, unsigned long long * host_pairs,
+                 unsigned int seq) {
     __shared__ int s_a[kVsReduceSlices][kVsReduceGroups];
     __shared__ int s_b[kVsReduceSlices][kVsReduceGroups];
     const int kk = threadIdx.x % kVsReduceGroups;
@@ -2031,8 +2032,15 @@ void k_vs_reduce(StatImage img, const int32_t * __restrict__ stage,
         a += s_a[q][kk];
         b += s_b[q][kk];
     }
+    // host_pairs: the new group sizes go straight into pinned host memory,
+    // each with the batch's ticket in the upper half of ONE 8-byte store; the
+    // host polls until every slot carries the ticket (k_publish_counts and
+    // its launch are not needed on this path)
+    const int32_t size_now = img.counts[k] + a;
+    if (host_pairs)
+        host_pairs[k] = ((unsigned long long)seq << 32) | (uint32_t)size_now;
     if (a == 0 && b == 0) return;
-    img.counts[k] += a;
+    img.counts[k] = size_now;
     if (KIND == DIST_BB) {
         img.i0[0][k] += b;        // heads
         img.i1[0][k] += a - b;    // tails
