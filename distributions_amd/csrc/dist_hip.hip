@@ -1674,15 +1674,7 @@ struct Gibbs {
             unsigned long long * pairs = nullptr;
             unsigned pairs_seq = 0;
             if (stage && img.counts == py.d_counts.p) {   // live statistics
-                if ((size_t)K() > pinned_pairs_cap) {
-                    if (pinned_pairs) (void)hipHostFree(pinned_pairs);
-                    pinned_pairs_cap = grow_capacity((size_t)K());
-                    HIP_CHECK(hipHostMalloc((void **)&pinned_pairs,
-                                            pinned_pairs_cap * 8,
-                                            hipHostMallocCoherent));
-                    memset(pinned_pairs, 0, pinned_pairs_cap * 8);
-                }
-                pairs = pinned_pairs;
+                pairs = pairs_buffer();
                 pairs_seq = pairs_ticket = ++publish_ticket;
             }
             const dim3 rgrid((K() + kVsReduceGroups - 1) / kVsReduceGroups),
@@ -1743,13 +1735,27 @@ struct Gibbs {
         apply_ints(live_image());
         replay_floats();
     }
-    void batch_delta(int32_t * delta_dev) {
+    // zeroed = the caller's image is all zero already (see clear below)
+    void batch_delta(int32_t * delta_dev, bool zeroed = false) {
         DIST_REQUIRE(batch_open, "no open batch");
-        HIP_CHECK(hipMemsetAsync(delta_dev, 0, stat_words() * 4, stream()));
+        if (!zeroed)
+            HIP_CHECK(hipMemsetAsync(delta_dev, 0, stat_words() * 4, stream()));
         if (batch_end == batch_begin) return;
         apply_ints(word_image(delta_dev));
     }
-    void batch_apply_delta(const int32_t * delta_dev) {
+    unsigned long long * pairs_buffer() {
+        if ((size_t)K() > pinned_pairs_cap) {
+            if (pinned_pairs) (void)hipHostFree(pinned_pairs);
+            pinned_pairs_cap = grow_capacity((size_t)K());
+            HIP_CHECK(hipHostMalloc((void **)&pinned_pairs,
+                                    pinned_pairs_cap * 8,
+                                    hipHostMallocCoherent));
+            memset(pinned_pairs, 0, pinned_pairs_cap * 8);
+        }
+        return pinned_pairs;
+    }
+    // clear = leave the image zeroed behind (it is not const then)
+    void batch_apply_delta(int32_t * delta_dev, bool clear = false) {
         DIST_REQUIRE(batch_open, "no open batch");
         StatImage a = live_image();
         const size_t k = (size_t)K();
@@ -1769,7 +1775,10 @@ struct Gibbs {
             push(a.i1[f], k);
             push(a.cnt[f], k * feats[f]->dim());
         }
-        LAUNCH(k_add_words, off, seg, delta_dev, off);
+        unsigned long long * pairs = pairs_buffer();
+        pairs_ticket = ++publish_ticket;
+        LAUNCH(k_add_words, off, seg, delta_dev, off, clear ? 1 : 0, pairs,
+               pairs_ticket);
         // the order-dependent statistics (NICH, GP log_prod) are not in the
         // image: the caller gathers the moves and calls replay_ordered
     }
@@ -2801,13 +2810,19 @@ int dist_gibbs_sweep_sharded(dist_gibbs_t * g, dist_comm_t * c,
             const size_t r1 = std::min(e.n_rows, r0 + batch_rows);
             e.batch_sample(r0, r1, seed_state, draw_base);
             const size_t words = e.stat_words();
-            e.delta_image.reserve(grow_capacity(words), 0);
-            e.batch_delta(e.delta_image.p);
+            // the exchange buffer is zeroed once; k_add_words clears what it
+            // consumes, so it is all zero again before every batch
+            if (words > e.delta_image.cap || !e.delta_image.p) {
+                e.delta_image.reserve(grow_capacity(words), 0);
+                HIP_CHECK(hipMemsetAsync(e.delta_image.p, 0,
+                                         e.delta_image.cap * 4, stream()));
+            }
+            e.batch_delta(e.delta_image.p, true);
             // in place, on the engine's stream: no hop to another stream
             RCCL_CHECK(rccl().all_reduce(e.delta_image.p, e.delta_image.p,
                                          words, ncclInt32, ncclSum, c->comm,
                                          stream()));
-            e.batch_apply_delta(e.delta_image.p);
+            e.batch_apply_delta(e.delta_image.p, true);
             e.batch_finish();
         }
         sync();
@@ -2832,7 +2847,10 @@ int dist_gibbs_batch_delta_dev(dist_gibbs_t * g, int32_t * delta_dev) {
 }
 int dist_gibbs_batch_apply_delta_dev(dist_gibbs_t * g,
                                      const int32_t * delta_dev) {
-    return guarded([&] { g->impl->batch_apply_delta(delta_dev); });
+    // (clear = false: the caller's image is only read)
+    return guarded([&] {
+        g->impl->batch_apply_delta(const_cast<int32_t *>(delta_dev), false);
+    });
 }
 int dist_gibbs_batch_apply_local(dist_gibbs_t * g) {
     return guarded([&] { g->impl->batch_apply_local(); });

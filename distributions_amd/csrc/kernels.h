@@ -2188,14 +2188,28 @@ struct WordSegments {
     int32_t * dst[1 + 3 * kMaxF];
     unsigned long long end[1 + 3 * kMaxF];   // running end offset in the image
 };
-__global__ void k_add_words(WordSegments seg,
-                            const int32_t * __restrict__ src, size_t total) {
+// clear: leave the image zeroed for the next batch (the library's own
+// exchange buffer is never memset again).  host_pairs: segment 0 is the group
+// sizes; their new values go to pinned host memory with the batch's ticket
+// (see k_vs_reduce).
+__global__ void k_add_words(WordSegments seg, int32_t * __restrict__ src,
+                            size_t total, int clear,
+                            unsigned long long * host_pairs,
+                            unsigned int seq) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     int j = 0;
     while (i >= seg.end[j]) ++j;
     const size_t begin = j ? seg.end[j - 1] : 0;
-    seg.dst[j][i - begin] += src[i];
+    const int32_t d = src[i];
+    if (j == 0 && host_pairs) {
+        const int32_t now = seg.dst[0][i] + d;
+        if (d) seg.dst[0][i] = now;
+        host_pairs[i] = ((unsigned long long)seq << 32) | (uint32_t)now;
+    } else if (d) {
+        seg.dst[j][i - begin] += d;
+    }
+    if (clear && d) src[i] = 0;
 }
 
 // Float statistics (NICH count/mean/ctv, GP log_prod) depend on update order
