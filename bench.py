@@ -305,6 +305,10 @@ def main():
                 "rows_per_launch": rows / max(launches, 1),
                 "avg_launch_ms": ms / max(launches, 1),
                 "launches": launches,
+                "note": "achieved = SURVEY 8d algorithmic bytes / kernel time; "
+                        "the value-sorted kernels serve those bytes from "
+                        "scalar-loaded per-value tables (HBM carries `traffic`) "
+                        "and are VALU-issue-bound: see DESIGN.md section 4",
             },
         }
         if world == 1 and args.cpu_rows > 0 and args.config == "dd":
