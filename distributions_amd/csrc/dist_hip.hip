@@ -856,6 +856,7 @@ struct Gibbs {
     DeviceBuf<int> vsArg;
     DeviceBuf<uint32_t> deferred, deferred_count;
     int value_sorted_mode = 1;   // 0 off, 1 auto, 2 always (when eligible)
+    int running_sums_min_tiles = 2048;   // see sample_value_sorted
     uint64_t vs_batches = 0, generic_batches = 0;
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -1417,7 +1418,8 @@ struct Gibbs {
         vsArg.reserve(nv, 0);
         // chunk-boundary running sums: worth their serial pass in
         // k_vs_prepare once the sampling kernel is throughput-bound
-        const bool prefix = c.n_tiles >= 2048 && Kpad <= 8192;
+        const bool prefix = c.n_tiles >= (uint32_t)running_sums_min_tiles
+                            && Kpad <= 8192;
         if (prefix) {
             vsPA.reserve(grow_capacity((size_t)nv * (Kpad / kVsUnroll)), 0);
             vsPB.reserve(grow_capacity((size_t)nv * (Kpad / kVsUnroll)), 0);
@@ -2936,6 +2938,12 @@ int dist_gibbs_set_option(dist_gibbs_t * g, const char * name, int value) {
         if (key == "value_sorted") {
             DIST_REQUIRE(value >= 0 && value <= 2, "value_sorted: 0, 1 or 2");
             g->impl->value_sorted_mode = value;
+        } else if (key == "running_sums_min_tiles") {
+            // launches of at least this many value tiles start each tile's
+            // total from the per-value running sums (a tuning knob: results
+            // do not depend on it)
+            DIST_REQUIRE(value >= 0, "running_sums_min_tiles: >= 0");
+            g->impl->running_sums_min_tiles = value;
         } else if (key == "sequential_chain") {
             // 1 (default): the device-resident chain kernel; 0: every row
             // as a batch of one

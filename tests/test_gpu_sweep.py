@@ -108,6 +108,26 @@ def test_value_sorted_larger_batches(config, dim, k):
     assert gpu.path_counts()[0] == 9
 
 
+@pytest.mark.parametrize("config,dim,k", [("dd", 256, 64), ("dd_skew", 64, 16),
+                                          ("dpd_other", 300, 24), ("bb", None, 8),
+                                          ("gp", None, 12), ("dd", 16, 700)])
+def test_value_sorted_running_sums(config, dim, k):
+    """the per-value running sums (a tile's total starts at its first own
+    chunk) are a tuning choice of large launches: forced on here, same bits"""
+    n = 60000
+    orc, gpu = both(config, n, k, 1.0, 0.1, dim=dim)
+    gpu.set_option("value_sorted", 2)
+    gpu.set_option("running_sums_min_tiles", 0)
+    seed = 77
+    st = ol.oracle().orc_rng_seed(seed)
+    for sweep in range(3):
+        for b in range(0, n, 30000):
+            orc.gibbs_batch(b, b + 30000, st, sweep * n)
+        gpu.sweep(0, n, 30000, seed, draw_base=sweep * n)
+        assert_same_state(orc, gpu, "%s sweep %d" % (config, sweep))
+    assert gpu.path_counts() == (6, 0)
+
+
 @pytest.mark.parametrize("config", ["dd", "gp_nich", "bb"])
 def test_sequential_chain_bit_exact(config):
     """batch of one row == the reference's sequential update."""

@@ -100,6 +100,8 @@ def trial(seed, large=False):
     orc.init_from_assignments(vals, assign, k, empty)
     mode = int(rng.choice([0, 1, 2]))
     gpu.set_option("value_sorted", mode)
+    if rng.integers(0, 2):   # the per-value running sums, also on small launches
+        gpu.set_option("running_sums_min_tiles", 0)
     gpu.load_rows(vals, assign, k, empty)
     what = "seed %d: n=%d k=%d empty=%d feats=%s mode=%d %s" % (
         seed, n, k, empty, "+".join(desc), mode,
@@ -155,6 +157,8 @@ def trial_collective(seed):
     a = torch.from_numpy(assign.view(np.int32)).to(dev)
     gpu = engine.Gibbs(alpha, d, gsh)
     gpu.set_option("value_sorted", int(rng.choice([0, 1, 2])))
+    if rng.integers(0, 2):
+        gpu.set_option("running_sums_min_tiles", 0)
     gpu.load_rows_torch(cols, a.clone(), k, 2)
     sharded = engine.ShardedGibbs(gpu.core, n, 0, device=dev,
                                   force_collective=True, columns=cols,
