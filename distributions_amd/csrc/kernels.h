@@ -1726,7 +1726,8 @@ __device__ __forceinline__ void vs_sum_and_scan(
             npos[r] += pos ? 1 : 0;
             more = more || (active[r] && pos);
         }
-        if (!__any(more)) break;
+        // (the ballot of the predicate itself: __any() goes through an int)
+        if (__builtin_amdgcn_ballot_w64(more) == 0) break;
     }
 #pragma unroll
     for (int r = 0; r < kVsR; ++r) {
