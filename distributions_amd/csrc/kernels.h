@@ -1431,7 +1431,7 @@ __global__ void k_score_rows(SweepParams P, float * __restrict__ out,
 // per-row work shrinks to the two order-sensitive recurrences (running sum,
 // subtractive scan) over wave-uniform inputs, with one per-lane exp for the
 // own slot.  Rows are pre-sorted by value (static: values never change), one
-// wave = one tile of <= 64 rows of one value.  Every float operation a row
+// wave = one tile of <= 64 * kVsR rows of one value.  Every float operation a row
 // performs is the one the generic kernel performs, in the same order; rows the
 // shortcut does not cover exactly (group of one member; own-slot score above
 // M[x] through table rounding; DPD OTHER) are handed to the generic kernel.
@@ -1606,22 +1606,25 @@ __global__ __launch_bounds__(kBlock) void k_vs_prepare(
     }
 }
 
-// rows per wave = 64 * kVsR: R consecutive tiles of one value share every
-// scalar load of the likelihood vector, so a 16-entry chunk feeds 16*R vector
-// ops and the scalar-load latency hides behind them
+// rows per lane (a tile = 64 * kVsR rows of one value).  Two: the lane's two
+// running values advance as one v_pk_add_f32 per entry, the entry selected
+// into both halves from its scalar register (tools/microbench/pk_add.hip:
+// 1.75x the rows per second of v_sub_f32, bit-identical)
 constexpr int kVsR = 2;
 
 // The two order-sensitive recurrences for the lanes whose likelihood vector
 // is `lp` (wave-uniform), own slot replaced by the lane's l_own:
 //   total = ((l_0 + l_1) + l_2) + ...                  random.cc:100-103
 //   t = total*u; t -= l_k until t <= 0                 random.hpp:323-330
-// The vector is consumed in chunks of 16 scalar-loaded entries.  For a
-// sub-tile in which no lane's own slot falls into the chunk, the chunk is
-// pure uniform arithmetic (one VALU op per entry and pass); otherwise it takes
-// the per-lane select.  Subtracting non-negative terms never increases t, so
-// each lane crosses zero in exactly one chunk; the scan only records that
-// chunk and the value of t on entry, and the lane then replays its 16
-// subtractions to get the exact index.
+// The vector is consumed in chunks of kVsUnroll scalar-loaded entries.  A
+// chunk into which no lane's own slot falls is pure uniform arithmetic (one
+// packed VALU op per entry and pass); otherwise its eight-entry pieces that
+// hold an own slot take the per-lane select.  Subtracting non-negative terms
+// never increases t, so each lane crosses zero in exactly one chunk; the scan
+// only records that chunk and the value of t on entry, and the lane then
+// replays its kVsUnroll subtractions to get the exact index.  With `prefix`
+// (the value's running sums at the chunk boundaries, k_vs_prepare) the total
+// starts at the tile's first own chunk.
 // Tables far larger than the scalar cache (C5: 328 MB) stream through the same
 // scalar loads: a coalesced-vector-load + v_readlane variant measured 1.2-1.7x
 // slower at every table size and was dropped.
