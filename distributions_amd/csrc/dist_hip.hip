@@ -1789,79 +1789,15 @@ struct Gibbs {
     // groups that lost their last member are swap-removed in descending slot
     // order; one empty group is appended per previously empty group that
     // gained members; caches are rebuilt from the statistics.
-    // appended groups zeroed, caches rebuilt, driver scores and the next
-    // batch's base scores rebuilt: one launch (k_batch_finish), from the host's
-    // view of the group set (K(), py.n_empty, py.sample_size)
-    void launch_finish(int k_new, bool maps_on_device,
-                       uint32_t first_new_global, bool fresh) {
-        FinishParams Q;
-        memset(&Q, 0, sizeof(Q));
-        Q.F = F();
-        size_t cells = (size_t)K();
-        for (int f = 0; f < F(); ++f) {
-            Q.feat[f] = feats[f]->view();
-            // with current cells only the appended groups need a full column
-            const size_t groups = fresh ? (size_t)(K() - k_new) : (size_t)K();
-            cells = std::max(cells, groups * std::max(1, feats[f]->dim()));
-        }
-        Q.counts = py.d_counts.p;
-        Q.shifted = py.d_shifted.p;
-        Q.K = K();
-        Q.k_new = k_new;
-        // (moved groups carry their cache entries with them)
-        Q.cells_fresh = fresh ? 1 : 0;
-        Q.alpha = alpha;
-        Q.d = d;
-        Q.nonempty = K() - py.n_empty;
-        Q.empty = py.n_empty;
-        base.reserve(grow_capacity((size_t)K()), 0);
-        base_single.reserve(grow_capacity((size_t)K()), 0);
-        Q.prep = DriverPrep{alpha, d, cluster, dataset_size, py.sample_size,
-                            K(), py.n_empty, base.p, base_single.p, scalars.p};
-        base_valid = true;
-        if (maps_on_device) {
-            Q.p2g = d_maps.p;
-            Q.g2p = reinterpret_cast<int32_t *>(d_maps.p + maps_pcap);
-            Q.first_new_global = first_new_global;
-        }
-        hipLaunchKernelGGL(k_batch_finish,
-                           dim3((unsigned)((cells + kBlock - 1) / kBlock),
-                                (unsigned)(F() + 1)),
-                           dim3(kBlock), 0, stream(), Q);
-        HIP_CHECK(hipGetLastError());
-    }
-
     void batch_finish() {
         DIST_REQUIRE(batch_open, "no open batch");
         batch_open = false;
         const std::vector<int> snap = py.counts;
         const int K0 = K();
-        // Almost every batch leaves the group set as it was (nobody's last
-        // member left, no empty group filled).  k_batch_finish for that case
-        // needs nothing the host does not know already -- same K, same number
-        // of empty groups, same total -- so it is issued BEFORE the host waits
-        // for the group sizes and runs while the host looks at them; a batch
-        // that did change the set runs the launch again after its moves (the
-        // kernel only recomputes functions of the statistics).
-        const int empty_before = py.n_empty;
-        const long total_before = py.sample_size;
-        const bool fresh_cells = cells_fresh;
-        cells_fresh = false;
-        launch_finish(K0, false, 0u, fresh_cells);
         refresh_host_counts();
         int created = 0;
-        long total_now = 0;
-        bool unchanged = true;
-        for (int k = 0; k < K0; ++k) {
+        for (int k = 0; k < K0; ++k)
             if (snap[k] == 0 && py.counts[k] > 0) created += 1;
-            if ((snap[k] == 0) != (py.counts[k] == 0)) unchanged = false;
-            total_now += py.counts[k];
-        }
-        (void)empty_before;   // (the same groups are empty: n_empty stands)
-        if (unchanged && total_now == total_before) {
-            collect_timing();
-            return;
-        }
         bool structural = created > 0;
         // swap-removals in descending slot order, simulated on the host:
         // content[i] = original slot of the group that ends up in slot i
@@ -1924,7 +1860,43 @@ struct Gibbs {
             py.sample_size += c;
             py.n_empty += (c == 0);
         }
-        launch_finish(k_new, maps_on_device, first_new_global, fresh_cells);
+        FinishParams Q;
+        memset(&Q, 0, sizeof(Q));
+        Q.F = F();
+        size_t cells = (size_t)K();
+        const bool fresh = cells_fresh;
+        for (int f = 0; f < F(); ++f) {
+            Q.feat[f] = feats[f]->view();
+            // with current cells only the appended groups need a full column
+            const size_t groups = fresh ? (size_t)(K() - k_new) : (size_t)K();
+            cells = std::max(cells, groups * std::max(1, feats[f]->dim()));
+        }
+        Q.counts = py.d_counts.p;
+        Q.shifted = py.d_shifted.p;
+        Q.K = K();
+        Q.k_new = k_new;
+        // (moved groups carry their cache entries with them)
+        Q.cells_fresh = cells_fresh ? 1 : 0;
+        cells_fresh = false;
+        Q.alpha = alpha;
+        Q.d = d;
+        Q.nonempty = K() - py.n_empty;
+        Q.empty = py.n_empty;
+        base.reserve(grow_capacity((size_t)K()), 0);
+        base_single.reserve(grow_capacity((size_t)K()), 0);
+        Q.prep = DriverPrep{alpha, d, cluster, dataset_size, py.sample_size,
+                            K(), py.n_empty, base.p, base_single.p, scalars.p};
+        base_valid = true;
+        if (maps_on_device) {
+            Q.p2g = d_maps.p;
+            Q.g2p = reinterpret_cast<int32_t *>(d_maps.p + maps_pcap);
+            Q.first_new_global = first_new_global;
+        }
+        hipLaunchKernelGGL(k_batch_finish,
+                           dim3((unsigned)((cells + kBlock - 1) / kBlock),
+                                (unsigned)(F() + 1)),
+                           dim3(kBlock), 0, stream(), Q);
+        HIP_CHECK(hipGetLastError());
         // (reading the batch's kernel timer waits on nothing by now, and the
         // device already has its next launch)
         collect_timing();
