@@ -1673,6 +1673,8 @@ struct Gibbs {
                 stage = vs_stage.p;
             }
             const int sole = c.one_chunk_per_value ? 1 : 0;
+            int apply_device = 0;
+            HIP_CHECK(hipGetDevice(&apply_device));
             unsigned long long * pairs = nullptr;
             unsigned pairs_seq = 0;
             if (stage && img.counts == py.d_counts.p) {   // live statistics
@@ -1683,12 +1685,19 @@ struct Gibbs {
                 rblock(kVsReduceGroups * kVsReduceSlices);
 #define VS_APPLY(KIND, SORT, LDS)                                            \
             do {                                                             \
-                if ((LDS) > 64 * 1024)   /* beyond the default opt-in */     \
+                /* beyond the default opt-in: raised (never lowered) once  \
+                 * per size, kernel instance and device */                   \
+                static std::atomic<size_t> opted_in[64];                     \
+                std::atomic<size_t> & have = opted_in[apply_device & 63];    \
+                if ((LDS) > 64 * 1024                                        \
+                    && (LDS) > have.load(std::memory_order_relaxed)) {       \
                     HIP_CHECK(hipFuncSetAttribute(                           \
                         reinterpret_cast<const void *>(                      \
                             &k_vs_apply<KIND, SORT>),                        \
                         hipFuncAttributeMaxDynamicSharedMemorySize,          \
                         (int)(LDS)));                                        \
+                    have.store((LDS), std::memory_order_relaxed);            \
+                }                                                            \
                 hipLaunchKernelGGL((k_vs_apply<KIND, SORT>), grid, block,    \
                                    LDS, stream(), P, img, c.chunks.p,        \
                                    c.sorted_rows.p, d_p2g_ptr,               \
