@@ -810,6 +810,7 @@ struct Gibbs {
         DeviceBuf<VsTile> chunks;          // apply work items, one value each
         uint32_t n_chunks = 0;
         bool one_chunk_per_value = false;
+        DeviceBuf<uint32_t> val_start;    // [nvals + 1] first position per value
         DeviceBuf<uint32_t> other_pos;    // positions the tiles do not cover
         uint32_t n_other = 0;
         // the rows' current assignment (global ids) in sorted-position
@@ -849,6 +850,8 @@ struct Gibbs {
     std::vector<std::unique_ptr<VsCache>> vs_cache;
     DeviceBuf<float> vsLA, vsLB, vsM, vsmB, vsPA, vsPB;
     DeviceBuf<int32_t> vs_stage;   // [chunks][K] deltas of the open batch
+    DeviceBuf<int> vsBandMode;     // VsTables::band_mode
+    DeviceBuf<VsTile> vsBandTile;  // VsTables::band_tile
     DeviceBuf<ChainResult> chain_result;
     DeviceBuf<int32_t> delta_image;         // dist_gibbs_sweep_sharded
     DeviceBuf<float> own_score;             // k_row_prepass
@@ -1334,6 +1337,7 @@ struct Gibbs {
         for (uint32_t x = 0; x <= nv; ++x) start[x + 1] = start[x] + h[x];
         DeviceBuf<uint32_t> cursor;
         cursor.upload(start.data(), nv + 1);
+        c->val_start.upload(start.data(), nv + 1);
         c->sorted_rows.reserve(std::max<size_t>(n, 1), 0);
         hipLaunchKernelGGL(k_vs_scatter, sort_grid, dim3(kBlock), 0, stream(),
                            values[0], r0, n, nv, cursor.p, c->sorted_rows.p);
@@ -1392,14 +1396,17 @@ struct Gibbs {
                                c->n_other);
             HIP_CHECK(hipGetLastError());
             HIP_CHECK(hipEventRecord(self->ev0, stream()));
-            const int per = kVsSampleBlock / 64;   // tiles per workgroup
-            const dim3 grid((c->n_tiles + per - 1) / per),
+            const uint32_t per = kVsSampleBlock / 64;   // tiles per workgroup
+            // (band tiles first, a whole number of workgroups)
+            const uint32_t band_ids =
+                T.band_mode ? (nv + per - 1) / per * per : 0;
+            const dim3 grid((band_ids + c->n_tiles + per - 1) / per),
                 block(kVsSampleBlock);
             if (c->n_tiles)   // else every row's value lies beyond the table
                 hipLaunchKernelGGL((k_vs_sample<KIND>), grid, block, 0,
                                    stream(), *P, T, c->tiles.p, c->n_tiles,
-                                   c->sorted_rows.p, self->deferred.p,
-                                   self->deferred_count.p);
+                                   band_ids, c->sorted_rows.p,
+                                   self->deferred.p, self->deferred_count.p);
             HIP_CHECK(hipGetLastError());
             HIP_CHECK(hipEventRecord(self->ev1, stream()));
         }
@@ -1418,8 +1425,15 @@ struct Gibbs {
         vsArg.reserve(nv, 0);
         // chunk-boundary running sums: worth their serial pass in
         // k_vs_prepare once the sampling kernel is throughput-bound
-        const bool prefix = c.n_tiles >= (uint32_t)running_sums_min_tiles
-                            && Kpad <= 8192;
+        const bool large = c.n_tiles >= (uint32_t)running_sums_min_tiles;
+        const bool prefix = large && Kpad <= 8192;
+        // the arg-max group's rows get a tile of their own per value when the
+        // launch is large (and group-sorted: k_vs_apply's LDS sort fits)
+        const bool bands = large && n / nv <= kVsBandWalkRows;
+        if (bands) {
+            vsBandMode.reserve(nv, 0);
+            vsBandTile.reserve(nv, 0);
+        }
         if (prefix) {
             vsPA.reserve(grow_capacity((size_t)nv * (Kpad / kVsUnroll)), 0);
             vsPB.reserve(grow_capacity((size_t)nv * (Kpad / kVsUnroll)), 0);
@@ -1438,7 +1452,10 @@ struct Gibbs {
         VsLaunch L{this, &P, &c,
                    VsTables{vsLA.p, vsLB.p, vsM.p, vsmB.p, vsArg.p, Kpad,
                             prefix ? vsPA.p : nullptr,
-                            prefix ? vsPB.p : nullptr}};
+                            prefix ? vsPB.p : nullptr,
+                            bands ? vsBandMode.p : nullptr,
+                            bands ? vsBandTile.p : nullptr, c.val_start.p,
+                            nv}};
         switch (feats[0]->sh.kind) {
         case DIST_DD: L.go<DIST_DD>(); break;
         case DIST_DPD: L.go<DIST_DPD>(); break;

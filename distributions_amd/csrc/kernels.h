@@ -1437,6 +1437,16 @@ __global__ void k_score_rows(SweepParams P, float * __restrict__ out,
 // M[x] through table rounding; DPD OTHER) are handed to the generic kernel.
 
 constexpr int kVsUnroll = 32;   // entries per scalar-loaded chunk
+// rows per lane (a tile = 64 * kVsR rows of one value).  Two: the lane's two
+// running values advance as one v_pk_add_f32 per entry, the entry selected
+// into both halves from its scalar register (tools/microbench/pk_add.hip:
+// 1.75x the rows per second of v_sub_f32, bit-identical)
+constexpr int kVsR = 2;
+struct VsTile {
+    uint32_t x;      // the tile's value
+    uint32_t pos;    // first position in the sorted row list
+    uint32_t n;      // rows in the tile (<= 64 * kVsR)
+};
 struct VsTables {
     float * LA;      // [nvals][Kpad]
     float * LB;
@@ -1448,12 +1458,20 @@ struct VsTables {
     // P[x][c] = ((l_0 + l_1) + ...) + l_{32c-1}; null = not built
     float * PA;      // [nvals][Kpad / kVsUnroll]
     float * PB;
+    // Rows that sit in their value's arg-max group use LB.  A tile that holds
+    // some next to others runs both passes -- one or two tiles per value, and
+    // the SIMD that holds one sets the kernel's time.  In a group-sorted range
+    // those rows are one contiguous band, so k_vs_prepare looks for it and, if
+    // it is a band of at most one tile, gives it a tile of its own
+    // (band_tile[x], band_mode[x] = 1): the value's regular tiles then skip
+    // the band's rows and nobody runs two passes.  Otherwise band_mode[x] = 0
+    // and the tiles do as before.  Null: not used for this launch.
+    int * band_mode;              // [nvals]
+    VsTile * band_tile;           // [nvals]
+    const uint32_t * val_start;   // [nvals + 1] positions of each value's rows
+    uint32_t n_values;
 };
-struct VsTile {
-    uint32_t x;      // the tile's value
-    uint32_t pos;    // first position in the sorted row list
-    uint32_t n;      // rows in the tile (<= 64)
-};
+constexpr uint32_t kVsBandWalkRows = 8192;
 
 // score of a row with value x at its own slot g after removing itself
 __device__ __forceinline__ float vs_own_score(const SweepParams & P,
@@ -1482,6 +1500,8 @@ __global__ __launch_bounds__(kBlock) void k_vs_prepare(
     __shared__ float r_m1[kBlock / 64], r_m2[kBlock / 64];
     __shared__ int r_i1[kBlock / 64];
     __shared__ float sh_M, sh_mB;
+    __shared__ uint32_t sh_lo, sh_hi, sh_n;
+    __shared__ int sh_amax;
     extern __shared__ float s_l[];   // [2][Kpad] when the running sums are built
     const uint32_t x = blockIdx.x;
     SlaveView v = P.feat[0];
@@ -1541,6 +1561,8 @@ __global__ __launch_bounds__(kBlock) void k_vs_prepare(
         }
         T.M[x] = M; T.mB[x] = mB; T.argmax[x] = g;
         sh_M = M; sh_mB = mB;
+        sh_amax = g;
+        sh_lo = 0xFFFFFFFFu; sh_hi = 0u; sh_n = 0u;
     }
     __syncthreads();
     const float M = sh_M, mB = sh_mB;
@@ -1558,6 +1580,45 @@ __global__ __launch_bounds__(kBlock) void k_vs_prepare(
         if (T.PA) {
             s_l[k] = a;
             s_l[T.Kpad + k] = b;
+        }
+    }
+    if (T.band_mode) {
+        // the positions of this value's rows in the arg-max group (see
+        // VsTables): first, last, how many -- four loads in flight per thread
+        const uint32_t begin = T.val_start[x];
+        // (a value with very many rows has more than a tile of them in any
+        // group, and walking them here would cost more than it can save)
+        const bool walk = T.val_start[x + 1] - begin <= kVsBandWalkRows;
+        const uint32_t end = walk ? T.val_start[x + 1] : begin;
+        const uint32_t amax = (uint32_t)sh_amax;
+        constexpr int U = 4;
+        for (uint32_t base = begin + threadIdx.x; base < end;
+             base += U * kBlock) {
+            uint32_t gid[U], slot[U];
+#pragma unroll
+            for (int q = 0; q < U; ++q) {
+                const uint32_t i = base + q * kBlock;
+                gid[q] = i < end ? P.assign_pos[i] : 0u;
+            }
+#pragma unroll
+            for (int q = 0; q < U; ++q) slot[q] = (uint32_t)P.g2p[gid[q]];
+#pragma unroll
+            for (int q = 0; q < U; ++q) {
+                const uint32_t i = base + q * kBlock;
+                if (i < end && slot[q] == amax) {
+                    atomicMin(&sh_lo, i);
+                    atomicMax(&sh_hi, i);
+                    atomicAdd(&sh_n, 1u);
+                }
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t n = sh_n;
+            const bool band = n > 0 && sh_hi - sh_lo + 1u == n
+                              && n <= 64u * kVsR;
+            T.band_mode[x] = (walk && (band || n == 0)) ? 1 : 0;
+            T.band_tile[x] = VsTile{x, band ? sh_lo : 0u, band ? n : 0u};
         }
     }
     if (T.PA == nullptr) return;
@@ -1606,11 +1667,7 @@ __global__ __launch_bounds__(kBlock) void k_vs_prepare(
     }
 }
 
-// rows per lane (a tile = 64 * kVsR rows of one value).  Two: the lane's two
-// running values advance as one v_pk_add_f32 per entry, the entry selected
-// into both halves from its scalar register (tools/microbench/pk_add.hip:
-// 1.75x the rows per second of v_sub_f32, bit-identical)
-constexpr int kVsR = 2;
+
 
 // The two order-sensitive recurrences for the lanes whose likelihood vector
 // is `lp` (wave-uniform), own slot replaced by the lane's l_own:
@@ -1769,15 +1826,25 @@ __global__ __launch_bounds__(kVsSampleBlock)
 __attribute__((amdgpu_waves_per_eu(8, 8)))
 void k_vs_sample(
         SweepParams P, VsTables T, const VsTile * __restrict__ tiles,
-        uint32_t n_tiles, const uint32_t * __restrict__ sorted_rows,
+        uint32_t n_tiles, uint32_t n_band_ids,
+        const uint32_t * __restrict__ sorted_rows,
         uint32_t * __restrict__ deferred, uint32_t * deferred_count) {
     const int lane = threadIdx.x & 63;
-    const uint32_t tile_id = __builtin_amdgcn_readfirstlane(
+    const uint32_t id = __builtin_amdgcn_readfirstlane(
         blockIdx.x * (kVsSampleBlock / 64) + (threadIdx.x >> 6));
-    if (tile_id >= n_tiles) return;
-    const uint32_t x = __builtin_amdgcn_readfirstlane(tiles[tile_id].x);
-    const uint32_t pos = __builtin_amdgcn_readfirstlane(tiles[tile_id].pos);
-    const uint32_t n = __builtin_amdgcn_readfirstlane(tiles[tile_id].n);
+    // the first n_band_ids ids (a whole number of workgroups, resident from
+    // the launch's first cycle) are the values' band tiles (VsTables); a band
+    // tile samples the arg-max group's rows only, a regular tile of a value
+    // with a band tile everything else
+    const bool band = id < n_band_ids;
+    const VsTile * mine = band ? T.band_tile + id : tiles + (id - n_band_ids);
+    if (band ? id >= T.n_values : id - n_band_ids >= n_tiles) return;
+    const uint32_t x = __builtin_amdgcn_readfirstlane(mine->x);
+    const uint32_t pos = __builtin_amdgcn_readfirstlane(mine->pos);
+    const uint32_t n = __builtin_amdgcn_readfirstlane(mine->n);
+    if (n == 0) return;
+    const bool skip_a = band;
+    const bool skip_b = !band && n_band_ids != 0 && T.band_mode[x] != 0;
     SlaveView v = P.feat[0];
     v.kind = KIND;
     const int K = P.K;
@@ -1806,8 +1873,11 @@ void k_vs_sample(
             const uint32_t at = pos + kVsR * lane + r;
             row[r] = P.row_begin + sorted_rows[at];
             g[r] = P.g2p[P.assign_pos[at]];
-            const int n_g = P.counts[g[r]];
             classB = (g[r] == amax);
+            if (classB ? skip_b : skip_a) valid[r] = false;
+        }
+        if (valid[r]) {
+            const int n_g = P.counts[g[r]];
             const float m = classB ? mB : M;
             float s_own = 0.f;
             bool defer = (n_g == 1);
