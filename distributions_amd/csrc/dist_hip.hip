@@ -860,6 +860,16 @@ struct Gibbs {
     DeviceBuf<uint32_t> deferred, deferred_count;
     int value_sorted_mode = 1;   // 0 off, 1 auto, 2 always (when eligible)
     int running_sums_min_tiles = 2048;   // see sample_value_sorted
+    int cu_count_cached = 0;
+    int cu_count() {
+        if (!cu_count_cached) {
+            int dev = 0;
+            HIP_CHECK(hipGetDevice(&dev));
+            HIP_CHECK(hipDeviceGetAttribute(
+                &cu_count_cached, hipDeviceAttributeMultiprocessorCount, dev));
+        }
+        return cu_count_cached;
+    }
     uint64_t vs_batches = 0, generic_batches = 0;
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -1429,7 +1439,16 @@ struct Gibbs {
         const bool prefix = large && Kpad <= 8192;
         // the arg-max group's rows get a tile of their own per value when the
         // launch is large (and group-sorted: k_vs_apply's LDS sort fits)
-        const bool bands = large && n / nv <= kVsBandWalkRows;
+        // ... and their workgroups do not push the launch past what is
+        // resident at once (two 1024-thread workgroups per CU at 8 waves/SIMD;
+        // a band workgroup is gone in about half the time of a regular one)
+        const uint32_t per_wg = kVsSampleBlock / 64;
+        const uint32_t tile_wgs = (c.n_tiles + per_wg - 1) / per_wg;
+        const uint32_t band_wgs = (nv + per_wg - 1) / per_wg;
+        const uint32_t slots = 2u * (uint32_t)cu_count();
+        const bool bands = large && n / nv <= kVsBandWalkRows
+                           && (tile_wgs + band_wgs / 2 <= slots
+                               || tile_wgs > slots);
         if (bands) {
             vsBandMode.reserve(nv, 0);
             vsBandTile.reserve(nv, 0);

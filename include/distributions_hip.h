@@ -390,7 +390,8 @@ int dist_gibbs_global_to_packed(const dist_gibbs_t * g, uint32_t global,
  * 2 (value-sorted kernel whenever the feature list allows it);
  * "sequential_chain" = 1 (device-resident chain kernel, default) or 0;
  * "running_sums_min_tiles" = launches of at least this many value tiles use
- * the per-value running sums (default 2048).  None changes a result. */
+ * the per-value running sums and band tiles (default 2048).  None changes a
+ * result. */
 int dist_gibbs_set_option(dist_gibbs_t * g, const char * name, int value);
 /* how many batches each score+sample kernel has served */
 int dist_gibbs_path_counts(const dist_gibbs_t * g, uint64_t * value_sorted,
