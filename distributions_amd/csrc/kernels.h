@@ -1582,29 +1582,83 @@ __global__ __launch_bounds__(kBlock) void k_vs_prepare(
             s_l[T.Kpad + k] = b;
         }
     }
-    if (T.band_mode) {
-        // the positions of this value's rows in the arg-max group (see
-        // VsTables): first, last, how many -- four loads in flight per thread
+    // Two jobs are left, and they run side by side:
+    //  * waves 0 and 1, one lane each: the running sums.  The likelihood total
+    //    of a row is the index-order sum with the row's own slot replaced
+    //    (random.cc:100-103), so up to the first own slot of a tile it is the
+    //    same number for every row of the value: the lane walks the vector
+    //    once (a dependent chain of Kpad adds, fed from the copy in LDS one
+    //    chunk ahead) and leaves the running sum at each chunk boundary;
+    //    k_vs_sample starts there.
+    //  * the other waves (all of them without running sums): the positions of
+    //    this value's rows in the arg-max group (VsTables::band_tile) --
+    //    first, last, how many; four loads in flight per thread.
+    if (T.PA == nullptr && T.band_mode == nullptr) return;
+    __syncthreads();   // s_l is complete
+    const int wave = threadIdx.x >> 6;
+    const bool chains = T.PA != nullptr;
+    bool walk = false;
+    if (chains && wave < 2) {
+        if ((threadIdx.x & 63) == 0) {
+            const float4 * src =
+                reinterpret_cast<const float4 *>(s_l + wave * T.Kpad);
+            const int nchunks = T.Kpad / kVsUnroll;
+            float * dst = (wave ? T.PB : T.PA) + (size_t)x * nchunks;
+            constexpr int Q = kVsUnroll / 4;
+            float4 even[Q], odd[Q];   // ping-pong: no register copies
+#pragma unroll
+            for (int q = 0; q < Q; ++q) even[q] = src[q];
+            float run = 0.f;
+            auto add_chunk = [&run](const float4 (&v)[Q]) {
+#pragma unroll
+                for (int q = 0; q < Q; ++q) {
+                    run += v[q].x;
+                    run += v[q].y;
+                    run += v[q].z;
+                    run += v[q].w;
+                }
+            };
+            for (int c = 0; c < nchunks; c += 2) {
+                const int c1 = c + 1 < nchunks ? c + 1 : c;
+#pragma unroll
+                for (int q = 0; q < Q; ++q) odd[q] = src[c1 * Q + q];
+                __builtin_amdgcn_sched_barrier(0);   // loads first
+                dst[c] = run;
+                add_chunk(even);
+                __builtin_amdgcn_sched_barrier(0);
+                if (c + 1 >= nchunks) break;
+                const int c2 = c + 2 < nchunks ? c + 2 : c;
+#pragma unroll
+                for (int q = 0; q < Q; ++q) even[q] = src[c2 * Q + q];
+                __builtin_amdgcn_sched_barrier(0);
+                dst[c + 1] = run;
+                add_chunk(odd);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    } else if (T.band_mode) {
         const uint32_t begin = T.val_start[x];
         // (a value with very many rows has more than a tile of them in any
         // group, and walking them here would cost more than it can save)
-        const bool walk = T.val_start[x + 1] - begin <= kVsBandWalkRows;
+        walk = T.val_start[x + 1] - begin <= kVsBandWalkRows;
         const uint32_t end = walk ? T.val_start[x + 1] : begin;
         const uint32_t amax = (uint32_t)sh_amax;
+        const uint32_t first = chains ? 128u : 0u;   // walking threads
+        const uint32_t step = kBlock - first;
         constexpr int U = 4;
-        for (uint32_t base = begin + threadIdx.x; base < end;
-             base += U * kBlock) {
+        for (uint32_t base = begin + (threadIdx.x - first); base < end;
+             base += U * step) {
             uint32_t gid[U], slot[U];
 #pragma unroll
             for (int q = 0; q < U; ++q) {
-                const uint32_t i = base + q * kBlock;
+                const uint32_t i = base + q * step;
                 gid[q] = i < end ? P.assign_pos[i] : 0u;
             }
 #pragma unroll
             for (int q = 0; q < U; ++q) slot[q] = (uint32_t)P.g2p[gid[q]];
 #pragma unroll
             for (int q = 0; q < U; ++q) {
-                const uint32_t i = base + q * kBlock;
+                const uint32_t i = base + q * step;
                 if (i < end && slot[q] == amax) {
                     atomicMin(&sh_lo, i);
                     atomicMax(&sh_hi, i);
@@ -1612,62 +1666,17 @@ __global__ __launch_bounds__(kBlock) void k_vs_prepare(
                 }
             }
         }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const uint32_t n = sh_n;
-            const bool band = n > 0 && sh_hi - sh_lo + 1u == n
-                              && n <= 64u * kVsR;
-            T.band_mode[x] = (walk && (band || n == 0)) ? 1 : 0;
-            T.band_tile[x] = VsTile{x, band ? sh_lo : 0u, band ? n : 0u};
-        }
     }
-    if (T.PA == nullptr) return;
-    // The likelihood total of a row is the index-order sum with the row's own
-    // slot replaced (random.cc:100-103), so up to the first own slot of a
-    // tile it is the same number for every row of the value: one lane per
-    // table walks the vector once (a dependent chain of Kpad adds, ~7 cycles
-    // each, fed from the copy in LDS one chunk ahead) and leaves the running
-    // sum at each chunk boundary; k_vs_sample starts there.
+    if (T.band_mode == nullptr) return;
     __syncthreads();
-    if ((threadIdx.x & 63) != 0 || threadIdx.x >= 128) return;
-    const int w = threadIdx.x >> 6;
-    const float4 * src = reinterpret_cast<const float4 *>(s_l + w * T.Kpad);
-    const int nchunks = T.Kpad / kVsUnroll;
-    float * dst = (w ? T.PB : T.PA) + (size_t)x * nchunks;
-    constexpr int Q = kVsUnroll / 4;
-    float4 even[Q], odd[Q];   // ping-pong: no register copies in the chain
-#pragma unroll
-    for (int q = 0; q < Q; ++q) even[q] = src[q];
-    float run = 0.f;
-    auto add_chunk = [&run](const float4 (&v)[Q]) {
-#pragma unroll
-        for (int q = 0; q < Q; ++q) {
-            run += v[q].x;
-            run += v[q].y;
-            run += v[q].z;
-            run += v[q].w;
-        }
-    };
-    for (int c = 0; c < nchunks; c += 2) {
-        const int c1 = c + 1 < nchunks ? c + 1 : c;
-#pragma unroll
-        for (int q = 0; q < Q; ++q) odd[q] = src[c1 * Q + q];
-        __builtin_amdgcn_sched_barrier(0);   // loads first: a chunk ahead
-        dst[c] = run;
-        add_chunk(even);
-        __builtin_amdgcn_sched_barrier(0);
-        if (c + 1 >= nchunks) break;
-        const int c2 = c + 2 < nchunks ? c + 2 : c;
-#pragma unroll
-        for (int q = 0; q < Q; ++q) even[q] = src[c2 * Q + q];
-        __builtin_amdgcn_sched_barrier(0);
-        dst[c + 1] = run;
-        add_chunk(odd);
-        __builtin_amdgcn_sched_barrier(0);
+    if (threadIdx.x == kBlock - 1) {   // (a walking thread: it knows `walk`)
+        const uint32_t n = sh_n;
+        const bool band = n > 0 && sh_hi - sh_lo + 1u == n
+                          && n <= 64u * kVsR;
+        T.band_mode[x] = (walk && (band || n == 0)) ? 1 : 0;
+        T.band_tile[x] = VsTile{x, band ? sh_lo : 0u, band ? n : 0u};
     }
 }
-
-
 
 // The two order-sensitive recurrences for the lanes whose likelihood vector
 // is `lp` (wave-uniform), own slot replaced by the lane's l_own:
