@@ -9,21 +9,29 @@ score all K groups, sample, add), in frozen sub-sweeps of --batch rows, with
 the statistics update, group-set normalisation and cache rebuild included.
 Rows are generated on the device (seeded) before the timed region.
 
-N > 1: one process per GPU (torch.distributed, backend nccl == RCCL); rows
-are sharded, weak scaling (N rows per GPU), one all-reduce of the integer
-statistic deltas per sub-sweep.
+`--gpus N` with N > 1 starts N ranks itself (one process per GPU, backend
+nccl == RCCL) unless a launcher (torch.distributed.run) already set
+WORLD_SIZE; the parent never touches a GPU.  Rows are sharded, weak scaling
+(N rows per GPU), one all-reduce of the integer statistic deltas per
+sub-sweep; `strong_scaling` adds the same job with --rows split over the
+ranks.
 
 Prints ONE JSON line (rank 0).  `roofline` prices the score+sample kernel
-(k_vs_sample, or k_sweep_sample when the value-sorted kernel does not apply)
-by ALGORITHMIC bytes: (12*K + 12) B per row over its HIP-event
-duration on the launch stream; `traffic` is the HBM byte count per launch from
-the committed rocprofv3 PMC passes (profiles/).  `cpu_baseline` times the
-oracle's sequential chain (the reference loop restated, oracle/oracle.c) on a
-bounded row sample of the same workload, one host thread.
+(k_vs_sample, or k_sweep_sample / k_sweep_program where the value-sorted kernel
+does not apply): its HIP-event duration on the launch stream is measured in
+this run; the counters behind `frac` (VALU busy cycles for the VALU-bound
+kernels, HBM bytes for the HBM-bound one) come from the rocprofv3 --pmc passes
+of this same command committed under profiles/ (profiles/r2_counters.json,
+ignored when the kernel sources changed since).  `cpu_baseline` times the
+oracle's sequential chain (the reference loop restated, oracle/oracle.c) on the
+first --cpu-rows rows of the very column the GPU holds, one host thread.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -32,6 +40,10 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s
+SIMDS = 1024            # 256 CUs x 4 SIMDs
+CLOCK_GHZ = 2.4         # MI355X_MICROARCH.md: max clock
+METRIC = ("row-Gibbs-updates/sec (score+sample+suffstat) at N=10M, K=1024; "
+          "1/2/4/8 GPU")
 
 
 def parse():
@@ -51,62 +63,177 @@ def parse():
     ap.add_argument("--cpu-rows", type=int, default=1_000_000,
                     help="rows of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--config", default="dd",
-                    choices=["dd", "gp_nich", "dpd", "bb", "gp", "nich", "mixed"],
+                    choices=["dd", "dd16", "gp_nich", "dpd", "bb", "gp",
+                             "nich", "mixed"],
                     help="dd = the headline workload (BASELINE configs[1]); "
                          "the others are the remaining BASELINE configs, for "
                          "DESIGN.md's table (not the bench line of record)")
+    ap.add_argument("--values", default="uniform",
+                    choices=["uniform", "zipf"],
+                    help="categorical columns: iid uniform, or Zipf(1.1) "
+                         "(SURVEY 8d's skewed variant of C2)")
     ap.add_argument("--value-sorted", type=int, default=1,
                     help="0 generic kernel only, 1 auto, 2 force")
+    ap.add_argument("--other-batches", default="65536",
+                    help="comma-separated sub-sweep sizes timed besides "
+                         "--batch (a few steps each, reported in "
+                         "`batch_variants`; empty = none)")
     ap.add_argument("--torch-collectives", action="store_true",
                     help="keep the per-batch all-reduce on torch.distributed "
                          "instead of the library's own RCCL communicator")
     ap.add_argument("--force-collective", action="store_true",
                     help="diagnostic: run the N>1 code path (statistic "
                          "deltas + RCCL all-reduce) with a single rank")
+    ap.add_argument("--no-strong", action="store_true",
+                    help="N > 1: skip the strong-scaling leg")
     return ap.parse_args()
 
 
-def measured_traffic(kernel, rows_per_launch):
-    """HBM bytes per launch of `kernel` from the committed PMC passes
-    (profiles/r1_traffic.json: FETCH_SIZE + WRITE_SIZE, separate rocprofv3
-    --pmc runs of this same command), scaled to this run's rows per launch.
-    None when no measurement is on file for the kernel."""
-    path = os.path.join(ROOT, "profiles", "r1_traffic.json")
+# ---------------------------------------------------------------------------
+# the launcher: `python bench.py --gpus N` starts its own ranks
+
+def libraries_built():
+    import glob
+    return (os.path.exists(os.path.join(ROOT, "distributions_amd",
+                                        "libdistributions_hip.so"))
+            and glob.glob(os.path.join(ROOT, "distributions_amd", "_core*.so"))
+            and os.path.exists(os.path.join(ROOT, "oracle", "liboracle.so")))
+
+
+def ensure_built():
+    """Compile what a bare checkout lacks, in a child process (the product has
+    no CPU path to fall back on, and this process must stay off the GPU)."""
+    if libraries_built():
+        return
+    import fcntl
+    # ranks of a launcher start together: one builds, the others wait here
+    with open(os.path.join(ROOT, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not libraries_built():
+                subprocess.check_call(
+                    [sys.executable, "-c",
+                     "import __graft_entry__; __graft_entry__.build()"],
+                    cwd=ROOT)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def launch_ranks(args):
+    """Parent of an N-rank run: builds once, checks the device count, starts
+    one child per GPU and exits with their status.  Touches no GPU itself
+    (torch.cuda.device_count() does not initialise one on this image)."""
+    ensure_built()
+    import torch
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        sys.stderr.write(
+            "bench.py: --gpus %d asked for, %d GPU(s) visible: refusing to "
+            "report an N-GPU number from fewer devices\n" % (args.gpus, have))
+        return 2
+    with socket.socket() as s:    # a free rendezvous port for this run
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(args.gpus):
+        env = dict(os.environ)
+        env.update(RANK=str(rank), LOCAL_RANK=str(rank),
+                   WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen(
+            [sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+            env=env, stdout=None if rank == 0 else subprocess.DEVNULL))
+    status = 0
+    live = list(procs)
+    while live:
+        for p in list(live):
+            rc = p.poll()
+            if rc is None:
+                continue
+            live.remove(p)
+            if rc != 0 and status == 0:
+                status = rc
+                for q in live:     # a rank died: its peers would hang
+                    q.terminate()
+        time.sleep(0.05)
+    return status
+
+
+# ---------------------------------------------------------------------------
+
+def source_hash():
+    """What the committed counters were measured on: the kernel sources."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "distributions_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")) and name != "ref_tables.h":
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def committed_counters(kernel):
+    """Per-launch counter means of `kernel` from the committed rocprofv3
+    --pmc passes (profiles/r2_counters.json, written by tools/counters.py on
+    the GPU box from separate passes of this command).  None when there is no
+    record or the kernel sources changed since it was taken."""
+    path = os.path.join(ROOT, "profiles", "r2_counters.json")
     try:
-        rec = json.load(open(path))[kernel]
-    except (OSError, KeyError, ValueError):
+        rec = json.load(open(path))
+    except (OSError, ValueError):
         return None
-    kb = rec["fetch_kb_per_launch"] + rec["write_kb_per_launch"]
-    return kb * 1024.0 * rows_per_launch / rec["rows_per_launch"]
+    k = rec.get("kernels", {}).get(kernel)
+    if k is None:
+        return None
+    k = dict(k)
+    k["stale"] = rec.get("source_hash") != source_hash()
+    return k
 
 
-def cpu_baseline(args):
-    """Oracle (port of the reference loop) on a bounded sample.  The figure of
-    record is ONE thread (the reference is single-threaded); `all_cores` adds
-    what the host reaches with one independent chain per core."""
+def host_cpu():
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return model, os.cpu_count() or 1
+
+
+def cpu_baseline(args, column_host):
+    """Oracle (port of the reference loop) on a bounded sample: the first
+    `cpu_rows` rows of the column the GPU holds.  The figure of record is ONE
+    thread (the reference is single-threaded); `all_cores` adds what the host
+    reaches with one independent chain per core, `march_native` the same
+    single chain from a -march=native build of the same file."""
     import threading
     import numpy as np
     import oracle_lib as ol
 
-    def chain(n, seed):
-        rng = np.random.default_rng(seed)
-        values = rng.integers(0, args.dim, n).astype(np.uint32)
+    dim = 16 if args.config == "dd16" else args.dim
+
+    def chain(values, lib=None):
+        n = len(values)
         assign = (np.arange(n) % args.groups).astype(np.uint32)
         orc = ol.OracleMixture(args.alpha, args.d, [
-            ol.make_shared(ol.DD, alphas=[0.5] * args.dim)])
+            ol.make_shared(ol.DD, alphas=[0.5] * dim)], lib=lib)
         orc.init_from_assignments([values], assign, args.groups, 1)
         return orc
 
-    n = min(args.cpu_rows, args.rows)
-    orc = chain(n, args.seed)
+    n = len(column_host)
+    values = np.ascontiguousarray(column_host, np.uint32)
+    orc = chain(values)
     st = ol.oracle().orc_rng_seed(args.seed)
     t0 = time.perf_counter()
     orc.gibbs_sequential(0, n, st)
     dt = time.perf_counter() - t0
 
-    cores = os.cpu_count() or 1
+    model, cores = host_cpu()
     n_par = max(10000, n // 8)
-    chains = [chain(n_par, args.seed + 1 + i) for i in range(cores)]
+    chains = [chain(np.roll(values, 7919 * (i + 1))[:n_par].copy())
+              for i in range(cores)]
     threads = [threading.Thread(target=c.gibbs_sequential, args=(0, n_par, st))
                for c in chains]          # ctypes releases the GIL
     t1 = time.perf_counter()
@@ -115,55 +242,46 @@ def cpu_baseline(args):
     for t in threads:
         t.join()
     dt_par = time.perf_counter() - t1
-    return {
+    out = {
         "value": n / dt,
         "unit": "row-updates/s",
         "cores": 1,
         "kind": "port",
-        "sample": "one sequential sweep over the first %d rows of the "
-                  "workload (K=%d, dim=%d), oracle/oracle.c -O3, %.1f s"
-                  % (n, args.groups, args.dim, dt),
+        "cpu": model,
+        "host_cores": cores,
+        "sample": "one sequential sweep (the reference's loop, "
+                  "examples/mixture/main.py:236-244) over the first %d rows "
+                  "of the GPU's own column (copied to the host), K=%d, "
+                  "dim=%d; oracle/oracle.c, gcc -O3 -msse4.1 -fno-fast-math, "
+                  "%.1f s" % (n, args.groups, dim, dt),
         "all_cores": {"value": cores * n_par / dt_par, "cores": cores,
                       "sample": "%d independent chains of %d rows, %.1f s"
                                 % (cores, n_par, dt_par)},
     }
-
-
-def main():
-    args = parse()
-    import torch
-    import torch.distributed as dist
+    # the same file built for this host's own instruction set
     try:
-        from distributions_amd import _core, engine
-    except (ImportError, OSError):
-        # a checkout without the built libraries: compile them, then go on
-        # (there is no other way to run: the product has no CPU path)
-        import __graft_entry__
-        if int(os.environ.get("LOCAL_RANK", "0")) == 0:
-            __graft_entry__.build()
-        else:
-            time.sleep(240)
-        from distributions_amd import _core, engine
+        subprocess.check_call(["make", "-s", "-C",
+                               os.path.join(ROOT, "oracle"), "native"],
+                              stdout=subprocess.DEVNULL,
+                              stderr=subprocess.DEVNULL)
+        native = ol.bind_oracle(os.path.join(ROOT, "oracle", "_native",
+                                             "liboracle_native.so"))
+        n_nat = min(n, 200_000)
+        orc2 = chain(values[:n_nat].copy(), native)
+        t2 = time.perf_counter()
+        orc2.gibbs_sequential(0, n_nat, st)
+        dt2 = time.perf_counter() - t2
+        out["march_native"] = {
+            "value": n_nat / dt2, "cores": 1,
+            "sample": "first %d rows, gcc -O3 -march=native "
+                      "-fno-fast-math -ffp-contract=off, %.1f s"
+                      % (n_nat, dt2)}
+    except (subprocess.CalledProcessError, OSError, AttributeError) as e:
+        out["march_native"] = {"value": None, "error": str(e)[:200]}
+    return out
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 or args.force_collective:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29577")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
-    torch.cuda.set_device(local_rank)
-    _core.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
 
-    n = args.rows
-    k = args.groups
-    row_offset = rank * n
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(args.seed + rank)
-    assign = (torch.arange(n, device=dev, dtype=torch.int64)
-              + row_offset).remainder(k).to(torch.int32)
-
+def make_columns(args, torch, engine, dev, gen, n, k):
     def poisson(mean):
         return torch.poisson(torch.full((n,), mean, device=dev),
                              generator=gen).to(torch.int32)
@@ -172,36 +290,49 @@ def main():
         return torch.randn((n,), generator=gen, device=dev,
                            dtype=torch.float32)
 
-    if args.config == "dd":
-        columns = [torch.randint(0, args.dim, (n,), generator=gen, device=dev,
-                                 dtype=torch.int32)]
-        shareds = [engine.dd_shared([0.5] * args.dim)]
+    def categorical(dim):
+        if args.values == "zipf":
+            # Zipf(s = 1.1) over the dim values, by inversion
+            w = 1.0 / torch.arange(1, dim + 1, device=dev,
+                                   dtype=torch.float64) ** 1.1
+            cdf = torch.cumsum(w / w.sum(), 0).to(torch.float32)
+            u = torch.rand((n,), generator=gen, device=dev)
+            return torch.searchsorted(cdf, u).clamp_(max=dim - 1).to(
+                torch.int32)
+        return torch.randint(0, dim, (n,), generator=gen, device=dev,
+                             dtype=torch.int32)
+
+    if args.config in ("dd", "dd16"):
+        dim = 16 if args.config == "dd16" else args.dim
+        columns = [categorical(dim)]
+        shareds = [engine.dd_shared([0.5] * dim)]
         bytes_per_row = 12 * k + 12       # 4K (PY) + 2*4K (DD) + 12
+        name = "DirichletDiscrete(dim=%d)" % dim
     elif args.config == "dpd":
-        columns = [torch.randint(0, args.dim, (n,), generator=gen, device=dev,
-                                 dtype=torch.int32)]
+        columns = [categorical(args.dim)]
         shareds = [engine.dpd_shared(0.5, [1.0 / args.dim] * args.dim, 0.0)]
         bytes_per_row = 12 * k + 12
+        name = "DirichletProcessDiscrete(V=%d)" % args.dim
     elif args.config == "bb":
         columns = [(torch.rand((n,), generator=gen, device=dev) < 0.3).to(
             torch.int32)]
         shareds = [engine.bb_shared(0.5, 2.0)]
         bytes_per_row = 8 * k + 12
+        name = "BetaBernoulli"
     elif args.config == "gp":
         columns = [poisson(5.0)]
         shareds = [engine.gp_shared(1.0, 1.0)]
         bytes_per_row = 16 * k + 12
+        name = "GammaPoisson"
     elif args.config == "nich":
         columns = [normal()]
         shareds = [engine.nich_shared(0.0, 1.0, 1.0, 1.0)]
         bytes_per_row = 20 * k + 12
+        name = "NormalInverseChiSq"
     elif args.config == "mixed":
         # a row of mixed type, the shape of real tables: two categoricals, a
         # boolean, a count and a real (run-time feature list in the kernel)
-        columns = [torch.randint(0, 16, (n,), generator=gen, device=dev,
-                                 dtype=torch.int32),
-                   torch.randint(0, 4, (n,), generator=gen, device=dev,
-                                 dtype=torch.int32),
+        columns = [categorical(16), categorical(4),
                    (torch.rand((n,), generator=gen, device=dev) < 0.3).to(
                        torch.int32),
                    poisson(5.0), normal()]
@@ -209,55 +340,197 @@ def main():
                    engine.bb_shared(0.5, 2.0), engine.gp_shared(1.0, 1.0),
                    engine.nich_shared(0.0, 1.0, 1.0, 1.0)]
         bytes_per_row = (1 + 2 + 2 + 1 + 3 + 4) * 4 * k + 28
+        name = "DD(16)+DD(4)+BetaBernoulli+GammaPoisson+NormalInverseChiSq"
     else:   # gp_nich: BASELINE configs[2]
         columns = [poisson(5.0), normal()]
         shareds = [engine.gp_shared(1.0, 1.0),
                    engine.nich_shared(0.0, 1.0, 1.0, 1.0)]
         bytes_per_row = 32 * k + 16       # (1+3+4)*4K + 16
-    g = engine.Gibbs(args.alpha, args.d, shareds)
-    g.set_option("value_sorted", args.value_sorted)
-    initial = assign.clone()   # the engine keeps updating `assign` in place
-    g.load_rows_torch(columns, assign, k, 1, row_offset=row_offset)
-    sharded = engine.ShardedGibbs(g.core, n, row_offset, device=dev,
-                                  force_collective=args.force_collective,
-                                  columns=columns, assign_packed=initial)
-    sharded.sync_initial_stats()
-    native_comm = (not args.torch_collectives) and sharded.use_native_comm()
+        name = "GammaPoisson+NormalInverseChiSq"
+    return columns, shareds, bytes_per_row, name
+
+
+def run_rank(args):
+    import torch
+    import torch.distributed as dist
+    ensure_built()    # (under a launcher rank 0 of a bare checkout builds;
+    #                   launch_ranks has done it already for our own children)
+    from distributions_amd import _core, engine
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and not (world == 1 and args.gpus == 1):
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d\n"
+                         % (args.gpus, world))
+        return 2
+    if torch.cuda.device_count() <= local_rank:
+        sys.stderr.write("bench.py: rank %d has no GPU %d (%d visible)\n"
+                         % (rank, local_rank, torch.cuda.device_count()))
+        return 2
+    if world > 1 or args.force_collective:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    torch.cuda.set_device(local_rank)
+    _core.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    k = args.groups
     seed_state = _core.rng_seed(args.seed)
 
-    def step(i):
-        # every sweep draws a fresh stretch of the engine's stream
-        sharded.sweep(args.batch, seed_state, draw_base=i * n * world)
+    def build_job(n, row_offset):
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(args.seed + rank)
+        assign = (torch.arange(n, device=dev, dtype=torch.int64)
+                  + row_offset).remainder(k).to(torch.int32)
+        columns, shareds, bytes_per_row, name = make_columns(
+            args, torch, engine, dev, gen, n, k)
+        g = engine.Gibbs(args.alpha, args.d, shareds)
+        g.set_option("value_sorted", args.value_sorted)
+        initial = assign.clone()   # the engine updates `assign` in place
+        g.load_rows_torch(columns, assign, k, 1, row_offset=row_offset)
+        sharded = engine.ShardedGibbs(
+            g.core, n, row_offset, device=dev,
+            force_collective=args.force_collective, columns=columns,
+            assign_packed=initial)
+        sharded.sync_initial_stats()
+        return g, sharded, columns, bytes_per_row, name
 
-    for i in range(args.warmup):
-        step(i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    g.kernel_stats(reset=True)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    def timed(sharded, g, n, batch, steps, warmup, first_draw):
+        """-> seconds for `steps` sweeps (max over ranks)"""
+        def step(i):
+            # every sweep draws a fresh stretch of the engine's stream
+            sharded.sweep(batch, seed_state,
+                          draw_base=(first_draw + i) * n * world)
+        for i in range(warmup):
+            step(i)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        g.kernel_stats(reset=True)
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(warmup + i)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
 
+    n = args.rows
+    g, sharded, columns, bytes_per_row, name = build_job(n, rank * n)
+    native_comm = (not args.torch_collectives) and sharded.use_native_comm()
+    column_host = None
+    if (rank == 0 and world == 1 and args.cpu_rows > 0
+            and args.config in ("dd", "dd16")):
+        column_host = columns[0][:min(args.cpu_rows, n)].cpu().numpy()
+
+    dt = timed(sharded, g, n, args.batch, args.steps, args.warmup, 0)
     ms, launches, rows = g.kernel_stats()
-    total_rows = float(n) * world * args.steps
     vs_batches, generic_batches = g.path_counts()
-    kernel = ("k_vs_sample" if vs_batches else "k_sweep_sample") + "<%s>" % (
-        args.config)
+    draws = args.warmup + args.steps
+
+    # the same job at other sub-sweep sizes (value depends on it: the
+    # per-batch kernels and launch gaps do not shrink with the batch)
+    variants = []
+    for b in [int(x) for x in args.other_batches.split(",") if x.strip()]:
+        if b == args.batch or b <= 0:
+            continue
+        steps_b = max(1, min(args.steps, 5))
+        dt_b = timed(sharded, g, n, b, steps_b, 1, draws)
+        draws += 1 + steps_b
+        ms_b, launches_b, rows_b = g.kernel_stats()
+        variants.append({
+            "batch_rows": b, "value": float(n) * world * steps_b / dt_b,
+            "ms_per_step": 1e3 * dt_b / steps_b, "steps": steps_b,
+            "kernel_avg_launch_ms": ms_b / max(launches_b, 1)})
+
+    strong = None
+    if world > 1 and not args.no_strong:
+        # strong scaling: the SAME N rows in total, split over the ranks
+        comm = sharded.native_comm
+        del sharded, g, columns
+        torch.cuda.empty_cache()
+        n_s = n // world
+        g2, sharded2, _, _, _ = build_job(n_s, rank * n_s)
+        if native_comm:
+            sharded2.use_native_comm(comm)
+        steps_s = max(1, min(args.steps, 10))
+        batch_s = max(1, min(args.batch, n_s))
+        dt_s = timed(sharded2, g2, n_s, batch_s, steps_s, args.warmup, 0)
+        strong = {"value": float(n_s) * world * steps_s / dt_s,
+                  "unit": "row-updates/s", "rows_total": n_s * world,
+                  "rows_per_gpu": n_s, "batch_rows": batch_s,
+                  "steps": steps_s, "ms_per_step": 1e3 * dt_s / steps_s}
+
+    total_rows = float(n) * world * args.steps
+    if vs_batches:
+        kernel = "k_vs_sample<%s>" % args.config
+    elif args.config == "mixed":
+        kernel = "k_sweep_program"
+    else:
+        kernel = "k_sweep_sample<%s>" % args.config
     if rank == 0:
+        launches = max(launches, 1)
+        avg_ms = ms / launches
+        rows_per_launch = rows / launches
+        ctr = committed_counters(kernel)
+        usable = ctr is not None and not ctr["stale"]
+        scale = (rows_per_launch / ctr["rows_per_launch"]) if usable else 0.0
+        traffic = ((ctr["fetch_bytes"] + ctr["write_bytes"]) * scale
+                   if usable and ctr.get("fetch_bytes") is not None else None)
+        valu_cycles = (ctr["valu_busy_cycles"] * scale
+                       if usable and ctr.get("valu_busy_cycles") is not None
+                       else None)
+        hbm_bound = args.config == "dpd"
+        secs = 1e-3 * avg_ms
+        hbm_frac = (traffic / secs / 1e9 / HBM_PEAK_GBS
+                    if traffic is not None else None)
+        valu_frac = (valu_cycles / (SIMDS * CLOCK_GHZ * 1e9 * secs)
+                     if valu_cycles is not None else None)
+        if hbm_bound:
+            roof = {"bound": "hbm", "kernel": kernel,
+                    "achieved": (traffic / secs / 1e9
+                                 if traffic is not None else None),
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_frac}
+        else:
+            roof = {"bound": "valu", "kernel": kernel,
+                    "achieved": (valu_cycles / secs / 1e9
+                                 if valu_cycles is not None else None),
+                    "peak": SIMDS * CLOCK_GHZ,
+                    "unit": "G SIMD-busy-cycles/s", "frac": valu_frac,
+                    "hbm_frac": hbm_frac}
+        roof.update({
+            "traffic": traffic,
+            "algorithmic_bytes_per_row": bytes_per_row,
+            "algorithmic_GBps": bytes_per_row * rows_per_launch / secs / 1e9,
+            "rows_per_launch": rows_per_launch,
+            "avg_launch_ms": avg_ms,
+            "launches": launches,
+            "counters": (None if ctr is None else
+                         {"file": "profiles/r2_counters.json",
+                          "stale": ctr["stale"],
+                          "rows_per_launch": ctr["rows_per_launch"]}),
+            "note": "avg_launch_ms: HIP events on the launch stream, this "
+                    "run.  frac: VALU-busy cycles (SQ_ACTIVE_INST_VALU x 4) "
+                    "over 1024 SIMDs x 2.4 GHz x kernel time for the "
+                    "VALU-bound kernels, HBM bytes (FETCH_SIZE + WRITE_SIZE) "
+                    "over time over 8 TB/s for the HBM-bound one; counters "
+                    "from separate rocprofv3 --pmc passes of this command "
+                    "(profiles/).  algorithmic_GBps is SURVEY 8d's "
+                    "streaming-formulation byte count over the kernel time: "
+                    "the value-sorted kernels do not move those bytes (one "
+                    "likelihood vector serves 128 rows), so it is not a "
+                    "fraction of any roof: DESIGN.md section 4",
+        })
         out = {
-            "metric": "row-Gibbs-updates/sec (score+sample+suffstat) at "
-                      "N=10M, K=1024; 1/2/4/8 GPU",
+            "metric": METRIC,
             "value": total_rows / dt,
             "unit": "row-updates/s",
             "n_gpus": world,
@@ -270,49 +543,27 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "%s N=%d rows/GPU K=%d+1 "
+                "workload": "%s N=%d rows/GPU K=%d+1 %s values "
                             "PitmanYor(alpha=%g,d=%g), frozen sub-sweeps of "
-                            "%d rows" % (
-                                {"dd": "DirichletDiscrete(dim=%d)" % args.dim,
-                                 "dpd": "DirichletProcessDiscrete(V=%d)"
-                                        % args.dim,
-                                 "bb": "BetaBernoulli", "gp": "GammaPoisson",
-                                 "nich": "NormalInverseChiSq",
-                                 "gp_nich": "GammaPoisson+NormalInverseChiSq",
-                                 "mixed": "DD(16)+DD(4)+BetaBernoulli+"
-                                          "GammaPoisson+NormalInverseChiSq",
-                                 }[args.config],
-                                n, k, args.alpha, args.d, args.batch),
+                            "%d rows" % (name, n, k, args.values, args.alpha,
+                                         args.d, args.batch),
                 "rows_per_gpu": n, "groups": k, "dim": args.dim,
                 "batch_rows": args.batch,
                 "parallelism": "rows sharded over %d GPU(s), all-reduce of "
                                "statistic deltas per sub-sweep" % world,
-                "collectives": ("none" if not sharded.collective else
+                "collectives": ("none" if not sharded_collective(
+                                    world, args) else
                                 "library RCCL communicator" if native_comm
                                 else "torch.distributed (RCCL)"),
+                "comm_ranks": world if sharded_collective(world, args) else 0,
             },
-            "roofline": {
-                "bound": "hbm",
-                "kernel": kernel,
-                "achieved": (bytes_per_row * rows / max(launches, 1))
-                            / (1e-3 * ms / max(launches, 1)) / 1e9,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": (bytes_per_row * rows) / (1e-3 * ms) / 1e9
-                        / HBM_PEAK_GBS,
-                "traffic": measured_traffic(kernel, rows / max(launches, 1)),
-                "algorithmic_bytes_per_row": bytes_per_row,
-                "rows_per_launch": rows / max(launches, 1),
-                "avg_launch_ms": ms / max(launches, 1),
-                "launches": launches,
-                "note": "achieved = SURVEY 8d algorithmic bytes / kernel time; "
-                        "the value-sorted kernels serve those bytes from "
-                        "scalar-loaded per-value tables (HBM carries `traffic`) "
-                        "and are VALU-issue-bound: see DESIGN.md section 4",
-            },
+            "roofline": roof,
+            "batch_variants": variants,
         }
-        if world == 1 and args.cpu_rows > 0 and args.config == "dd":
-            out["cpu_baseline"] = cpu_baseline(args)
+        if strong is not None:
+            out["strong_scaling"] = strong
+        if column_host is not None:
+            out["cpu_baseline"] = cpu_baseline(args, column_host)
         # RCCL prints its version banner through C stdio; push that out first
         # so that the JSON line is the last thing on stdout
         try:
@@ -324,7 +575,22 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1 or args.force_collective:
         dist.destroy_process_group()
+    return 0
+
+
+def sharded_collective(world, args):
+    return world > 1 or args.force_collective
+
+
+def main():
+    args = parse()
+    if args.gpus < 1:
+        sys.stderr.write("bench.py: --gpus must be >= 1\n")
+        return 2
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_ranks(args)
+    return run_rank(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -192,6 +192,8 @@ cdef extern from "distributions_hip.h" nogil:
     int dist_gibbs_get_group(const dist_gibbs_t *, int, size_t, uint32_t *)
     int dist_gibbs_packed_to_global(const dist_gibbs_t *, uint32_t, uint32_t *)
     int dist_gibbs_global_to_packed(const dist_gibbs_t *, uint32_t, uint32_t *)
+    size_t dist_gibbs_global_size(const dist_gibbs_t *)
+    int dist_gibbs_debug_counts(dist_gibbs_t *, uint64_t *, size_t)
     int dist_gibbs_kernel_stats(dist_gibbs_t *, double *, uint64_t *,
                                 uint64_t *, int)
     int dist_gibbs_set_option(dist_gibbs_t *, const char *, int)
@@ -1043,6 +1045,17 @@ cdef class GibbsEngine:
         cdef uint32_t out = 0
         check(dist_gibbs_global_to_packed(self.ptr, global_, &out))
         return out
+
+    def global_size(self):
+        return dist_gibbs_global_size(self.ptr)
+
+    def debug_counts(self):
+        """dict of the engine's path diagnostics (dist_gibbs_debug_counts)"""
+        cdef uint64_t out[6]
+        check(dist_gibbs_debug_counts(self.ptr, out, 6))
+        return {"value_sorted_batches": out[0], "other_batches": out[1],
+                "band_launches": out[2], "running_sum_launches": out[3],
+                "band_values_last": out[4], "handed_over_last": out[5]}
 
     def set_option(self, name, int value):
         check(dist_gibbs_set_option(self.ptr, name.encode(), value))

@@ -32,7 +32,8 @@ void sort_pairs(void * temp, size_t temp_bytes, const uint32_t * keys_in,
                 uint32_t * vals_out, size_t n, int bits, hipStream_t stream);
 
 __device__ Tables g_tables_dev;
-__device__ LgammaLut g_lgamma_lut;
+__device__ LgammaLut g_lgamma_lut[2];
+__device__ int g_lgamma_cur;
 static Tables g_tables_host_storage;
 const Tables * g_tables_host = nullptr;
 
@@ -94,8 +95,14 @@ struct LgammaEntry {
     int users;
 };
 static std::map<int, std::map<float, LgammaEntry>> g_lgamma_registered;
+static std::map<int, int> g_lgamma_current;   // per device: the copy in use
 
-static void upload_lgamma_table(const std::map<float, LgammaEntry> & table) {
+// (under g_init_mutex)  The new table goes into the copy no kernel reads:
+// kernels that other host threads launch meanwhile keep searching the current
+// one, which stays untouched until the flip below; whatever still ran on the
+// spare copy from before the previous flip is drained first.
+static void upload_lgamma_table(int dev,
+                                const std::map<float, LgammaEntry> & table) {
     static LgammaLut staging;
     staging.n = 0;
     for (auto & kv : table) {
@@ -103,10 +110,15 @@ static void upload_lgamma_table(const std::map<float, LgammaEntry> & table) {
         staging.v[staging.n] = kv.second.value;
         staging.n += 1;
     }
-    HIP_CHECK(hipDeviceSynchronize());   // no kernel may be reading the table
-    HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_lgamma_lut), &staging,
-                                sizeof(LgammaLut)));
+    const int spare = 1 - g_lgamma_current[dev];
     HIP_CHECK(hipDeviceSynchronize());
+    HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_lgamma_lut), &staging,
+                                sizeof(LgammaLut),
+                                (size_t)spare * sizeof(LgammaLut)));
+    HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_lgamma_cur), &spare,
+                                sizeof(int)));
+    HIP_CHECK(hipDeviceSynchronize());
+    g_lgamma_current[dev] = spare;
 }
 // Adds the arguments below 2.5 among `ys` to the device's table (see
 // special.h: the reference evaluates libm's lgammaf there).  `hold`: the
@@ -134,7 +146,7 @@ static void register_small_lgamma(const std::vector<float> & ys,
         }
         if (hold) it->second.users += 1;
     }
-    if (changed) upload_lgamma_table(table);
+    if (changed) upload_lgamma_table(dev, table);
 }
 static void release_small_lgamma(const std::vector<float> & ys) {
     std::lock_guard<std::mutex> lock(g_init_mutex);
@@ -871,6 +883,10 @@ struct Gibbs {
         return cu_count_cached;
     }
     uint64_t vs_batches = 0, generic_batches = 0;
+    // diagnostics (dist_gibbs_debug_counts): launches that had band tiles /
+    // running sums switched on, and whether the last one did
+    uint64_t band_batches = 0, prefix_batches = 0;
+    bool last_bands = false, last_prefix = false;
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double kernel_ms = 0.0;
@@ -1033,13 +1049,22 @@ struct Gibbs {
             const volatile unsigned long long * pairs = pinned_pairs;
             bool seen = false;
             size_t k = 0;
-            for (long spin = 0; spin < 200000000L && !seen; ++spin) {
+            auto scan = [&] {
                 while (k < n && (pairs[k] >> 32) == want) ++k;
-                seen = k == n;
-            }
-            if (!seen) {   // (a failed kernel never writes: surface its error)
+                return k == n;
+            };
+            for (long spin = 0; spin < 200000000L && !seen; ++spin)
+                seen = scan();
+            if (!seen) {
+                // Not there after the bounded spin: the publishing kernel may
+                // simply be queued behind a long kernel or a collective that
+                // waits for a late peer.  Drain the stream (which also
+                // surfaces the error of a failed kernel) and look again;
+                // only slots still without the ticket after that are a bug.
                 HIP_CHECK(hipStreamSynchronize(stream()));
-                DIST_REQUIRE(false, "group sizes were not published");
+                std::atomic_thread_fence(std::memory_order_acquire);
+                seen = scan();
+                DIST_REQUIRE(seen, "group sizes were not published");
             }
             std::atomic_thread_fence(std::memory_order_acquire);
             for (size_t i = 0; i < n; ++i)
@@ -1384,8 +1409,16 @@ struct Gibbs {
         LAUNCH(k_pos_gather, n, assign + r0, c->sorted_rows.p,
                c->assign_pos.p, n);
         sync();
-        if (vs_cache.size() >= 64) {
+        // room for every range of a pass over the rows at this batch size (a
+        // pass that evicts its own ranges pays the sort, two host round
+        // trips and the loss of the group-sorted order on every batch); the
+        // ranges together hold 8 B per row plus the tile lists
+        const size_t keep = std::min<size_t>(
+            std::max<size_t>(64, (n_rows + n - 1) / std::max<size_t>(n, 1) + 2),
+            1u << 16);
+        if (vs_cache.size() >= keep) {
             flush_assign_pos();
+            sync();   // the evicted range's buffers are freed below
             vs_cache.erase(vs_cache.begin());
         }
         vs_cache.push_back(std::move(c));
@@ -1453,6 +1486,10 @@ struct Gibbs {
             vsBandMode.reserve(nv, 0);
             vsBandTile.reserve(nv, 0);
         }
+        last_bands = bands;
+        last_prefix = prefix;
+        band_batches += bands ? 1 : 0;
+        prefix_batches += prefix ? 1 : 0;
         if (prefix) {
             vsPA.reserve(grow_capacity((size_t)nv * (Kpad / kVsUnroll)), 0);
             vsPB.reserve(grow_capacity((size_t)nv * (Kpad / kVsUnroll)), 0);
@@ -2977,6 +3014,9 @@ int dist_gibbs_global_to_packed(const dist_gibbs_t * g, uint32_t global,
                                 uint32_t * out) {
     return guarded([&] { *out = g->impl->tracker.global_to_packed(global); });
 }
+size_t dist_gibbs_global_size(const dist_gibbs_t * g) {
+    return g->impl->tracker.g2p.size();
+}
 int dist_gibbs_set_option(dist_gibbs_t * g, const char * name, int value) {
     return guarded([&] {
         const std::string key(name);
@@ -3004,6 +3044,26 @@ int dist_gibbs_path_counts(const dist_gibbs_t * g, uint64_t * value_sorted,
     return guarded([&] {
         *value_sorted = g->impl->vs_batches;
         *generic = g->impl->generic_batches;
+    });
+}
+int dist_gibbs_debug_counts(dist_gibbs_t * g, uint64_t * out, size_t n) {
+    return guarded([&] {
+        Gibbs & e = *g->impl;
+        uint64_t v[6] = {e.vs_batches, e.generic_batches, e.band_batches,
+                         e.prefix_batches, 0, 0};
+        if (e.last_bands && !e.batch_open && e.vsBandMode.p) {
+            // values whose arg-max group's rows had a tile of their own in
+            // the last value-sorted launch
+            std::vector<int> mode((size_t)e.vs_nvals());
+            e.vsBandMode.download(mode.data(), mode.size());
+            for (int m : mode) v[4] += m != 0;
+        }
+        if (e.deferred_count.p) {
+            uint32_t d = 0;
+            e.deferred_count.download(&d, 1);
+            v[5] = d;
+        }
+        for (size_t i = 0; i < n && i < 6; ++i) out[i] = v[i];
     });
 }
 int dist_gibbs_kernel_stats(dist_gibbs_t * g, double * ms_out,

@@ -47,7 +47,11 @@ struct LgammaLut {
     float y[kLgammaLutCap];
     float v[kLgammaLutCap];
 };
-extern __device__ LgammaLut g_lgamma_lut;
+// Two copies: the host fills the one no kernel reads and then flips
+// g_lgamma_cur, so a table is never rewritten under a running kernel (another
+// host thread may launch while this one registers a feature).
+extern __device__ LgammaLut g_lgamma_lut[2];
+extern __device__ int g_lgamma_cur;
 
 DIST_HD float u2f(uint32_t u) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -132,13 +136,13 @@ DIST_HD float fast_exp_nonpos(float x, const uint32_t * exp_table, float a,
 // every scoring loop and cost them their registers.
 static __device__ __noinline__ float libm_lgammaf_device(float y) {
     // registered arguments: glibc's value, bit for bit
-    int lo = 0, hi = g_lgamma_lut.n;
+    const LgammaLut & lut = g_lgamma_lut[g_lgamma_cur & 1];
+    int lo = 0, hi = lut.n;
     while (lo < hi) {
         const int mid = (lo + hi) >> 1;
-        if (g_lgamma_lut.y[mid] < y) lo = mid + 1; else hi = mid;
+        if (lut.y[mid] < y) lo = mid + 1; else hi = mid;
     }
-    if (lo < g_lgamma_lut.n && g_lgamma_lut.y[lo] == y)
-        return g_lgamma_lut.v[lo];
+    if (lo < lut.n && lut.y[lo] == y) return lut.v[lo];
     return (float)::lgamma((double)y);
 }
 #endif

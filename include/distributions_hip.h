@@ -386,6 +386,8 @@ int dist_gibbs_packed_to_global(const dist_gibbs_t * g, uint32_t packed,
                                 uint32_t * global_out);
 int dist_gibbs_global_to_packed(const dist_gibbs_t * g, uint32_t global,
                                 uint32_t * packed_out);
+/* MixtureIdTracker::global_size (mixture.hpp:517): ids handed out so far */
+size_t dist_gibbs_global_size(const dist_gibbs_t * g);
 /* options: "value_sorted" = 0 (generic kernel only), 1 (auto, default),
  * 2 (value-sorted kernel whenever the feature list allows it);
  * "sequential_chain" = 1 (device-resident chain kernel, default) or 0;
@@ -396,6 +398,12 @@ int dist_gibbs_set_option(dist_gibbs_t * g, const char * name, int value);
 /* how many batches each score+sample kernel has served */
 int dist_gibbs_path_counts(const dist_gibbs_t * g, uint64_t * value_sorted,
                            uint64_t * generic);
+/* diagnostics for the tests: out[0..5] = batches through the value-sorted
+ * kernel, through the other kernels, launches with band tiles on, launches
+ * with running sums on, values whose arg-max rows had their own tile in the
+ * last value-sorted launch, rows that launch handed to the wave-per-row
+ * kernel (first min(n, 6) entries are written) */
+int dist_gibbs_debug_counts(dist_gibbs_t * g, uint64_t * out, size_t n);
 /* HIP-event time (ms) and launch count of the score+sample kernel since the
  * last reset, measured on the engine's stream */
 int dist_gibbs_kernel_stats(dist_gibbs_t * g, double * ms_out,

@@ -885,6 +885,7 @@ void orc_mix_tracker_remove_group(orc_mix * m, uint32_t packed) {
         m->g2p[m->p2g[packed]] = (int32_t)packed;
     }
 }
+uint32_t orc_mix_global_size(const orc_mix * m) { return m->global_size; }
 uint32_t orc_mix_packed_to_global(const orc_mix * m, uint32_t packed) {
     return m->p2g[packed];
 }
@@ -1342,6 +1343,62 @@ void orc_mix_init_from_assignments(orc_mix * m, size_t n_rows,
         for (size_t i = 0; i < n_rows; ++i)
             assign_global_out[i] = m->p2g[assign_packed[i]];
     free(counts);
+    orc_ftz_restore(saved);
+}
+
+/* Adopt a state that was produced elsewhere (tests: the engine's state after
+ * some sweeps, so that the oracle can follow it from there): K groups in the
+ * given slot order -- sizes, per-feature statistics as
+ * orc_mix_slave_get_group lays them out (one block of K * words per feature),
+ * the id maps of the tracker -- then the caches as init() builds them
+ * (clustering.hpp:151-161, mixture.hpp:354-359). */
+void orc_mix_load_state(orc_mix * m, int K, const int32_t * counts,
+                        const uint32_t * const * group_words,
+                        const uint32_t * p2g, uint32_t global_size) {
+    unsigned saved = orc_ftz_enable();
+    for (int fi = 0; fi < m->F; ++fi) {
+        feat * f = &m->f[fi];
+        f->K = 0;
+        for (int k = 0; k < K; ++k) orc_mix_slave_append_empty(m, fi);
+        const int kind = f->sh.kind;
+        const size_t words = is_cat(kind) ? 1 + (size_t)f->sh.dim
+                           : (kind == ORC_BB || kind == ORC_BNB) ? 2 : 3;
+        for (int k = 0; k < K; ++k) {
+            const uint32_t * w = group_words[fi] + (size_t)k * words;
+            f->i0[k] = (int32_t)w[0];
+            if (is_cat(kind)) {
+                memcpy(f->cnt + (size_t)k * f->sh.dim, w + 1,
+                       4 * (size_t)f->sh.dim);
+            } else if (kind == ORC_BB || kind == ORC_BNB) {
+                f->i1[k] = (int32_t)w[1];
+            } else if (kind == ORC_GP) {
+                f->i1[k] = (int32_t)w[1];
+                f->f0[k] = u2f(w[2]);
+            } else {
+                f->f0[k] = u2f(w[1]);
+                f->f1[k] = u2f(w[2]);
+            }
+        }
+    }
+    orc_mix_driver_init(m, counts, K);
+    for (int fi = 0; fi < m->F; ++fi) cache_update_all(&m->f[fi]);
+    /* the tracker: ids handed out so far, the live ones at their slots */
+    orc_mix_tracker_init(m, 0);
+    if ((int)global_size + 1 > m->g2p_cap) {
+        m->g2p_cap = (int)global_size + 16;
+        m->g2p = realloc(m->g2p, sizeof(int32_t) * m->g2p_cap);
+    }
+    if (K + 1 > m->p2g_cap) {
+        m->p2g_cap = K + 16;
+        m->p2g = realloc(m->p2g, sizeof(uint32_t) * m->p2g_cap);
+    }
+    for (uint32_t g = 0; g < global_size; ++g) m->g2p[g] = -1;
+    for (int k = 0; k < K; ++k) {
+        m->p2g[k] = p2g[k];
+        m->g2p[p2g[k]] = k;
+    }
+    m->p2g_size = K;
+    m->global_size = global_size;
     orc_ftz_restore(saved);
 }
 

@@ -173,6 +173,7 @@ void orc_py_sample_assignments(float alpha, float d, int size,
 void orc_mix_tracker_init(orc_mix * m, int group_count);
 void orc_mix_tracker_add_group(orc_mix * m);
 void orc_mix_tracker_remove_group(orc_mix * m, uint32_t packed);
+uint32_t orc_mix_global_size(const orc_mix * m);
 uint32_t orc_mix_packed_to_global(const orc_mix * m, uint32_t packed);
 uint32_t orc_mix_global_to_packed(const orc_mix * m, uint32_t global);
 
@@ -183,6 +184,11 @@ void orc_mix_init_from_assignments(orc_mix * m, size_t n_rows,
                                    const uint32_t * assign_packed,
                                    int nonempty_groups, int empty_groups,
                                    uint32_t * assign_global_out);
+/* adopt a state produced elsewhere: K groups in slot order with their sizes,
+ * statistics (orc_mix_slave_get_group layout, K blocks per feature) and ids */
+void orc_mix_load_state(orc_mix * m, int K, const int32_t * counts,
+                        const uint32_t * const * group_words,
+                        const uint32_t * p2g, uint32_t global_size);
 /* the reference loop, examples/mixture/main.py:236-244 over lp wrappers ==
  * SURVEY 3.2; consumes one engine step per row */
 void orc_mix_gibbs_sequential(orc_mix * m, size_t row_begin, size_t row_end,

@@ -73,6 +73,13 @@ def oracle():
     path = os.path.join(ORACLE_DIR, "liboracle.so")
     if not os.path.exists(path):
         build()
+    _ORACLE = bind_oracle(path)
+    return _ORACLE
+
+
+def bind_oracle(path):
+    """ctypes signatures of one build of oracle.c (liboracle.so, or the
+    -march=native build bench.py's cpu_baseline reports beside it)."""
     L = ctypes.CDLL(path)
     sz = ctypes.c_size_t
     u32 = ctypes.c_uint32
@@ -142,14 +149,15 @@ def oracle():
     sig("orc_mix_tracker_add_group", None, vp)
     sig("orc_mix_tracker_remove_group", None, vp, u32)
     sig("orc_mix_packed_to_global", u32, vp, u32)
+    sig("orc_mix_global_size", u32, vp)
     sig("orc_mix_global_to_packed", u32, vp, u32)
     pp = ctypes.POINTER(ctypes.c_void_p)
     sig("orc_mix_init_from_assignments", None, vp, sz, pp, c_u32p, ci, ci,
         c_u32p)
     sig("orc_mix_gibbs_sequential", None, vp, sz, sz, pp, c_u32p, u32ptr)
+    sig("orc_mix_load_state", None, vp, ci, c_i32p, pp, c_u32p, u32)
     sig("orc_mix_gibbs_batch", None, vp, sz, sz, pp, c_u32p, u32, u64)
     sig("orc_mix_batch_row_scores", ci, vp, c_u32p, u32, c_f32p)
-    _ORACLE = L
     return L
 
 
@@ -226,8 +234,8 @@ def ptr_array(arrays):
 class OracleMixture(object):
     """PY driver + feature slaves + id tracker, in the oracle."""
 
-    def __init__(self, alpha, d, shareds):
-        self.L = oracle()
+    def __init__(self, alpha, d, shareds, lib=None):
+        self.L = lib if lib is not None else oracle()
         self.shareds = list(shareds)
         arr = (Shared * max(1, len(shareds)))(*shareds)
         self._arr = arr
@@ -259,6 +267,41 @@ class OracleMixture(object):
             out)
         self.assign = out
         return out
+
+    # the accessors adopt() reads from an engine, so that one oracle can also
+    # adopt another's state (tests of load_state itself)
+    @property
+    def core(self):
+        return self
+
+    def packed_to_global(self, k):
+        return self.L.orc_mix_packed_to_global(self.h, k)
+
+    def global_size(self):
+        return self.L.orc_mix_global_size(self.h)
+
+    def assignments(self):
+        return self.assign
+
+    def adopt(self, gpu, values):
+        """Take over the engine's current state (group order, sizes,
+        statistics, id maps, assignments): the oracle then follows the GPU
+        from a state only the GPU has reached (e.g. sweep 2 at N = 10M)."""
+        K = len(gpu)
+        counts = np.ascontiguousarray(gpu.counts(), np.int32)
+        blocks = [np.ascontiguousarray(np.concatenate(
+            [gpu.get_group(f, g) for g in range(K)]).astype(np.uint32))
+            for f in range(self.F)]
+        p2g = np.array([gpu.core.packed_to_global(k) for k in range(K)],
+                       np.uint32)
+        self.values = [value_words(s.kind, v)
+                       for s, v in zip(self.shareds, values)]
+        self.n_rows = len(self.values[0]) if self.values else 0
+        self._vals = ptr_array(self.values)
+        self._blocks = blocks
+        self.L.orc_mix_load_state(self.h, K, counts, ptr_array(blocks), p2g,
+                                  int(gpu.core.global_size()))
+        self.assign = np.ascontiguousarray(gpu.assignments(), np.uint32).copy()
 
     def gibbs_sequential(self, row_begin, row_end, rng_state):
         st = ctypes.c_uint32(rng_state)

@@ -1,0 +1,86 @@
+"""Is a frozen sub-sweep still a sampler for the same posterior?
+
+The reference chain is sequential (examples/mixture/main.py:236-244); the
+engine scores a whole batch of B rows against one snapshot (DESIGN.md section
+3).  On a planted mixture -- 64 clusters over four DirichletDiscrete(16) and
+two NormalInverseChiSq features -- the sequential chain and batch chains start
+from the same assignment and are compared on the trajectory of the joint log
+score (Mixture.score_data over the features + PitmanYor.score_counts) and on
+the adjusted Rand index against the planted clusters.  This file runs the
+oracle (the batch semantics restated on the CPU; the GPU engine equals it bit
+for bit, tests/test_gpu_*.py) on 20 000 rows; tests/test_gpu_batch_validity.py
+runs the engine itself on 200 000.  What the runs show (tools/batch_validity.py
+prints the table DESIGN.md quotes): every B reaches the sequential chain's
+plateau; what B costs is burn-in -- a batch of B = N/10 lags the sequential
+chain by about one sweep, B = N/3 by two or three, B = N (fully synchronous)
+by seven."""
+import numpy as np
+
+import oracle_lib as ol
+import workloads
+
+ALPHA, D = 1.0, 0.0
+
+
+def joint_score(m):
+    s = sum(m.L.orc_mix_slave_score_data(m.h, f) for f in range(m.F))
+    c = np.ascontiguousarray(m.counts(), np.int32)
+    return s + m.L.orc_py_score_counts(ALPHA, D, c, c.size)
+
+
+def run_chain(osh, vals, start, k0, batch, sweeps, seed=7):
+    """batch == 0: the sequential chain.  -> (score per row after each sweep,
+    final assignment)"""
+    n = len(start)
+    m = ol.OracleMixture(ALPHA, D, osh)
+    m.init_from_assignments(vals, start, k0, 1)
+    st = ol.oracle().orc_rng_seed(seed)
+    traj = [joint_score(m) / n]
+    for s in range(sweeps):
+        if batch == 0:
+            st = m.gibbs_sequential(0, n, st)
+        else:
+            for b in range(0, n, batch):
+                m.gibbs_batch(b, min(n, b + batch), st, s * n)
+        traj.append(joint_score(m) / n)
+    return np.array(traj), m.assign.copy()
+
+
+def sweeps_to_reach(traj, level):
+    return int(np.argmax(traj >= level)) if (traj >= level).any() else len(traj)
+
+
+def test_batch_chains_reach_the_sequential_plateau():
+    n, k = 20_000, 64
+    truth, osh, _, vals = workloads.planted(n, k)
+    start = (np.arange(n) % k).astype(np.uint32)
+    sweeps = 12
+    seq, seq_assign = run_chain(osh, vals, start, k, 0, sweeps)
+    ari_seq = workloads.adjusted_rand_index(truth, seq_assign)
+    assert ari_seq > 0.8                    # the chain does find the clusters
+    gain = seq[-1] - seq[0]
+    assert gain > 5.0                       # nats per row
+    level = seq[0] + 0.9 * gain
+    s_seq = sweeps_to_reach(seq, level)
+    for batch, lag in [(256, 1), (2048, 2)]:     # N/78, N/10
+        traj, assign = run_chain(osh, vals, start, k, batch, sweeps)
+        # the same plateau (chains settle in slightly different modes: the
+        # spread between two sequential chains with different seeds is the
+        # same 3 % of the gain)
+        assert abs(traj[-3:].mean() - seq[-3:].mean()) < 0.05 * gain, batch
+        assert workloads.adjusted_rand_index(truth, assign) > ari_seq - 0.08
+        # burn-in: at most `lag` sweeps behind the sequential chain
+        assert sweeps_to_reach(traj, level) <= s_seq + lag, batch
+
+
+def test_fully_synchronous_sweeps_still_converge():
+    """B = N: every row of a sweep is scored against the same snapshot.  Burn-in
+    is several sweeps slower; the plateau is the same."""
+    n, k = 20_000, 64
+    truth, osh, _, vals = workloads.planted(n, k)
+    start = (np.arange(n) % k).astype(np.uint32)
+    seq, _ = run_chain(osh, vals, start, k, 0, 12)
+    gain = seq[-1] - seq[0]
+    traj, assign = run_chain(osh, vals, start, k, n, 24)
+    assert abs(traj[-3:].mean() - seq[-3:].mean()) < 0.05 * gain
+    assert workloads.adjusted_rand_index(truth, assign) > 0.75

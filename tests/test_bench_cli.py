@@ -1,0 +1,75 @@
+"""bench.py's launcher contract: `--gpus N` starts N ranks itself, refuses to
+report an N-GPU number from fewer devices, and rejects a world size that
+disagrees with --gpus."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def run(args, env=None, timeout=600):
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, BENCH] + args, env=e, text=True,
+                          capture_output=True, timeout=timeout)
+
+
+def gpu_count():
+    import torch
+    return torch.cuda.device_count()
+
+
+def test_more_gpus_than_devices_is_refused():
+    ask = max(2, gpu_count() + 1)
+    r = run(["--gpus", str(ask), "--cpu-rows", "0"])
+    assert r.returncode != 0
+    assert "refusing" in r.stderr and "--gpus %d" % ask in r.stderr
+    assert r.stdout.strip() == ""          # no JSON line from a refused run
+
+
+def test_world_size_must_agree_with_gpus():
+    r = run(["--gpus", "2"], env={"WORLD_SIZE": "4", "RANK": "0",
+                                  "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=4" in r.stderr
+
+
+@pytest.mark.gpu
+def test_small_single_gpu_run_prints_one_json_line():
+    r = run(["--rows", "400000", "--batch", "100000", "--steps", "2",
+             "--warmup", "1", "--cpu-rows", "20000", "--other-batches",
+             "50000"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [x for x in r.stdout.splitlines() if x.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["unit"] == "row-updates/s"
+    assert out["value"] > 0 and out["cpu_baseline"]["value"] > 0
+    assert out["cpu_baseline"]["cores"] == 1
+    assert out["batch_variants"][0]["batch_rows"] == 50000
+    roof = out["roofline"]
+    assert roof["bound"] in ("valu", "hbm") and roof["avg_launch_ms"] > 0
+    if roof["frac"] is not None:
+        assert 0.0 < roof["frac"] <= 1.0
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(gpu_count() < 2, reason="needs two GPUs")
+def test_two_ranks_over_rccl():
+    """--gpus 2: two processes, one RCCL communicator of two ranks, the
+    library's own all-reduce per sub-sweep; plus the strong-scaling leg"""
+    r = run(["--gpus", "2", "--rows", "400000", "--batch", "100000",
+             "--steps", "2", "--warmup", "1", "--cpu-rows", "0",
+             "--other-batches", ""])
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([x for x in r.stdout.splitlines()
+                      if x.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["config"]["comm_ranks"] == 2
+    assert out["config"]["collectives"] == "library RCCL communicator"
+    assert out["strong_scaling"]["rows_total"] == 400000

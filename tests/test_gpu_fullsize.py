@@ -79,12 +79,16 @@ def recount_check(gpu, vals, config_kinds):
                                        [m for _, m in want], atol=1e-4)
 
 
-@pytest.mark.parametrize("config,dim,first,batch,kinds", [
-    ("dd", 256, 1_000_000, 1_000_000, ["cat"]),            # BASELINE configs[1]
-    ("gp_nich", None, 200_000, 1_000_000, ["count", "real"]),  # configs[2]
+@pytest.mark.parametrize("config,dim,first,batch,kinds,d", [
+    ("dd", 256, 1_000_000, 1_000_000, ["cat"], D),         # BASELINE configs[1]
+    ("gp_nich", None, 200_000, 1_000_000, ["count", "real"], D),  # configs[2]
+    # SURVEY 8d's variants of C2: Zipf(1.1) values; d = 0 (the CRP)
+    ("dd_zipf", 256, 300_000, 1_000_000, ["cat"], D),
+    ("dd", 256, 300_000, 1_000_000, ["cat"], 0.0),
 ])
-def test_full_size_sweep(config, dim, first, batch, kinds):
+def test_full_size_sweep(config, dim, first, batch, kinds, d):
     from distributions_amd import engine
+    D = d
     osh, gsh, vals, assign = workloads.make(config, N, K, dim=dim)
     orc = ol.OracleMixture(ALPHA, D, osh)
     orc.init_from_assignments(vals, assign, K, 1)
@@ -113,6 +117,115 @@ def test_full_size_sweep(config, dim, first, batch, kinds):
     again.sweep(first, N, batch, seed, draw_base=0)
     np.testing.assert_array_equal(again.assignments(), final)
     np.testing.assert_array_equal(again.counts(), gpu.counts())
+
+
+@pytest.mark.parametrize("batch", [1_000_000, 65_536])
+def test_steady_state_sub_sweep_at_full_size(batch):
+    """The state bench.py times: after a whole sweep at N = 10M / K = 1024 the
+    tiles of every batch range are sorted by group, each value's arg-max rows
+    have a tile of their own and totals start from the per-value running
+    sums.  The oracle adopts the GPU's state after sweep 1 (group order,
+    statistics, ids, assignments) and follows the first sub-sweep of sweep 2
+    bit for bit."""
+    from distributions_amd import engine
+    osh, gsh, vals, assign = workloads.make("dd", N, K, dim=256)
+    gpu = engine.Gibbs(ALPHA, D, gsh)
+    gpu.load_rows(vals, assign, K, 1)
+    seed = 20240601
+    st = ol.oracle().orc_rng_seed(seed)
+    gpu.sweep(0, N, batch, seed, draw_base=0)
+    assert gpu.counts().sum() == N
+    orc = ol.OracleMixture(ALPHA, D, osh)
+    orc.adopt(gpu, vals)
+    assert_same_state(orc, gpu, "adopted state")
+    before = gpu.core.debug_counts()
+
+    orc.gibbs_batch(0, batch, st, N)
+    gpu.sweep(0, batch, batch, seed, draw_base=N)
+    after = gpu.core.debug_counts()
+    assert after["value_sorted_batches"] == before["value_sorted_batches"] + 1
+    assert after["other_batches"] == before["other_batches"] == 0
+    if batch >= 1_000_000:
+        # the launch is large enough for both devices, and the group-sorted
+        # range lets (nearly) every value give its arg-max rows their tile
+        assert after["band_launches"] == before["band_launches"] + 1
+        assert after["running_sum_launches"] == before["running_sum_launches"] + 1
+        assert after["band_values_last"] >= 200
+    assert_same_state(orc, gpu, "sweep 2, first sub-sweep of %d" % batch)
+
+    # and the second sub-sweep of sweep 2 (the caches of a range sampled a
+    # moment ago next to one that was not)
+    orc.gibbs_batch(batch, 2 * batch, st, N)
+    gpu.sweep(batch, 2 * batch, batch, seed, draw_base=N)
+    assert_same_state(orc, gpu, "sweep 2, second sub-sweep of %d" % batch)
+
+
+def test_c1_dd16_k64_n100k():
+    """BASELINE configs[0] (benchmarks/mixture.cc's model at its CPU size):
+    DirichletDiscrete(dim=16), K = 64, N = 100 000 -- frozen sub-sweeps of
+    4096 / 65 536 / N rows and then the reference's sequential chain over the
+    whole table, each followed by the oracle bit for bit."""
+    from distributions_amd import engine
+    n, k, dim = 100_000, 64, 16
+    osh, gsh, vals, assign = workloads.make("dd", n, k, dim=dim)
+    orc = ol.OracleMixture(ALPHA, 0.0, osh)       # SURVEY 8d: CRP for C1/C2
+    orc.init_from_assignments(vals, assign, k, 1)
+    gpu = engine.Gibbs(ALPHA, 0.0, gsh)
+    gpu.load_rows(vals, assign, k, 1)
+    seed = 20240601
+    st = ol.oracle().orc_rng_seed(seed)
+    sweep = 0
+    for batch in (4096, 65_536, n):
+        for b in range(0, n, batch):
+            orc.gibbs_batch(b, min(n, b + batch), st, sweep * n)
+        gpu.sweep(0, n, batch, seed, draw_base=sweep * n)
+        assert_same_state(orc, gpu, "C1 batch %d" % batch)
+        sweep += 1
+    state = orc.gibbs_sequential(0, n, st)
+    assert gpu.sweep_sequential(0, n, st) == state
+    assert_same_state(orc, gpu, "C1 sequential sweep")
+
+
+def test_c5_full_size_dpd_10m_rows():
+    """BASELINE configs[4] at its full size: DirichletProcessDiscrete over
+    V = 10 000 values, K = 8192 groups, N = 10M rows, bench.py's
+    PitmanYor(1, 0.2).  The oracle (12 k row-updates/s at this K) follows one
+    sub-sweep of 20 000 rows bit for bit; the rest of the sweep runs in
+    sub-sweeps of 10^6 rows and is checked through the recount properties."""
+    from distributions_amd import engine
+    k, dim, first = 8192, 10_000, 20_000
+    osh, gsh, vals, assign = workloads.make("dpd", N, k, dim=dim)
+    orc = ol.OracleMixture(ALPHA, D, osh)
+    orc.init_from_assignments(vals, assign, k, 1)
+    gpu = engine.Gibbs(ALPHA, D, gsh)
+    gpu.load_rows(vals, assign, k, 1)
+    seed = 99
+    st = ol.oracle().orc_rng_seed(seed)
+    orc.gibbs_batch(0, first, st, 0)
+    gpu.sweep(0, first, first, seed, draw_base=0)
+    assert len(gpu) == len(orc)
+    np.testing.assert_array_equal(gpu.counts(), orc.counts())
+    np.testing.assert_array_equal(gpu.assignments(), orc.assign)
+    for g in range(0, len(orc), 97):      # (a group is 10 001 words)
+        np.testing.assert_array_equal(gpu.get_group(0, g),
+                                      orc.get_group(0, g))
+    del orc
+    gpu.sweep(first, N, 1_000_000, seed, draw_base=0)
+    assert gpu.path_counts()[1] == 0      # every batch value-sorted
+    final = gpu.assignments()
+    counts = gpu.counts()
+    assert counts.sum() == N and counts.shape[0] == len(gpu)
+    ids, sizes = np.unique(final, return_counts=True)
+    assert ids.size == np.count_nonzero(counts)
+    assert sorted(sizes.tolist()) == sorted(counts[counts > 0].tolist())
+    # per group: its statistics are the recount of its rows' values
+    slot_of = {int(gpu.core.packed_to_global(s)): s for s in range(len(gpu))}
+    for gid in ids[::257]:
+        w = gpu.get_group(0, slot_of[int(gid)]).astype(np.int64)
+        want = np.bincount(vals[0][final == gid], minlength=dim)
+        assert w[0] == want.sum()
+        np.testing.assert_array_equal(w[1:1 + dim], want)
+    assert np.count_nonzero(final != assign) > N // 2
 
 
 def test_c5_shape_dpd_8192_groups_streamed_tables():

@@ -536,3 +536,53 @@ def test_low_entropy_model_and_mixture():
                 if groupid < len(counts):
                     counts[groupid] = back
             check(counts)
+
+
+def test_c1_benchmark_loop_dd16_k64():
+    """benchmarks/mixture.cc:79-115 at BASELINE configs[0] (DirichletDiscrete
+    dim = 16, K = 64), through distributions_amd.lp: groups filled with 4 * K
+    values, then the timed loop's body -- remove the value from its group,
+    score_value ACCUMULATING into a vector that is zeroed every 8 iterations
+    (mixture.cc:104-113), add it back -- with the accumulated scores compared
+    with the oracle's MixtureSlave bit for bit at every iteration."""
+    from distributions_amd.lp.models import dd
+    L = ol.oracle()
+    K, dim, iters = 64, 16, 4096
+    rng = np.random.default_rng(20240601)
+    shared = dd.Shared.from_dict({"alphas": [0.5] * dim})
+    values = rng.integers(0, dim, 4 * K).tolist()        # mixture.cc:93-100
+    assignments = rng.integers(0, K, 4 * K).tolist()
+    mixture = dd.Mixture()
+    members = [[] for _ in range(K)]
+    for v, g in zip(values, assignments):
+        members[g].append(v)
+    for g in range(K):
+        mixture.append(dd.Group.from_values(shared, members[g]))
+    mixture.init(shared)
+
+    orc = ol.OracleMixture(1.0, 0.0, [ol.make_shared(ol.DD,
+                                                     alphas=[0.5] * dim)])
+    for g in range(K):
+        L.orc_mix_slave_append_empty(orc.h, 0)
+        for v in members[g]:
+            L.orc_mix_slave_group_add_value(orc.h, 0, g, v)
+    L.orc_mix_slave_init(orc.h, 0)
+
+    scores = np.zeros(K, np.float32)
+    want = np.zeros(K, np.float32)
+    for i in range(iters):
+        if i % 8 == 0:                                   # vector_zero
+            scores[:] = 0
+            want[:] = 0
+        k = i % len(values)
+        value, groupid = values[k], assignments[k]
+        mixture.remove_value(shared, groupid, value)
+        L.orc_mix_slave_remove_value(orc.h, 0, groupid, value)
+        mixture.score_value(shared, value, scores)       # accumulates
+        L.orc_mix_slave_score_value(orc.h, 0, value, want)
+        mixture.add_value(shared, groupid, value)
+        L.orc_mix_slave_add_value(orc.h, 0, groupid, value)
+        assert np.array_equal(bits(scores), bits(want)), (i, scores, want)
+    for g in range(K):
+        assert mixture[g].dump() == dd.Group.from_values(
+            shared, members[g]).dump()

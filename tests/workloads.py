@@ -17,6 +17,14 @@ def make(config, n, k, seed=SEED, dim=None):
         vals = [rng.integers(0, dim, n).astype(np.uint32)]
         osh = [ol.make_shared(ol.DD, alphas=[0.5] * dim)]
         gsh = [engine.dd_shared([0.5] * dim)]
+    elif config == "dd_zipf":
+        # SURVEY 8d's skewed variant of C2: Zipf(s = 1.1) values, the same
+        # symmetric prior
+        dim = dim or 256
+        p = 1.0 / np.arange(1, dim + 1) ** 1.1
+        vals = [rng.choice(dim, n, p=p / p.sum()).astype(np.uint32)]
+        osh = [ol.make_shared(ol.DD, alphas=[0.5] * dim)]
+        gsh = [engine.dd_shared([0.5] * dim)]
     elif config == "dd_skew":
         dim = dim or 16
         p = 1.0 / np.arange(1, dim + 1) ** 1.1
@@ -76,3 +84,43 @@ def make(config, n, k, seed=SEED, dim=None):
     else:
         raise ValueError(config)
     return osh, gsh, vals, assign
+
+
+def planted(n, k_true=64, seed=1, n_cat=4, dim=16, n_real=2):
+    """A planted mixture (rows that DO have structure, unlike the bench's
+    noise): k_true clusters, each with its own peaked categorical law for
+    n_cat DirichletDiscrete(dim) features and its own mean for n_real
+    NormalInverseChiSq features.
+    -> (truth[n], oracle shareds, engine shareds, values per feature)"""
+    rng = np.random.default_rng(seed)
+    z = rng.integers(0, k_true, n)
+    vals, osh, gsh = [], [], []
+    for _ in range(n_cat):
+        theta = rng.dirichlet([0.1] * dim, k_true)
+        cdf = np.cumsum(theta, 1)
+        u = rng.random(n)
+        x = (u[:, None] > cdf[z]).sum(1).clip(max=dim - 1).astype(np.uint32)
+        vals.append(x)
+        osh.append(ol.make_shared(ol.DD, alphas=[0.5] * dim))
+        gsh.append(engine.dd_shared([0.5] * dim))
+    for _ in range(n_real):
+        mu = rng.normal(0, 4, k_true)
+        x = (mu[z] + rng.normal(0, 0.5, n)).astype(np.float32)
+        vals.append(x)
+        osh.append(ol.make_shared(ol.NICH, mu=0.0, kappa=0.1, sigmasq=1.0,
+                                  nu=1.0))
+        gsh.append(engine.nich_shared(0.0, 0.1, 1.0, 1.0))
+    return z, osh, gsh, vals
+
+
+def adjusted_rand_index(a, b):
+    ua, ia = np.unique(a, return_inverse=True)
+    ub, ib = np.unique(b, return_inverse=True)
+    c = np.zeros((ua.size, ub.size), np.int64)
+    np.add.at(c, (ia, ib), 1)
+
+    def pairs(x):
+        return x * (x - 1) / 2.0
+    s, sa, sb = pairs(c).sum(), pairs(c.sum(1)).sum(), pairs(c.sum(0)).sum()
+    e = sa * sb / pairs(a.size)
+    return float((s - e) / (0.5 * (sa + sb) - e))

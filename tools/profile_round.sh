@@ -1,31 +1,44 @@
 #!/bin/bash
-# The round's evidence, on the GPU box: tools/profile_round.sh <out-dir under gpurun_out>
-# (kernel trace + stats, FETCH_SIZE / WRITE_SIZE in separate passes, the bench
-# line of record with the CPU baseline, the other configurations)
+# The round's evidence, on the GPU box: tools/profile_round.sh <tag>
+# writes gpurun_out/<tag>/ (copy what is to be judged into profiles/):
+#   kernel trace + stats of the bench command, the SQ / FETCH_SIZE / WRITE_SIZE
+#   counter passes (each its own run, --kernel-trace only beside --pmc),
+#   counters.json (tools/counters.py), the bench line with the CPU baseline
 set -u
-out=gpurun_out/$1
+tag=$1
+out=gpurun_out/$tag
 mkdir -p $out
 repo=$PWD
 cd /tmp && export TMPDIR=/tmp && cd $repo
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py --cpu-rows 0 > $out/bench_under_rocprof.json 2> $out/trace.log
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/fetch -- python3 bench.py --steps 2 --warmup 1 --cpu-rows 0 > /dev/null 2> $out/fetch.log
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/write -- python3 bench.py --steps 2 --warmup 1 --cpu-rows 0 > /dev/null 2> $out/write.log
+B="bench.py --cpu-rows 0 --other-batches="
+SQ="SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY"
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $B > $out/bench_under_rocprof.json 2> $out/trace.log
 cp $(ls $out/trace/*/*kernel_stats.csv | head -1) $out/kernel_stats.csv
-python tools/pmc_means.py $out/fetch FETCH_SIZE > $out/pmc_fetch_size.csv
-python tools/pmc_means.py $out/write WRITE_SIZE > $out/pmc_write_size.csv
-rm -rf $out/trace $out/fetch $out/write
-python bench.py 2> $out/bench.log | tail -1 > $out/bench.json
-: > $out/bench_other_configs.jsonl
-# (3 timed sweeps after 1: on pure-noise reals the groups of the NormalInverseChiSq
-# configurations merge sweep by sweep, and the per-group ordered replay of a
-# group of 10^6 rows is one dependent chain -- the numbers are for K ~ 1024)
-for c in gp_nich nich gp bb mixed; do
-  python bench.py --cpu-rows 0 --steps 3 --warmup 1 --config $c 2>/dev/null | tail -1 >> $out/bench_other_configs.jsonl
+rocprofv3 --pmc $SQ --kernel-trace --output-format csv -d $out/sq -- python3 $B --steps 3 --warmup 2 > /dev/null 2> $out/sq.log
+rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $out/grbm -- python3 $B --steps 3 --warmup 2 > /dev/null 2> $out/grbm.log
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/fetch -- python3 $B --steps 3 --warmup 2 > /dev/null 2> $out/fetch.log
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/write -- python3 $B --steps 3 --warmup 2 > /dev/null 2> $out/write.log
+# C5 (the HBM-bound configuration) and C3 (the general-row kernel)
+C5="--config dpd --groups 8192 --dim 10000 --steps 3 --warmup 2"
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/c5 -- python3 $B $C5 > $out/bench_c5_under_rocprof.json 2>/dev/null
+cp $(ls $out/c5/*/*kernel_stats.csv | head -1) $out/kernel_stats_c5_dpd.csv
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/c5f -- python3 $B $C5 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/c5w -- python3 $B $C5 > /dev/null 2>&1
+rocprofv3 --pmc $SQ --kernel-trace --output-format csv -d $out/c5s -- python3 $B $C5 > /dev/null 2>&1
+C3="--config gp_nich --steps 3 --warmup 1"
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/c3 -- python3 $B $C3 > $out/bench_c3_under_rocprof.json 2>/dev/null
+cp $(ls $out/c3/*/*kernel_stats.csv | head -1) $out/kernel_stats_c3_gp_nich.csv
+rocprofv3 --pmc $SQ --kernel-trace --output-format csv -d $out/c3s -- python3 $B $C3 > /dev/null 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/c3f -- python3 $B $C3 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/c3w -- python3 $B $C3 > /dev/null 2>&1
+python3 tools/counters.py $out/counters.json \
+    "k_vs_sample<dd>=k_vs_sample<0>:1000000:100000" \
+    "k_vs_sample<dpd>=k_vs_sample<4>:1000000:100000" \
+    "k_vs_prepare<dpd>=k_vs_prepare<4>:1000000:0" \
+    "k_sweep_sample<gp_nich>=k_sweep_sample<2, 3, 2>:1000000:100000" \
+    -- $out/sq $out/grbm $out/fetch $out/write $out/c5f $out/c5w $out/c5s $out/c3s $out/c3f $out/c3w > $out/counters.log 2>&1
+for d in sq grbm fetch write c5f c5w c5s c3s c3f c3w; do
+  python3 tools/pmc_summary.py $out/$d k_ > $out/pmc_$d.txt 2>/dev/null
 done
-python bench.py --cpu-rows 0 --steps 3 --warmup 2 --config dpd --groups 8192 --dim 10000 2>/dev/null | tail -1 >> $out/bench_other_configs.jsonl
-python bench.py --cpu-rows 0 --force-collective 2>/dev/null | tail -1 > $out/bench_collective_one_rank.json
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/c3 -- python3 bench.py --cpu-rows 0 --steps 3 --warmup 1 --config gp_nich > /dev/null 2>&1
-cp $(ls $out/c3/*/*kernel_stats.csv | head -1) $out/kernel_stats_c3_gp_nich.csv; rm -rf $out/c3
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/c5 -- python3 bench.py --cpu-rows 0 --steps 3 --warmup 2 --config dpd --groups 8192 --dim 10000 > /dev/null 2>&1
-cp $(ls $out/c5/*/*kernel_stats.csv | head -1) $out/kernel_stats_c5_dpd.csv; rm -rf $out/c5
+rm -rf $out/trace $out/sq $out/grbm $out/fetch $out/write $out/c5 $out/c5f $out/c5w $out/c5s $out/c3 $out/c3s $out/c3f $out/c3w
 ls -la $out
