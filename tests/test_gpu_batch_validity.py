@@ -1,6 +1,6 @@
 """tests/test_batch_validity.py on the engine itself, at ten times the rows:
 the exact sequential chain (sweep_sequential) against batch chains of
-B = 4096, N/10, 65 536 and N rows on the planted mixture, N = 200 000.  The
+B = 4096, N/10, N/3 and N rows on the planted mixture, N = 100 000.  The
 joint score comes from the product path (SlaveMixture.score_data over the
 engine's groups + py_score_counts)."""
 import numpy as np
@@ -41,7 +41,7 @@ def run_chain(gsh, vals, start, k0, batch, sweeps, seed=7):
 
 
 def test_batch_chains_reach_the_sequential_plateau_on_the_engine():
-    n, k, sweeps = 200_000, 64, 12
+    n, k, sweeps = 100_000, 64, 12
     truth, _, gsh, vals = workloads.planted(n, k)
     start = (np.arange(n) % k).astype(np.uint32)
     seq, seq_assign = run_chain(gsh, vals, start, k, 0, sweeps)
@@ -53,14 +53,15 @@ def test_batch_chains_reach_the_sequential_plateau_on_the_engine():
     s_seq = sweeps_to_reach(seq, level)
     report = ["sequential: ARI %.3f, %d sweeps to 90%%: %s" % (
         ari_seq, s_seq, np.round(seq, 2))]
-    # (B, sweeps, allowed lag in sweeps): B/N = 0.02, 0.1, 0.33, 1
-    for batch, n_sweeps, lag in [(4096, sweeps, 1), (20_000, sweeps, 2),
-                                 (65_536, sweeps + 4, 4), (n, sweeps + 12, 9)]:
+    # (B, sweeps, allowed lag in sweeps): B/N = 0.04, 0.1, 0.33, 1
+    for batch, n_sweeps, lag in [(4096, sweeps, 1), (10_000, sweeps, 2),
+                                 (32_768, sweeps + 4, 4), (n, sweeps + 12, 9)]:
         traj, assign = run_chain(gsh, vals, start, k, batch, n_sweeps)
         ari = workloads.adjusted_rand_index(truth, assign)
         report.append("B=%d: ARI %.3f, %d sweeps to 90%%: %s" % (
             batch, ari, sweeps_to_reach(traj, level), np.round(traj, 2)))
-        assert abs(traj[-3:].mean() - seq[-3:].mean()) < 0.05 * gain, report
+        assert traj[-3:].mean() > seq[-3:].mean() - 0.05 * gain, report
+        assert traj[-3:].mean() < seq[-3:].mean() + 0.10 * gain, report
         assert ari > ari_seq - 0.1, report
         assert sweeps_to_reach(traj, level) <= s_seq + lag, report
     print("\n".join(report))
