@@ -74,6 +74,9 @@ def parse():
                          "(SURVEY 8d's skewed variant of C2)")
     ap.add_argument("--value-sorted", type=int, default=1,
                     help="0 generic kernel only, 1 auto, 2 force")
+    ap.add_argument("--value-stream", type=int, default=1,
+                    help="the table-free value-sorted kernel: 0 never, "
+                         "1 auto, 2 always")
     ap.add_argument("--other-batches", default="65536",
                     help="comma-separated sub-sweep sizes timed besides "
                          "--batch (a few steps each, reported in "
@@ -387,6 +390,7 @@ def run_rank(args):
             args, torch, engine, dev, gen, n, k)
         g = engine.Gibbs(args.alpha, args.d, shareds)
         g.set_option("value_sorted", args.value_sorted)
+        g.set_option("value_stream", args.value_stream)
         initial = assign.clone()   # the engine updates `assign` in place
         g.load_rows_torch(columns, assign, k, 1, row_offset=row_offset)
         sharded = engine.ShardedGibbs(
@@ -434,6 +438,7 @@ def run_rank(args):
     dt = timed(sharded, g, n, args.batch, args.steps, args.warmup, 0)
     ms, launches, rows = g.kernel_stats()
     vs_batches, generic_batches = g.path_counts()
+    streamed = g.core.debug_counts()["stream_batches"]
     draws = args.warmup + args.steps
 
     # the same job at other sub-sweep sizes (value depends on it: the
@@ -470,7 +475,9 @@ def run_rank(args):
                   "steps": steps_s, "ms_per_step": 1e3 * dt_s / steps_s}
 
     total_rows = float(n) * world * args.steps
-    if vs_batches:
+    if vs_batches and streamed:
+        kernel = "k_vs_stream<%s>" % args.config
+    elif vs_batches:
         kernel = "k_vs_sample<%s>" % args.config
     elif args.config == "mixed":
         kernel = "k_sweep_program"

@@ -821,10 +821,12 @@ struct Gibbs {
         uint32_t n_tiles = 0;
         DeviceBuf<VsTile> chunks;          // apply work items, one value each
         uint32_t n_chunks = 0;
-        bool one_chunk_per_value = false;
+        bool one_chunk_per_value = false;  // every value's rows in ONE chunk
+        bool mixed_chunks = false;         // some chunks hold several values
         DeviceBuf<uint32_t> val_start;    // [nvals + 1] first position per value
         DeviceBuf<uint32_t> other_pos;    // positions the tiles do not cover
         uint32_t n_other = 0;
+        uint32_t n_values_present = 0;    // values with at least one row
         // the rows' current assignment (global ids) in sorted-position
         // order; while `dirty`, assign[] (row order) is stale for this range
         DeviceBuf<uint32_t> assign_pos;
@@ -871,6 +873,10 @@ struct Gibbs {
     DeviceBuf<int> vsArg;
     DeviceBuf<uint32_t> deferred, deferred_count;
     int value_sorted_mode = 1;   // 0 off, 1 auto, 2 always (when eligible)
+    // the table-free form of the value-sorted kernel (k_vs_stream): 0 never,
+    // 1 where a value has about a tile per batch, 2 always
+    int value_stream_mode = 1;
+    uint64_t stream_batches = 0;
     int running_sums_min_tiles = 2048;   // see sample_value_sorted
     int cu_count_cached = 0;
     int cu_count() {
@@ -1385,16 +1391,36 @@ struct Gibbs {
                                                           h[x] - off)});
         c->n_tiles = (uint32_t)tiles.size();
         c->tiles.upload(tiles.data(), tiles.size());
+        for (uint32_t x = 0; x < nv; ++x) c->n_values_present += h[x] != 0;
+        // apply work items: up to kVsApplyRows rows of one value -- or, where
+        // values have few rows each (the table-free kernel's case) and the
+        // kind is categorical, of several WHOLE values (k_vs_apply_mixed)
         std::vector<VsTile> chunks;
-        for (uint32_t x = 0; x <= nv; ++x)
+        const bool pack = is_cat(feats[0]->sh.kind) && use_stream(*c);
+        bool open = false;   // the last chunk can still take whole values
+        for (uint32_t x = 0; x <= nv; ++x) {
+            if (pack && x < nv && h[x] && h[x] <= (uint32_t)kVsApplyRows / 2) {
+                if (open && chunks.back().n + h[x] <= (uint32_t)kVsApplyRows) {
+                    chunks.back().x = kVsMixedChunk;
+                    chunks.back().n += h[x];
+                } else {
+                    chunks.push_back(VsTile{x, start[x], h[x]});
+                    open = true;
+                }
+                continue;
+            }
             for (uint32_t off = 0; off < h[x]; off += kVsApplyRows)
                 chunks.push_back(VsTile{x, start[x] + off,
                                         std::min<uint32_t>(kVsApplyRows,
                                                            h[x] - off)});
+            if (h[x]) open = false;
+        }
         c->n_chunks = (uint32_t)chunks.size();
         c->one_chunk_per_value = true;
+        c->mixed_chunks = false;
         for (uint32_t x = 0; x <= nv; ++x)
             if (h[x] > (uint32_t)kVsApplyRows) c->one_chunk_per_value = false;
+        for (auto & ch : chunks) c->mixed_chunks |= ch.x == kVsMixedChunk;
         c->chunks.upload(chunks.data(), chunks.size());
         // rows whose value is outside the table: generic kernel, by position
         c->n_other = h[nv];
@@ -1455,8 +1481,74 @@ struct Gibbs {
         }
     };
 
+    // Tables (k_vs_prepare) pay when several tiles share a value's vector;
+    // with a tile or so per value the tile builds the vector itself.
+    bool use_stream(const VsCache & c) const {
+        if (value_stream_mode == 0) return false;
+        if (value_stream_mode == 2) return true;
+        return (size_t)c.n_tiles * 2 <= (size_t)c.n_values_present * 3;
+    }
+    struct VsStreamLaunch {
+        Gibbs * self;
+        SweepParams * P;
+        VsCache * c;
+        template <int KIND>
+        void go() {
+            const uint32_t per = kVsStreamBlock / 64;
+            hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, stream(),
+                               self->deferred_count.p, c->n_other);
+            HIP_CHECK(hipEventRecord(self->ev0, stream()));
+            if (c->n_tiles)
+                hipLaunchKernelGGL((k_vs_stream<KIND>),
+                                   dim3((c->n_tiles + per - 1) / per),
+                                   dim3(kVsStreamBlock), 0, stream(), *P,
+                                   c->tiles.p, c->n_tiles, c->sorted_rows.p,
+                                   self->deferred.p, self->deferred_count.p);
+            HIP_CHECK(hipGetLastError());
+            HIP_CHECK(hipEventRecord(self->ev1, stream()));
+        }
+    };
+    void sample_value_stream(SweepParams & P, VsCache & c) {
+        const size_t n = P.row_end - P.row_begin;
+        deferred.reserve(std::max<size_t>(n, 1), 0);
+        deferred_count.reserve(1, 0);
+        prepare(P, false);
+        if (c.n_other)
+            HIP_CHECK(hipMemcpyAsync(deferred.p, c.other_pos.p,
+                                     4 * (size_t)c.n_other,
+                                     hipMemcpyDeviceToDevice, stream()));
+        P.sorted_rows = c.sorted_rows.p;
+        P.assign_pos = c.assign_pos.p;
+        last_bands = last_prefix = false;
+        stream_batches += 1;
+        VsStreamLaunch L{this, &P, &c};
+        switch (feats[0]->sh.kind) {
+        case DIST_DD: L.go<DIST_DD>(); break;
+        case DIST_DPD: L.go<DIST_DPD>(); break;
+        case DIST_GP: L.go<DIST_GP>(); break;
+        case DIST_BNB: L.go<DIST_BNB>(); break;
+        default: L.go<DIST_BB>(); break;
+        }
+        launch_deferred(P);
+    }
+    // the handed-over rows, by the wave-per-row kernel (or, when its strip of
+    // LDS cannot hold K entries, the lane-per-row kernel) in list mode
+    void launch_deferred(SweepParams & P) {
+        SweepParams Q = P;
+        Q.row_list = deferred.p;
+        Q.row_list_count = deferred_count.p;
+        if (wave_rows_fit()) {
+            WaveRowsLaunch D{&Q, K(), 256};
+            dispatch(D);
+        } else {
+            DeferredLaunch D{&Q};
+            dispatch(D);
+        }
+    }
+
     void sample_value_sorted(SweepParams & P) {
         VsCache & c = vs_get(P.row_begin, P.row_end);
+        if (use_stream(c)) return sample_value_stream(P, c);
         const size_t n = P.row_end - P.row_begin;
         const uint32_t nv = (uint32_t)vs_nvals();
         const int Kpad = (K() + kVsUnroll - 1) / kVsUnroll * kVsUnroll;
@@ -1519,17 +1611,7 @@ struct Gibbs {
         case DIST_BNB: L.go<DIST_BNB>(); break;
         default: L.go<DIST_BB>(); break;
         }
-        // the handed-over rows, by the generic kernel in list mode
-        SweepParams Q = P;
-        Q.row_list = deferred.p;
-        Q.row_list_count = deferred_count.p;
-        if (wave_rows_fit()) {
-            WaveRowsLaunch D{&Q, K(), 256};
-            dispatch(D);
-        } else {
-            DeferredLaunch D{&Q};
-            dispatch(D);
-        }
+        launch_deferred(P);
     }
     struct DeferredLaunch {
         SweepParams * P;
@@ -1783,6 +1865,28 @@ struct Gibbs {
                                        (uint32_t)vs_nvals(), pairs,          \
                                        pairs_seq);                           \
             } while (0)
+            // chunks of several values first (their rows of the staging
+            // matrix must be there when k_vs_reduce runs)
+            if (c.mixed_chunks) {   // (categorical kinds only, see vs_get)
+                const size_t lds = lds_plain;
+                auto mixed = feats[0]->sh.kind == DIST_DPD
+                                 ? &k_vs_apply_mixed<DIST_DPD>
+                                 : &k_vs_apply_mixed<DIST_DD>;
+                static std::atomic<size_t> opted_in[2][64];
+                std::atomic<size_t> & have =
+                    opted_in[feats[0]->sh.kind == DIST_DPD][apply_device & 63];
+                if (lds > 64 * 1024
+                    && lds > have.load(std::memory_order_relaxed)) {
+                    HIP_CHECK(hipFuncSetAttribute(
+                        reinterpret_cast<const void *>(mixed),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    have.store(lds, std::memory_order_relaxed);
+                }
+                hipLaunchKernelGGL(mixed, grid, block, lds, stream(), P, img,
+                                   c.chunks.p, c.sorted_rows.p, d_p2g_ptr,
+                                   c.assign_pos.p, refresh, stage);
+                HIP_CHECK(hipGetLastError());
+            }
             if (bb && sort) VS_APPLY(DIST_BB, true, lds_sort);
             else if (bb) VS_APPLY(DIST_BB, false, lds_plain);
             else if (gp && sort) VS_APPLY(DIST_GP, true, lds_sort);
@@ -3023,6 +3127,10 @@ int dist_gibbs_set_option(dist_gibbs_t * g, const char * name, int value) {
         if (key == "value_sorted") {
             DIST_REQUIRE(value >= 0 && value <= 2, "value_sorted: 0, 1 or 2");
             g->impl->value_sorted_mode = value;
+        } else if (key == "value_stream") {
+            // the table-free value-sorted kernel: 0 never, 1 auto, 2 always
+            DIST_REQUIRE(value >= 0 && value <= 2, "value_stream: 0, 1 or 2");
+            g->impl->value_stream_mode = value;
         } else if (key == "running_sums_min_tiles") {
             // launches of at least this many value tiles start each tile's
             // total from the per-value running sums (a tuning knob: results
@@ -3049,8 +3157,8 @@ int dist_gibbs_path_counts(const dist_gibbs_t * g, uint64_t * value_sorted,
 int dist_gibbs_debug_counts(dist_gibbs_t * g, uint64_t * out, size_t n) {
     return guarded([&] {
         Gibbs & e = *g->impl;
-        uint64_t v[6] = {e.vs_batches, e.generic_batches, e.band_batches,
-                         e.prefix_batches, 0, 0};
+        uint64_t v[7] = {e.vs_batches, e.generic_batches, e.band_batches,
+                         e.prefix_batches, 0, 0, e.stream_batches};
         if (e.last_bands && !e.batch_open && e.vsBandMode.p) {
             // values whose arg-max group's rows had a tile of their own in
             // the last value-sorted launch
@@ -3063,7 +3171,7 @@ int dist_gibbs_debug_counts(dist_gibbs_t * g, uint64_t * out, size_t n) {
             e.deferred_count.download(&d, 1);
             v[5] = d;
         }
-        for (size_t i = 0; i < n && i < 6; ++i) out[i] = v[i];
+        for (size_t i = 0; i < n && i < 7; ++i) out[i] = v[i];
     });
 }
 int dist_gibbs_kernel_stats(dist_gibbs_t * g, double * ms_out,

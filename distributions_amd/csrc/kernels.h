@@ -1944,6 +1944,267 @@ void k_vs_sample(
     }
 }
 
+// ---------------------------------------------------------------------------
+// The value-sorted row update WITHOUT per-value tables (k_vs_stream).
+//
+// The tables of k_vs_prepare pay when many tiles share a value's likelihood
+// vector.  Where a value has a tile or two per batch (C5: V = 10 000 values,
+// K = 8192 groups, 100 rows per value and sub-sweep -- the 2 x 328 MB of LA /
+// LB would be written to HBM and read back exactly once each) one wave per
+// tile builds the vector itself: scores and (max, arg-max, second max) in a
+// first pass over the value's cache row S[x][.] (the only HBM stream), then
+// per pass of the two recurrences the exponentials of kVsStreamChunk entries
+// at a time into the wave's strip of LDS, consumed from there by uniform
+// ds_read_b128 exactly as vs_sum_and_scan consumes its scalar loads (same
+// float operations in the same order: bit-identical to k_vs_sample).  Rows of
+// the arg-max group (shift mB instead of M) take a second round of the same
+// loop; rows the shortcut does not cover are handed over as before.
+constexpr int kVsStreamChunk = 512;
+constexpr int kVsStreamBlock = 256;
+
+__global__ void k_set_u32(uint32_t * p, uint32_t value) { *p = value; }
+
+template <int KIND>
+__device__ __forceinline__ float vs_stream_score(const SweepParams & P,
+                                                 const SlaveView & v, int k,
+                                                 uint32_t x, float lf) {
+    return accumulate(KIND, P.base[k], load_entry(v, k, x), x, lf, v.p);
+}
+
+template <int KIND>
+__global__ __launch_bounds__(kVsStreamBlock) void k_vs_stream(
+        SweepParams P, const VsTile * __restrict__ tiles, uint32_t n_tiles,
+        const uint32_t * __restrict__ sorted_rows,
+        uint32_t * __restrict__ deferred, uint32_t * deferred_count) {
+    __shared__ uint32_t s_exp[1024];
+    __shared__ float s_strip[kVsStreamBlock / 64][kVsStreamChunk];
+    for (int i = threadIdx.x; i < 1024; i += kVsStreamBlock)
+        s_exp[i] = g_tables_dev.exp_table[i];
+    __syncthreads();
+    const float ea = u2f(g_tables_dev.exp_ab[0]);
+    const float eb = u2f(g_tables_dev.exp_ab[1]);
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    float * strip = s_strip[wave];
+    const uint32_t id = __builtin_amdgcn_readfirstlane(
+        blockIdx.x * (kVsStreamBlock / 64) + wave);
+    if (id >= n_tiles) return;
+    const uint32_t x = __builtin_amdgcn_readfirstlane(tiles[id].x);
+    const uint32_t pos = __builtin_amdgcn_readfirstlane(tiles[id].pos);
+    const uint32_t n = __builtin_amdgcn_readfirstlane(tiles[id].n);
+    if (n == 0) return;
+    SlaveView v = P.feat[0];
+    v.kind = KIND;
+    const int K = P.K;
+    const float shift = P.scalars->shift;
+    const float lf = KIND == DIST_GP ? fast_log_factorial(x) : 0.f;
+
+    // pass 0: (max, first arg-max, max of the rest) of the value's scores
+    float m1 = -INFINITY, m2 = -INFINITY;
+    int i1 = 0x7fffffff;
+    for (int k = lane; k < K; k += 64) {
+        const float s = vs_stream_score<KIND>(P, v, k, x, lf);
+        if (s > m1) { m2 = m1; m1 = s; i1 = k; }
+        else if (s > m2) m2 = s;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float b1 = __shfl_xor(m1, off), b2 = __shfl_xor(m2, off);
+        const int bi = __shfl_xor(i1, off);
+        if (m1 > b1 || (m1 == b1 && i1 < bi)) {
+            m2 = fmaxf(m2, b1);
+        } else {
+            m2 = fmaxf(b2, m1);
+            m1 = b1;
+            i1 = bi;
+        }
+    }
+    const float M = m1, M2 = m2;
+    const int amax = i1;
+
+    bool valid[kVsR], classB[kVsR];
+    size_t row[kVsR];
+    int g[kVsR], g2[kVsR];
+    float l_own[kVsR], u[kVsR], m_row[kVsR];
+#pragma unroll
+    for (int r = 0; r < kVsR; ++r) {
+        valid[r] = (uint32_t)(kVsR * lane + r) < n;
+        row[r] = 0;
+        g[r] = -1;
+        g2[r] = 0;
+        l_own[r] = 0.f;
+        u[r] = 0.f;
+        m_row[r] = M;
+        classB[r] = false;
+        if (valid[r]) {
+            const uint32_t at = pos + kVsR * lane + r;
+            row[r] = P.row_begin + sorted_rows[at];
+            g[r] = P.g2p[P.assign_pos[at]];
+            classB[r] = (g[r] == amax);
+            const int n_g = P.counts[g[r]];
+            float s_own = 0.f;
+            bool defer = (n_g == 1);
+            if (!defer) {
+                s_own = vs_own_score(P, v, g[r], n_g, x, lf, shift);
+                defer = !classB[r] && s_own > M;   // table rounding lifted it
+            }
+            if (defer) {
+                deferred[atomicAdd(deferred_count, 1u)] = at;
+                valid[r] = false;
+            } else {
+                m_row[r] = classB[r] ? fmaxf(s_own, M2) : M;
+                l_own[r] = fast_exp_nonpos(s_own - m_row[r], s_exp, ea, eb);
+                u[r] = batch_row_unif01(P, row[r]);
+            }
+        }
+    }
+    const int nchunks32 = (K + kVsUnroll - 1) / kVsUnroll;
+    // round 0: the rows outside the arg-max group (shift M); round 1: the
+    // rows inside it (shift mB, the same for all of them)
+    for (int round = 0; round < 2; ++round) {
+        bool active[kVsR];
+        bool any_active = false;
+        float m = M;
+#pragma unroll
+        for (int r = 0; r < kVsR; ++r) {
+            active[r] = valid[r] && (classB[r] == (round == 1));
+            any_active = any_active || active[r];
+            if (active[r] && round == 1) m = m_row[r];
+        }
+        if (!__any(any_active)) continue;
+        if (round == 1) {   // wave-uniform: every such row has the same own score
+            const unsigned long long who =
+                __builtin_amdgcn_ballot_w64(any_active);
+            const int src = __builtin_ctzll(who);
+            m = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(m), src));
+        }
+        int gchunk[kVsR], gpiece[kVsR];
+#pragma unroll
+        for (int r = 0; r < kVsR; ++r) {
+            gchunk[r] = active[r] ? (g[r] / kVsUnroll) : -1;
+            gpiece[r] = active[r] ? (g[r] >> 3) : -1;
+        }
+        v2f acc = {0.f, 0.f};              // the total, then t
+        float t_start[kVsR] = {0.f, 0.f};
+        int npos[kVsR] = {0, 0};
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            if (pass == 1) {
+                acc = acc * (v2f){u[0], u[1]};
+                t_start[0] = acc.x;
+                t_start[1] = acc.y;
+            }
+            bool done = false;
+            for (int k0 = 0; k0 < K && !done; k0 += kVsStreamChunk) {
+                // the chunk's likelihoods, 64 at a time, into the strip
+#pragma unroll
+                for (int j = 0; j < kVsStreamChunk / 64; ++j) {
+                    const int k = k0 + lane + 64 * j;
+                    float l = 0.f;
+                    if (k < K)
+                        l = fast_exp_nonpos(
+                            vs_stream_score<KIND>(P, v, k, x, lf) - m, s_exp,
+                            ea, eb);
+                    strip[lane + 64 * j] = l;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const int sub_end = min(kVsStreamChunk, K - k0);
+                for (int off = 0; off < sub_end; off += kVsUnroll) {
+                    const int c = (k0 + off) / kVsUnroll;
+                    const int kk = k0 + off;
+                    float l[kVsUnroll];
+                    const float4 * src =
+                        reinterpret_cast<const float4 *>(strip + off);
+#pragma unroll
+                    for (int q = 0; q < kVsUnroll / 4; ++q) {
+                        const float4 w = src[q];
+                        l[4 * q] = w.x; l[4 * q + 1] = w.y;
+                        l[4 * q + 2] = w.z; l[4 * q + 3] = w.w;
+                    }
+                    if (__any(gchunk[0] == c || gchunk[1] == c)) {
+#pragma unroll
+                        for (int b = 0; b < kVsUnroll / 8; ++b) {
+                            const int piece = (kk >> 3) + b;
+                            if (__any(gpiece[0] == piece
+                                      || gpiece[1] == piece)) {
+#pragma unroll
+                                for (int j = 8 * b; j < 8 * b + 8; ++j) {
+                                    const v2f e = {
+                                        (kk + j == g[0]) ? l_own[0] : l[j],
+                                        (kk + j == g[1]) ? l_own[1] : l[j]};
+                                    acc = pass ? acc - e : acc + e;
+                                }
+                            } else {
+#pragma unroll
+                                for (int j = 8 * b; j < 8 * b + 8; ++j)
+                                    acc = pass ? acc - vs_splat(l[j])
+                                               : acc + vs_splat(l[j]);
+                            }
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < kVsUnroll; ++j)
+                            acc = pass ? acc - vs_splat(l[j])
+                                       : acc + vs_splat(l[j]);
+                    }
+                    if (pass == 1) {
+                        const float tr[kVsR] = {acc.x, acc.y};
+                        bool more = false;
+#pragma unroll
+                        for (int r = 0; r < kVsR; ++r) {
+                            const bool p = tr[r] > 0.f;
+                            t_start[r] = p ? tr[r] : t_start[r];
+                            npos[r] += p ? 1 : 0;
+                            more = more || (active[r] && p);
+                        }
+                        if (__builtin_amdgcn_ballot_w64(more) == 0) {
+                            done = true;
+                            break;
+                        }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();   // before the strip is refilled
+            }
+        }
+        // replay the chunk in which a row crosses zero (random.hpp:326-329);
+        // its likelihoods are recomputed -- the same operations as above
+#pragma unroll
+        for (int r = 0; r < kVsR; ++r) {
+            if (!active[r]) continue;
+            int f = K - 1;
+            if (npos[r] < nchunks32) {
+                const int base_k = npos[r] * kVsUnroll;
+                float tt = t_start[r];
+                int steps = 0;
+                for (int j = 0; j < kVsUnroll; ++j) {
+                    const int k = base_k + j;
+                    float l = 0.f;
+                    if (k == g[r])
+                        l = l_own[r];
+                    else if (k < K)
+                        l = fast_exp_nonpos(
+                            vs_stream_score<KIND>(P, v, k, x, lf) - m, s_exp,
+                            ea, eb);
+                    tt -= l;
+                    steps += (tt > 0.f) ? 1 : 0;
+                }
+                f = base_k + steps;
+            }
+            g2[r] = f < K - 1 ? f : K - 1;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < kVsR; ++r) {
+        if (valid[r]) {
+            const uint32_t at = pos + kVsR * lane + r;
+            P.old_packed[at] = (uint32_t)g[r];
+            P.new_packed[at] = (uint32_t)g2[r];
+        }
+    }
+}
+
 // Applying a batch's moves in value-sorted order: one workgroup takes up to
 // kVsApplyRows rows of ONE value x and accumulates the per-group change d[k]
 // in LDS.  What every chunk changes alike -- counts[k], and the per-group
@@ -1984,6 +2245,7 @@ __global__ __launch_bounds__(kVsApplyBlock) void k_vs_apply(
     const uint32_t x = chunks[blockIdx.x].x;
     const uint32_t pos = chunks[blockIdx.x].pos;
     const uint32_t n = chunks[blockIdx.x].n;
+    if (x == 0xFFFFFFFEu) return;   // several values: k_vs_apply_mixed's
     for (int k = threadIdx.x; k < K; k += kVsApplyBlock) {
         delta[k] = 0;
         if (SORT) hist[k] = 0;
@@ -2083,6 +2345,71 @@ __global__ __launch_bounds__(kVsApplyBlock) void k_vs_apply(
     for (uint32_t i = threadIdx.x; i < n; i += kVsApplyBlock) {
         sorted_rows[pos + i] = rows_s[i];
         assign_pos[pos + i] = gid_s[i];
+    }
+}
+
+// k_vs_apply for a chunk that holds the rows of SEVERAL values (categorical
+// kinds; VsTile::x == kVsMixedChunk): where a value has only a few rows per
+// batch (C5: 100), one workgroup per value would spend its time on O(K) LDS
+// passes.  The chunk covers whole values, so this workgroup is still the only
+// one that touches their cells (k, x): per-group changes go to LDS and the
+// staging matrix as before, the cells take one atomic per moved row and end,
+// and (refresh_cells) the touched cache entries are rewritten from the final
+// counts.  Rows keep their order (tiles hold one value each).
+constexpr uint32_t kVsMixedChunk = 0xFFFFFFFEu;
+template <int KIND>
+__global__ __launch_bounds__(kVsApplyBlock) void k_vs_apply_mixed(
+        SweepParams P, StatImage img, const VsTile * __restrict__ chunks,
+        const uint32_t * __restrict__ sorted_rows,
+        const uint32_t * __restrict__ p2g, uint32_t * __restrict__ assign_pos,
+        int refresh_cells, int32_t * __restrict__ stage) {
+    extern __shared__ int vs_lds[];
+    const int K = P.K;
+    int * delta = vs_lds;                 // [K]
+    if (chunks[blockIdx.x].x != kVsMixedChunk) return;   // k_vs_apply's
+    const uint32_t pos = chunks[blockIdx.x].pos;
+    const uint32_t n = chunks[blockIdx.x].n;
+    const int dim = P.feat[0].dim;
+    for (int k = threadIdx.x; k < K; k += kVsApplyBlock) delta[k] = 0;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += kVsApplyBlock) {
+        const uint32_t go = P.old_packed[pos + i], gn = P.new_packed[pos + i];
+        assign_pos[pos + i] = p2g[gn];
+        if (go == gn) continue;
+        atomicAdd(&delta[go], -1);
+        atomicAdd(&delta[gn], 1);
+        const uint32_t x = P.values[0][P.row_begin + sorted_rows[pos + i]];
+        atomicAdd(&img.cnt[0][(size_t)go * dim + x], -1);
+        atomicAdd(&img.cnt[0][(size_t)gn * dim + x], 1);
+    }
+    __threadfence();     // the cell updates are complete before the refresh
+    __syncthreads();
+    for (int k = threadIdx.x; k < K; k += kVsApplyBlock) {
+        const int dlt = delta[k];
+        if (stage) {
+            stage[(size_t)blockIdx.x * K + k] = dlt;
+        } else if (dlt != 0) {
+            atomicAdd(&img.counts[k], dlt);
+            atomicAdd(&img.i0[0][k], dlt);     // count_sum
+        }
+    }
+    if (!refresh_cells) return;
+    // dd.hpp:458-467 for every touched cell, from the counts as they now stand
+    // (a cell moved by several rows is rewritten by each of them, alike)
+    const SlaveView & s = P.feat[0];
+    for (uint32_t i = threadIdx.x; i < n; i += kVsApplyBlock) {
+        const uint32_t go = P.old_packed[pos + i], gn = P.new_packed[pos + i];
+        if (go == gn) continue;
+        const uint32_t x = P.values[0][P.row_begin + sorted_rows[pos + i]];
+        const float prior = s.prior[x];
+        const int c_old = __hip_atomic_load(
+            &img.cnt[0][(size_t)go * dim + x], __ATOMIC_RELAXED,
+            __HIP_MEMORY_SCOPE_AGENT);
+        const int c_new = __hip_atomic_load(
+            &img.cnt[0][(size_t)gn * dim + x], __ATOMIC_RELAXED,
+            __HIP_MEMORY_SCOPE_AGENT);
+        s.S[(size_t)x * s.cap + go] = fast_log(prior + (float)c_old);
+        s.S[(size_t)x * s.cap + gn] = fast_log(prior + (float)c_new);
     }
 }
 

@@ -392,8 +392,10 @@ size_t dist_gibbs_global_size(const dist_gibbs_t * g);
  * 2 (value-sorted kernel whenever the feature list allows it);
  * "sequential_chain" = 1 (device-resident chain kernel, default) or 0;
  * "running_sums_min_tiles" = launches of at least this many value tiles use
- * the per-value running sums and band tiles (default 2048).  None changes a
- * result. */
+ * the per-value running sums and band tiles (default 2048);
+ * "value_stream" = 0 (per-value tables always), 1 (auto: the table-free
+ * kernel where a value has about one tile per batch), 2 (always).  None
+ * changes a result. */
 int dist_gibbs_set_option(dist_gibbs_t * g, const char * name, int value);
 /* how many batches each score+sample kernel has served */
 int dist_gibbs_path_counts(const dist_gibbs_t * g, uint64_t * value_sorted,
@@ -402,7 +404,8 @@ int dist_gibbs_path_counts(const dist_gibbs_t * g, uint64_t * value_sorted,
  * kernel, through the other kernels, launches with band tiles on, launches
  * with running sums on, values whose arg-max rows had their own tile in the
  * last value-sorted launch, rows that launch handed to the wave-per-row
- * kernel (first min(n, 6) entries are written) */
+ * kernel, value-sorted batches that took the table-free kernel (first
+ * min(n, 7) entries are written) */
 int dist_gibbs_debug_counts(dist_gibbs_t * g, uint64_t * out, size_t n);
 /* HIP-event time (ms) and launch count of the score+sample kernel since the
  * last reset, measured on the engine's stream */

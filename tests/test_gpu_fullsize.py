@@ -212,8 +212,10 @@ def test_c5_full_size_dpd_10m_rows():
     del orc
     gpu.sweep(first, N, 1_000_000, seed, draw_base=0)
     # (the 20 000-row batch is below the value-sorted kernel's threshold of
-    # 16 rows per value; the ten batches of the sweep proper are above it)
+    # 16 rows per value; the ten batches of the sweep proper are above it,
+    # and with 100 rows per value they take the table-free kernel)
     assert tuple(gpu.path_counts()) == (10, 1)
+    assert gpu.core.debug_counts()["stream_batches"] == 10
     final = gpu.assignments()
     counts = gpu.counts()
     assert counts.sum() == N and counts.shape[0] == len(gpu)
@@ -230,11 +232,12 @@ def test_c5_full_size_dpd_10m_rows():
     assert np.count_nonzero(final != assign) > N // 2
 
 
-def test_c5_shape_dpd_8192_groups_streamed_tables():
+@pytest.mark.parametrize("stream", [0, 2])
+def test_c5_shape_dpd_8192_groups_streamed_tables(stream):
     """BASELINE configs[4]'s shape -- DirichletProcessDiscrete over V = 10 000
-    values with K = 8192 groups, likelihood tables (V*K*4 B = 328 MB) streamed
-    from HBM by the vector-load form of the value-sorted kernel -- on as many
-    rows as the oracle follows in seconds: bit-exact."""
+    values with K = 8192 groups -- on as many rows as the oracle follows in
+    seconds, once through the per-value tables (V*K*4 B = 328 MB each,
+    streamed from HBM) and once through the table-free kernel: bit-exact."""
     from distributions_amd import engine
     n, k, dim = 120_000, 8192, 10_000
     osh, gsh, vals, assign = workloads.make("dpd", n, k, dim=dim)
@@ -242,6 +245,7 @@ def test_c5_shape_dpd_8192_groups_streamed_tables():
     orc.init_from_assignments(vals, assign, k, 1)
     gpu = engine.Gibbs(0.5, 0.1, gsh)
     gpu.set_option("value_sorted", 2)
+    gpu.set_option("value_stream", stream)
     gpu.load_rows(vals, assign, k, 1)
     seed = 77
     st = ol.oracle().orc_rng_seed(seed)
@@ -249,6 +253,7 @@ def test_c5_shape_dpd_8192_groups_streamed_tables():
         orc.gibbs_batch(b, b + 60_000, st, 0)
     gpu.sweep(0, n, 60_000, seed, draw_base=0)
     assert tuple(gpu.path_counts()) == (2, 0)   # value-sorted, generic
+    assert gpu.core.debug_counts()["stream_batches"] == stream
     assert_same_state(orc, gpu, "dpd V=10000 K=8192")
 
 

@@ -18,14 +18,16 @@ VS_ELIGIBLE = ("dd", "dd_skew", "bb", "dpd", "dpd_other", "gp", "bnb")
 def both(config, n, k, alpha, d, empty=1, dim=None, seed=workloads.SEED,
          mode=None):
     """mode: None = library default; 0 = generic kernel only; 2 = the
-    value-sorted kernel whenever the feature list allows it."""
+    value-sorted kernel (per-value tables) whenever the feature list allows
+    it; 3 = its table-free form (k_vs_stream) whenever it does."""
     from distributions_amd import engine
     osh, gsh, vals, assign = workloads.make(config, n, k, seed=seed, dim=dim)
     orc = ol.OracleMixture(alpha, d, osh)
     orc.init_from_assignments(vals, assign, k, empty)
     gpu = engine.Gibbs(alpha, d, gsh)
     if mode is not None:
-        gpu.set_option("value_sorted", mode)
+        gpu.set_option("value_sorted", min(mode, 2))
+        gpu.set_option("value_stream", 2 if mode == 3 else 0)
     gpu.load_rows(vals, assign, k, empty)
     return orc, gpu
 
@@ -72,9 +74,9 @@ def test_row_scores_match_oracle(config):
 
 @pytest.mark.parametrize("config", CONFIGS)
 @pytest.mark.parametrize("batch", [256, 1000, 4096])
-@pytest.mark.parametrize("mode", [0, 2])
+@pytest.mark.parametrize("mode", [0, 2, 3])
 def test_batch_sweeps_bit_exact(config, batch, mode):
-    if mode == 2 and config not in VS_ELIGIBLE:
+    if mode >= 2 and config not in VS_ELIGIBLE:
         pytest.skip("value-sorted kernel needs one small-domain feature")
     n, k = 4096, 32
     orc, gpu = both(config, n, k, 1.0, 0.2, mode=mode)
@@ -87,17 +89,20 @@ def test_batch_sweeps_bit_exact(config, batch, mode):
         gpu.sweep(0, n, batch, seed, draw_base=base)
         assert_same_state(orc, gpu, "%s sweep %d batch %d" % (config, sweep, batch))
     vs, generic = gpu.path_counts()
-    assert (vs > 0 and generic == 0) if mode == 2 else (vs == 0)
+    assert (vs > 0 and generic == 0) if mode >= 2 else (vs == 0)
+    streamed = gpu.core.debug_counts()["stream_batches"]
+    assert streamed == (vs if mode == 3 else 0)
 
 
 @pytest.mark.parametrize("config,dim,k", [("dd", 256, 64), ("dd_skew", 64, 16),
                                           ("dpd_other", 300, 24), ("bb", None, 8),
                                           ("gp", None, 12)])
-def test_value_sorted_larger_batches(config, dim, k):
+@pytest.mark.parametrize("mode", [None, 3])
+def test_value_sorted_larger_batches(config, dim, k, mode):
     """default mode picks the value-sorted kernel for large batches; groups of
     very different sizes make rows sit in the arg-max group (class B)."""
     n = 60000
-    orc, gpu = both(config, n, k, 1.0, 0.1, dim=dim)
+    orc, gpu = both(config, n, k, 1.0, 0.1, dim=dim, mode=mode)
     seed = 2024
     st = ol.oracle().orc_rng_seed(seed)
     for sweep in range(3):
@@ -207,6 +212,7 @@ def test_randomised_configurations():
         orc.init_from_assignments(vals, assign, k, empty)
         gpu = engine.Gibbs(alpha, d, feats_g)
         gpu.set_option("value_sorted", int(rng.choice([0, 1, 2])))
+        gpu.set_option("value_stream", int(rng.choice([0, 1, 2])))
         gpu.load_rows(vals, assign, k, empty)
         seed = int(rng.integers(1, 2 ** 31))
         st = L.orc_rng_seed(seed)

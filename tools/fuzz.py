@@ -102,6 +102,8 @@ def trial(seed, large=False):
     gpu.set_option("value_sorted", mode)
     if rng.integers(0, 2):   # the per-value running sums, also on small launches
         gpu.set_option("running_sums_min_tiles", 0)
+    # per-value tables or the table-free kernel (and its packed apply chunks)
+    gpu.set_option("value_stream", int(rng.choice([0, 1, 2])))
     gpu.load_rows(vals, assign, k, empty)
     what = "seed %d: n=%d k=%d empty=%d feats=%s mode=%d %s" % (
         seed, n, k, empty, "+".join(desc), mode,
@@ -159,6 +161,7 @@ def trial_collective(seed):
     gpu.set_option("value_sorted", int(rng.choice([0, 1, 2])))
     if rng.integers(0, 2):
         gpu.set_option("running_sums_min_tiles", 0)
+    gpu.set_option("value_stream", int(rng.choice([0, 1, 2])))
     gpu.load_rows_torch(cols, a.clone(), k, 2)
     sharded = engine.ShardedGibbs(gpu.core, n, 0, device=dev,
                                   force_collective=True, columns=cols,
