@@ -2,6 +2,8 @@
 // dist_hip.hip.  Layout and roofline notes per kernel are in DESIGN.md.
 #pragma once
 
+#include <type_traits>
+
 #include "models.h"
 
 namespace dist {
@@ -1703,6 +1705,24 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 static_assert(kVsR == 2, "the recurrences below are written for two rows per "
                          "lane (one v_pk_add_f32 per entry)");
 __device__ __forceinline__ v2f vs_splat(float x) { return (v2f){x, x}; }
+// One eight-entry piece of the likelihood vector into which own slots fall
+// (entries k0 .. k0+7, `l` wave-uniform): acc (+/-)= the entry, a lane's own
+// slot replaced by its l_own.  (A form that looks for the one entry in
+// question first -- ballots, readlane, a wave-uniform index -- was tried and
+// measured slower at every batch size: the compiler turns the uniform
+// branches back into selects, two per entry as here, and the search is
+// extra.)
+template <bool SUB>
+__device__ __forceinline__ void vs_own_piece(
+        v2f & acc, const float (&l)[8], int k0, const int (&g)[kVsR],
+        const float (&l_own)[kVsR]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const v2f e = {(k0 + j == g[0]) ? l_own[0] : l[j],
+                       (k0 + j == g[1]) ? l_own[1] : l[j]};
+        acc = SUB ? acc - e : acc + e;
+    }
+}
 __device__ __forceinline__ void vs_sum_and_scan(
         uniform_fp lp, const float * lp_vec, uniform_fp prefix, int K,
         const int (&g)[kVsR],
@@ -1742,10 +1762,11 @@ __device__ __forceinline__ void vs_sum_and_scan(
             for (int b = 0; b < kVsUnroll / 8; ++b) {
                 const int piece = (k0 >> 3) + b;
                 if (__any(gpiece[0] == piece || gpiece[1] == piece)) {
-#pragma unroll
-                    for (int j = 8 * b; j < 8 * b + 8; ++j)
-                        total += (v2f){(k0 + j == g[0]) ? l_own[0] : l[j],
-                                       (k0 + j == g[1]) ? l_own[1] : l[j]};
+                    const float l8[8] = {l[8 * b], l[8 * b + 1], l[8 * b + 2],
+                                         l[8 * b + 3], l[8 * b + 4],
+                                         l[8 * b + 5], l[8 * b + 6],
+                                         l[8 * b + 7]};
+                    vs_own_piece<false>(total, l8, k0 + 8 * b, g, l_own);
                 } else {
 #pragma unroll
                     for (int j = 8 * b; j < 8 * b + 8; ++j)
@@ -1772,10 +1793,11 @@ __device__ __forceinline__ void vs_sum_and_scan(
             for (int b = 0; b < kVsUnroll / 8; ++b) {
                 const int piece = (k0 >> 3) + b;
                 if (__any(gpiece[0] == piece || gpiece[1] == piece)) {
-#pragma unroll
-                    for (int j = 8 * b; j < 8 * b + 8; ++j)
-                        t -= (v2f){(k0 + j == g[0]) ? l_own[0] : l[j],
-                                   (k0 + j == g[1]) ? l_own[1] : l[j]};
+                    const float l8[8] = {l[8 * b], l[8 * b + 1], l[8 * b + 2],
+                                         l[8 * b + 3], l[8 * b + 4],
+                                         l[8 * b + 5], l[8 * b + 6],
+                                         l[8 * b + 7]};
+                    vs_own_piece<true>(t, l8, k0 + 8 * b, g, l_own);
                 } else {
 #pragma unroll
                     for (int j = 8 * b; j < 8 * b + 8; ++j)
@@ -1964,6 +1986,41 @@ constexpr int kVsStreamBlock = 256;
 
 __global__ void k_set_u32(uint32_t * p, uint32_t value) { *p = value; }
 
+// acc (+/-)= splat(w.x), then w.y, w.z, w.w: four dependent v_pk_add_f32 whose
+// second operand is ONE dword of a register pair taken into both halves by
+// op_sel (the compiler moves the odd dwords into place first, a VALU move per
+// entry).  A packed add that consumes the previous one's result needs one
+// wait state (the compiler puts s_nop 0 / a scalar move there itself); inside
+// an asm block nobody does, so they are spelled out, also ahead of the first
+// add and after the last.  x - y == x + (-y) exactly (neg_lo / neg_hi).
+template <bool SUB>
+__device__ __forceinline__ void vs_pk_chain4(v2f & acc, const float4 & w) {
+    const v2f lo = {w.x, w.y}, hi = {w.z, w.w};
+    if (SUB) {
+        asm("s_nop 0\n\t"
+            "v_pk_add_f32 %0, %0, %1 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+            "s_nop 0\n\t"
+            "v_pk_add_f32 %0, %0, %1 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+            "s_nop 0\n\t"
+            "v_pk_add_f32 %0, %0, %2 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+            "s_nop 0\n\t"
+            "v_pk_add_f32 %0, %0, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+            "s_nop 0"
+            : "+v"(acc) : "v"(lo), "v"(hi));
+    } else {
+        asm("s_nop 0\n\t"
+            "v_pk_add_f32 %0, %0, %1 op_sel_hi:[1,0]\n\t"
+            "s_nop 0\n\t"
+            "v_pk_add_f32 %0, %0, %1 op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+            "s_nop 0\n\t"
+            "v_pk_add_f32 %0, %0, %2 op_sel_hi:[1,0]\n\t"
+            "s_nop 0\n\t"
+            "v_pk_add_f32 %0, %0, %2 op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+            "s_nop 0"
+            : "+v"(acc) : "v"(lo), "v"(hi));
+    }
+}
+
 template <int KIND>
 __device__ __forceinline__ float vs_stream_score(const SweepParams & P,
                                                  const SlaveView & v, int k,
@@ -1972,7 +2029,9 @@ __device__ __forceinline__ float vs_stream_score(const SweepParams & P,
 }
 
 template <int KIND>
-__global__ __launch_bounds__(kVsStreamBlock) void k_vs_stream(
+__global__ __launch_bounds__(kVsStreamBlock)
+__attribute__((amdgpu_waves_per_eu(8, 8)))
+void k_vs_stream(
         SweepParams P, const VsTile * __restrict__ tiles, uint32_t n_tiles,
         const uint32_t * __restrict__ sorted_rows,
         uint32_t * __restrict__ deferred, uint32_t * deferred_count) {
@@ -2087,8 +2146,8 @@ __global__ __launch_bounds__(kVsStreamBlock) void k_vs_stream(
         v2f acc = {0.f, 0.f};              // the total, then t
         float t_start[kVsR] = {0.f, 0.f};
         int npos[kVsR] = {0, 0};
-#pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
+        auto run_pass = [&](auto pass_tag) {
+            constexpr int pass = decltype(pass_tag)::value;
             if (pass == 1) {
                 acc = acc * (v2f){u[0], u[1]};
                 t_start[0] = acc.x;
@@ -2114,40 +2173,30 @@ __global__ __launch_bounds__(kVsStreamBlock) void k_vs_stream(
                 for (int off = 0; off < sub_end; off += kVsUnroll) {
                     const int c = (k0 + off) / kVsUnroll;
                     const int kk = k0 + off;
-                    float l[kVsUnroll];
+                    float4 w[kVsUnroll / 4];
                     const float4 * src =
                         reinterpret_cast<const float4 *>(strip + off);
 #pragma unroll
-                    for (int q = 0; q < kVsUnroll / 4; ++q) {
-                        const float4 w = src[q];
-                        l[4 * q] = w.x; l[4 * q + 1] = w.y;
-                        l[4 * q + 2] = w.z; l[4 * q + 3] = w.w;
-                    }
-                    if (__any(gchunk[0] == c || gchunk[1] == c)) {
+                    for (int q = 0; q < kVsUnroll / 4; ++q) w[q] = src[q];
+                    const bool own_here =
+                        __any(gchunk[0] == c || gchunk[1] == c);
 #pragma unroll
-                        for (int b = 0; b < kVsUnroll / 8; ++b) {
-                            const int piece = (kk >> 3) + b;
-                            if (__any(gpiece[0] == piece
-                                      || gpiece[1] == piece)) {
-#pragma unroll
-                                for (int j = 8 * b; j < 8 * b + 8; ++j) {
-                                    const v2f e = {
-                                        (kk + j == g[0]) ? l_own[0] : l[j],
-                                        (kk + j == g[1]) ? l_own[1] : l[j]};
-                                    acc = pass ? acc - e : acc + e;
-                                }
-                            } else {
-#pragma unroll
-                                for (int j = 8 * b; j < 8 * b + 8; ++j)
-                                    acc = pass ? acc - vs_splat(l[j])
-                                               : acc + vs_splat(l[j]);
-                            }
+                    for (int b = 0; b < kVsUnroll / 8; ++b) {
+                        const int piece = (kk >> 3) + b;
+                        if (own_here && __any(gpiece[0] == piece
+                                              || gpiece[1] == piece)) {
+                            // an own slot in these eight entries: per-lane
+                            // select (vs_sum_and_scan's form)
+                            const float l[8] = {
+                                w[2 * b].x, w[2 * b].y, w[2 * b].z, w[2 * b].w,
+                                w[2 * b + 1].x, w[2 * b + 1].y,
+                                w[2 * b + 1].z, w[2 * b + 1].w};
+                            vs_own_piece<pass == 1>(acc, l, kk + 8 * b, g,
+                                                    l_own);
+                        } else {
+                            vs_pk_chain4<pass == 1>(acc, w[2 * b]);
+                            vs_pk_chain4<pass == 1>(acc, w[2 * b + 1]);
                         }
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < kVsUnroll; ++j)
-                            acc = pass ? acc - vs_splat(l[j])
-                                       : acc + vs_splat(l[j]);
                     }
                     if (pass == 1) {
                         const float tr[kVsR] = {acc.x, acc.y};
@@ -2167,7 +2216,9 @@ __global__ __launch_bounds__(kVsStreamBlock) void k_vs_stream(
                 }
                 __builtin_amdgcn_wave_barrier();   // before the strip is refilled
             }
-        }
+        };
+        run_pass(std::integral_constant<int, 0>{});   // the total
+        run_pass(std::integral_constant<int, 1>{});   // the scan
         // replay the chunk in which a row crosses zero (random.hpp:326-329);
         // its likelihoods are recomputed -- the same operations as above
 #pragma unroll
