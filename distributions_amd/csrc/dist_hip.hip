@@ -894,6 +894,19 @@ struct Gibbs {
     uint64_t band_batches = 0, prefix_batches = 0;
     bool last_bands = false, last_prefix = false;
 
+    // Device-side normalisation of the group set (k_normalise): a whole sweep
+    // is queued without the host looking at the group sizes in between.
+    // While `async_active`, K() is an UPPER BOUND (the host sizes launches and
+    // buffers with it; the kernels read the group count from dev_state) and
+    // the host mirrors (py.counts, tracker) are stale; sweep_async pulls the
+    // state back before it returns.
+    DeviceBuf<DevState> dev_state;
+    DeviceBuf<int32_t> snap_counts;   // group sizes at batch entry
+    bool async_active = false;
+    int device_normalise_mode = 1;    // 0 never, 1 where it applies
+    uint64_t async_batches = 0;
+    std::vector<hipEvent_t> ev_pool;
+
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double kernel_ms = 0.0;
     uint64_t kernel_launches = 0, kernel_rows = 0;
@@ -912,6 +925,7 @@ struct Gibbs {
     ~Gibbs() {
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
+        for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
         if (pinned_counts) (void)hipHostFree(pinned_counts);
         if (pinned_seq) (void)hipHostFree(pinned_seq);
         if (pinned_pairs) (void)hipHostFree(pinned_pairs);
@@ -921,17 +935,21 @@ struct Gibbs {
     int K() const { return py.K(); }
 
     // both id maps travel in one copy: [p2g (capacity slots) | g2p]
-    void upload_maps() {
-        if (!maps_dirty) return;
+    // min_p / min_g: room the device needs for the slots / ids it appends
+    // itself (k_batch_finish)
+    void upload_maps(size_t min_p = 0, size_t min_g = 0) {
         const size_t np = tracker.p2g.size(), ng = tracker.g2p.size();
-        const size_t pcap = grow_capacity(np);
+        const bool roomy = maps_pcap >= std::max(np, min_p)
+                           && d_maps.cap >= maps_pcap + std::max(ng, min_g);
+        if (!maps_dirty && roomy) return;
+        const size_t pcap = grow_capacity(std::max(np, min_p));
         maps_host.resize(pcap + ng);
         std::copy(tracker.p2g.begin(), tracker.p2g.end(), maps_host.begin());
         for (size_t i = 0; i < ng; ++i)
             maps_host[pcap + i] = (uint32_t)tracker.g2p[i];
         // headroom for groups the device appends itself (k_batch_finish)
-        if (maps_host.size() + 1024 > d_maps.cap)
-            d_maps.reserve(grow_capacity(maps_host.size() + 1024), 0);
+        const size_t want = pcap + std::max(ng + 1024, min_g);
+        if (want > d_maps.cap) d_maps.reserve(grow_capacity(want), 0);
         d_maps.upload(maps_host.data(), maps_host.size());
         d_p2g_ptr = d_maps.p;
         d_g2p_ptr = reinterpret_cast<const int32_t *>(d_maps.p + pcap);
@@ -973,6 +991,7 @@ struct Gibbs {
         ensure_pow_tables(r1 - r0);
         P.pow_lo = pow_lo.p;
         P.pow_hi = pow_hi.p;
+        P.dev = async_active ? dev_state.p : nullptr;
         return P;
     }
 
@@ -1383,12 +1402,28 @@ struct Gibbs {
         hipLaunchKernelGGL(k_vs_scatter, sort_grid, dim3(kBlock), 0, stream(),
                            values[0], r0, n, nv, cursor.p, c->sorted_rows.p);
         HIP_CHECK(hipGetLastError());
+        // A value's rows are kept sorted by group (k_vs_apply), so its j-th
+        // tile starts its total at the running sum of about the j-th part of
+        // the vector: early tiles run a nearly full first pass, late ones
+        // almost none.  Consecutive tile ids share a workgroup, ids 4 apart a
+        // SIMD: list a value's tiles four from the front, four from the
+        // back, ... so that every SIMD gets long and short ones alike.
         std::vector<VsTile> tiles;
-        for (uint32_t x = 0; x < nv; ++x)
-            for (uint32_t off = 0; off < h[x]; off += 64 * kVsR)
-                tiles.push_back(VsTile{x, start[x] + off,
-                                       std::min<uint32_t>(64 * kVsR,
-                                                          h[x] - off)});
+        for (uint32_t x = 0; x < nv; ++x) {
+            const uint32_t T = (h[x] + 64 * kVsR - 1) / (64 * kVsR);
+            uint32_t front = 0, back = T;
+            bool from_front = true;
+            while (front < back) {
+                for (int q = 0; q < 4 && front < back; ++q) {
+                    const uint32_t j = from_front ? front++ : --back;
+                    const uint32_t off = j * 64 * kVsR;
+                    tiles.push_back(VsTile{x, start[x] + off,
+                                           std::min<uint32_t>(64 * kVsR,
+                                                              h[x] - off)});
+                }
+                from_front = !from_front;
+            }
+        }
         c->n_tiles = (uint32_t)tiles.size();
         c->tiles.upload(tiles.data(), tiles.size());
         for (uint32_t x = 0; x < nv; ++x) c->n_values_present += h[x] != 0;
@@ -1832,8 +1867,8 @@ struct Gibbs {
             HIP_CHECK(hipGetDevice(&apply_device));
             unsigned long long * pairs = nullptr;
             unsigned pairs_seq = 0;
-            if (stage && img.counts == py.d_counts.p) {   // live statistics
-                pairs = pairs_buffer();
+            if (stage && img.counts == py.d_counts.p && !async_active) {
+                pairs = pairs_buffer();   // live statistics: publish sizes
                 pairs_seq = pairs_ticket = ++publish_ticket;
             }
             const dim3 rgrid((K() + kVsReduceGroups - 1) / kVsReduceGroups),
@@ -1863,7 +1898,8 @@ struct Gibbs {
                                        0, stream(), img, stage, c.chunks.p,  \
                                        c.n_chunks, K(),                      \
                                        (uint32_t)vs_nvals(), pairs,          \
-                                       pairs_seq);                           \
+                                       pairs_seq,                            \
+                                       async_active ? dev_state.p : nullptr);\
             } while (0)
             // chunks of several values first (their rows of the staging
             // matrix must be there when k_vs_reduce runs)
@@ -2088,9 +2124,201 @@ struct Gibbs {
         collect_timing();
     }
 
+    // ---- sweeps with the group set normalised on the device ---------------
+    // LDS of k_normalise: K + 2 ints and K / 2 + 1 slot pairs
+    static size_t normalise_lds(int K) {
+        return ((size_t)K + 2) * 4 + ((size_t)K / 2 + 1) * 8;
+    }
+    // Every batch of the sweep takes the value-sorted path, the statistics
+    // are integers, and the bound on the group count fits the kernels' LDS.
+    bool async_eligible(size_t r0, size_t r1, size_t batch) const {
+        if (device_normalise_mode == 0 || cluster != 0 || F() != 1) return false;
+        if (r1 <= r0 || any_float_stats() || py.n_empty < 1) return false;
+        const size_t last = (r1 - r0) % batch;
+        if (!use_value_sorted(std::min(batch, r1 - r0))) return false;
+        if (last && !use_value_sorted(last)) return false;
+        const size_t n_batches = (r1 - r0 + batch - 1) / batch;
+        const size_t bound = (size_t)K() + n_batches * (size_t)py.n_empty;
+        if (normalise_lds((int)bound) > 150 * 1024) return false;
+        // k_vs_apply's plain form must fit (see apply_ints)
+        return bound * 4 <= 144 * 1024;
+    }
+    void launch_normalise() {
+        NormaliseParams N;
+        memset(&N, 0, sizeof(N));
+        N.F = F();
+        for (int f = 0; f < F(); ++f) N.feat[f] = feats[f]->view();
+        N.counts = py.d_counts.p;
+        N.snap = snap_counts.p;
+        N.p2g = d_maps.p;
+        N.g2p = reinterpret_cast<int32_t *>(d_maps.p + maps_pcap);
+        N.dev = dev_state.p;
+        N.n_empty = py.n_empty;
+        const size_t lds = normalise_lds(K());
+        int device = 0;
+        HIP_CHECK(hipGetDevice(&device));
+        static std::atomic<size_t> opted_in[64];
+        std::atomic<size_t> & have = opted_in[device & 63];
+        if (lds > 64 * 1024 && lds > have.load(std::memory_order_relaxed)) {
+            HIP_CHECK(hipFuncSetAttribute(
+                reinterpret_cast<const void *>(&k_normalise),
+                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            have.store(lds, std::memory_order_relaxed);
+        }
+        hipLaunchKernelGGL(k_normalise, dim3(1), dim3(kNormaliseBlock), lds,
+                           stream(), N);
+        HIP_CHECK(hipGetLastError());
+    }
+    // batch_finish with the group set normalised by the device
+    void batch_finish_device() {
+        DIST_REQUIRE(batch_open, "no open batch");
+        batch_open = false;
+        launch_normalise();
+        FinishParams Q;
+        memset(&Q, 0, sizeof(Q));
+        Q.F = F();
+        size_t cells = (size_t)K();
+        for (int f = 0; f < F(); ++f) {
+            Q.feat[f] = feats[f]->view();
+            // (with current cells: the appended groups' columns only, at
+            // most one per empty group)
+            const size_t groups =
+                cells_fresh ? (size_t)py.n_empty : (size_t)K();
+            cells = std::max(cells, groups * std::max(1, feats[f]->dim()));
+        }
+        Q.counts = py.d_counts.p;
+        Q.shifted = py.d_shifted.p;
+        Q.cells_fresh = cells_fresh ? 1 : 0;
+        cells_fresh = false;
+        Q.alpha = alpha;
+        Q.d = d;
+        Q.empty = py.n_empty;
+        Q.prep = DriverPrep{alpha, d, cluster, dataset_size, py.sample_size,
+                            K(), py.n_empty, base.p, base_single.p, scalars.p};
+        base_valid = true;
+        Q.p2g = d_maps.p;
+        Q.g2p = reinterpret_cast<int32_t *>(d_maps.p + maps_pcap);
+        Q.dev = dev_state.p;
+        Q.snap = snap_counts.p;
+        hipLaunchKernelGGL(k_batch_finish,
+                           dim3((unsigned)((cells + kBlock - 1) / kBlock),
+                                (unsigned)(F() + 1)),
+                           dim3(kBlock), 0, stream(), Q);
+        HIP_CHECK(hipGetLastError());
+    }
+    // the host mirrors (group sizes, group count, id maps) from the device
+    void pull_host_state() {
+        sync();
+        DevState st;
+        dev_state.download(&st, 1);
+        const size_t Kn = (size_t)st.K;
+        py.counts.resize(Kn);
+        py.d_counts.download(py.counts.data(), Kn);
+        py.n_empty = 0;
+        py.sample_size = 0;
+        for (int c : py.counts) {
+            py.sample_size += c;
+            py.n_empty += (c == 0);
+        }
+        for (auto & s : feats) s->K = (int)Kn;
+        std::vector<uint32_t> maps(maps_pcap + st.global_size);
+        d_maps.download(maps.data(), maps.size());
+        tracker.p2g.assign(maps.begin(), maps.begin() + (long)Kn);
+        tracker.g2p.resize(st.global_size);
+        for (size_t i = 0; i < st.global_size; ++i)
+            tracker.g2p[i] = (int32_t)maps[maps_pcap + i];
+        maps_dirty = false;   // the device's copy IS the state
+    }
+    void sweep_async(size_t r0, size_t r1, size_t batch, uint32_t seed,
+                     uint64_t draw_base) {
+        const size_t n_batches = (r1 - r0 + batch - 1) / batch;
+        const int K0 = K();
+        const int bound = K0 + (int)n_batches * py.n_empty;
+        // room for everything the device may grow into, before the first
+        // launch (growing a buffer synchronises)
+        py.reserve(bound);
+        for (auto & s : feats) s->reserve(bound);
+        if ((size_t)bound > base.cap || (size_t)bound > base_single.cap) {
+            base.reserve(grow_capacity((size_t)bound), 0);
+            base_single.reserve(grow_capacity((size_t)bound), 0);
+            base_valid = false;   // (the new buffers are empty)
+        }
+        upload_maps((size_t)bound,
+                    tracker.g2p.size() + n_batches * (size_t)py.n_empty);
+        DevState st;
+        memset(&st, 0, sizeof(st));
+        st.K = K0;
+        st.k_new = K0;
+        st.global_size = (uint32_t)tracker.g2p.size();
+        st.first_new_global = st.global_size;
+        st.nonempty = K0 - py.n_empty;
+        dev_state.upload(&st, 1);
+        snap_counts.reserve(grow_capacity((size_t)bound), 0);
+        HIP_CHECK(hipMemcpyAsync(snap_counts.p, py.d_counts.p,
+                                 (size_t)K0 * 4, hipMemcpyDeviceToDevice,
+                                 stream()));
+        if (!base_valid) {   // (with the true group count, before K() bounds)
+            SweepParams P0 = params(r0, r0, seed, draw_base);
+            prepare(P0, false);
+        }
+        while (ev_pool.size() < 2 * n_batches) {
+            hipEvent_t e = nullptr;
+            HIP_CHECK(hipEventCreate(&e));
+            ev_pool.push_back(e);
+        }
+        hipEvent_t own0 = ev0, own1 = ev1;
+        // from here on K() is the bound
+        py.counts.resize((size_t)bound, 0);
+        async_active = true;
+        pairs_ticket = 0;
+        size_t done = 0;
+        try {
+            for (size_t b = r0; b < r1; b += batch, ++done) {
+                const size_t e = std::min(r1, b + batch);
+                ev0 = ev_pool[2 * done];
+                ev1 = ev_pool[2 * done + 1];
+                batch_sample(b, e, seed, draw_base);
+                DIST_REQUIRE(batch_value_sorted,
+                             "internal: asynchronous sweep left its path");
+                apply_ints(live_image());
+                batch_finish_device();
+                async_batches += 1;
+            }
+        } catch (...) {
+            ev0 = own0;
+            ev1 = own1;
+            async_active = false;
+            timing_pending = false;
+            batch_open = false;
+            (void)hipStreamSynchronize(stream());
+            try { pull_host_state(); } catch (...) {}
+            throw;
+        }
+        ev0 = own0;
+        ev1 = own1;
+        async_active = false;
+        timing_pending = false;
+        pull_host_state();
+        for (size_t i = 0; i < done; ++i) {
+            float ms = 0.f;
+            HIP_CHECK(hipEventElapsedTime(&ms, ev_pool[2 * i],
+                                          ev_pool[2 * i + 1]));
+            kernel_ms += ms;
+            kernel_launches += 1;
+            kernel_rows += std::min(r1, r0 + (i + 1) * batch)
+                           - (r0 + i * batch);
+        }
+    }
+
     void sweep(size_t r0, size_t r1, size_t batch, uint32_t seed,
                uint64_t draw_base) {
         DIST_REQUIRE(batch > 0, "batch_rows must be positive");
+        DIST_REQUIRE(r0 <= r1 && r1 <= n_rows, "bad row range");
+        if (async_eligible(r0, r1, batch)) {
+            DIST_REQUIRE(!batch_open, "previous batch not finished");
+            sweep_async(r0, r1, batch, seed, draw_base);
+            return;
+        }
         for (size_t b = r0; b < r1; b += batch) {
             const size_t e = std::min(r1, b + batch);
             batch_sample(b, e, seed, draw_base);
@@ -3131,6 +3359,12 @@ int dist_gibbs_set_option(dist_gibbs_t * g, const char * name, int value) {
             // the table-free value-sorted kernel: 0 never, 1 auto, 2 always
             DIST_REQUIRE(value >= 0 && value <= 2, "value_stream: 0, 1 or 2");
             g->impl->value_stream_mode = value;
+        } else if (key == "device_normalise") {
+            // sweeps whose batches all take the value-sorted path normalise
+            // the group set on the device (no host round trip per batch):
+            // 0 never, 1 where it applies
+            DIST_REQUIRE(value == 0 || value == 1, "device_normalise: 0 or 1");
+            g->impl->device_normalise_mode = value;
         } else if (key == "running_sums_min_tiles") {
             // launches of at least this many value tiles start each tile's
             // total from the per-value running sums (a tuning knob: results
@@ -3157,8 +3391,9 @@ int dist_gibbs_path_counts(const dist_gibbs_t * g, uint64_t * value_sorted,
 int dist_gibbs_debug_counts(dist_gibbs_t * g, uint64_t * out, size_t n) {
     return guarded([&] {
         Gibbs & e = *g->impl;
-        uint64_t v[7] = {e.vs_batches, e.generic_batches, e.band_batches,
-                         e.prefix_batches, 0, 0, e.stream_batches};
+        uint64_t v[8] = {e.vs_batches, e.generic_batches, e.band_batches,
+                         e.prefix_batches, 0, 0, e.stream_batches,
+                         e.async_batches};
         if (e.last_bands && !e.batch_open && e.vsBandMode.p) {
             // values whose arg-max group's rows had a tile of their own in
             // the last value-sorted launch
@@ -3171,7 +3406,7 @@ int dist_gibbs_debug_counts(dist_gibbs_t * g, uint64_t * out, size_t n) {
             e.deferred_count.download(&d, 1);
             v[5] = d;
         }
-        for (size_t i = 0; i < n && i < 7; ++i) out[i] = v[i];
+        for (size_t i = 0; i < n && i < 8; ++i) out[i] = v[i];
     });
 }
 int dist_gibbs_kernel_stats(dist_gibbs_t * g, double * ms_out,

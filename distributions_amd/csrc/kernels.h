@@ -214,6 +214,20 @@ __global__ void k_slave_move_group(SlaveView s, int dst, int src) {
     }
 }
 
+// What the device knows about the group set when it normalises the set
+// itself between batches (k_normalise): the host then queues whole sweeps
+// without looking at the group sizes, its mirrors follow afterwards.
+struct DevState {
+    int K;                   // groups after the last normalisation
+    int k_new;               // first slot that normalisation appended
+    int created;             // slots it appended: [k_new, K)
+    int removed;             // groups it swap-removed
+    uint32_t global_size;    // ids handed out so far (MixtureIdTracker)
+    uint32_t first_new_global;   // id of slot k_new
+    int nonempty;            // K - (empty groups)
+    int pad;
+};
+
 struct SweepScalars {
     float shift;         // -fast_log(float(N - 1) + alpha)   (row removed)
     float empty_single;  // empty-group score with one non-empty group fewer
@@ -289,28 +303,42 @@ struct FinishParams {
     uint32_t * p2g;
     int32_t * g2p;
     uint32_t first_new_global;
+    // the device normalised the group set (k_normalise): K, k_new, nonempty
+    // and first_new_global are read from *dev instead of the fields above
+    const DevState * dev;
+    int32_t * snap;        // (optional) receives the new group sizes
 };
 __global__ void k_batch_finish(FinishParams P) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int K = P.K;
+    int K = P.K, k_new = P.k_new, nonempty = P.nonempty;
+    uint32_t first_new_global = P.first_new_global;
+    DriverPrep prep = P.prep;
+    if (P.dev) {   // the device normalised the group set itself (k_normalise)
+        K = P.dev->K;
+        k_new = P.dev->k_new;
+        nonempty = P.dev->nonempty;
+        first_new_global = P.dev->first_new_global;
+        prep.K = K;
+    }
     if ((int)blockIdx.y == P.F) {
         if (i >= (size_t)K) return;
         const int k = (int)i;
         int n = P.counts[k];
-        if (k >= P.k_new) {
+        if (k >= k_new) {
             n = 0;
             P.counts[k] = 0;
             if (P.p2g) {
-                const uint32_t global = P.first_new_global + (uint32_t)(k - P.k_new);
+                const uint32_t global = first_new_global + (uint32_t)(k - k_new);
                 P.p2g[k] = global;
                 P.g2p[global] = k;
             }
         }
+        if (P.snap) P.snap[k] = n;   // the sizes the next batch starts from
         const float shifted =
             n ? py_nonempty_score(n, P.d)
-              : py_empty_score(P.alpha, P.d, P.nonempty, P.empty);
+              : py_empty_score(P.alpha, P.d, nonempty, P.empty);
         P.shifted[k] = shifted;
-        driver_prepare_slot(P.prep, i, n, shifted);
+        driver_prepare_slot(prep, i, n, shifted);
         return;
     }
     const SlaveView & s = P.feat[blockIdx.y];
@@ -318,19 +346,19 @@ __global__ void k_batch_finish(FinishParams P) {
         int v, k;
         if (P.cells_fresh) {
             // only the appended groups' cells and every group's shift
-            const int n_new = K - P.k_new;
+            const int n_new = K - k_new;
             if (i < (size_t)K) {
-                if ((int)i < P.k_new) refresh_shift(s, (int)i);
+                if ((int)i < k_new) refresh_shift(s, (int)i);
             }
             if (i >= (size_t)n_new * s.dim) return;
             v = (int)(i / n_new);
-            k = P.k_new + (int)(i % n_new);
+            k = k_new + (int)(i % n_new);
         } else {
             if (i >= (size_t)K * s.dim) return;
             v = (int)(i / K);
             k = (int)(i % K);     // group fastest: S[v][k] coalesces
         }
-        if (k >= P.k_new) {
+        if (k >= k_new) {
             s.cnt[(size_t)k * s.dim + v] = 0;
             if (v == 0) { s.i0[k] = 0; s.i1[k] = 0; s.f0[k] = 0.f; s.f1[k] = 0.f; }
             s.S[(size_t)v * s.cap + k] = fast_log(s.prior[v] + 0.f);
@@ -342,11 +370,128 @@ __global__ void k_batch_finish(FinishParams P) {
     } else {
         if (i >= (size_t)K) return;
         const int k = (int)i;
-        if (k >= P.k_new) {
+        if (k >= k_new) {
             const Stats zero = {0, 0, 0.f, 0.f};
             store_stats(s, k, zero);
         }
         refresh_scalar_entry(s, k);
+    }
+}
+
+// MixtureDriver's group-set normalisation after a batch (mixture.hpp:84-89,
+// 108-119; what Gibbs::batch_finish works out on the host), on the device:
+// ONE workgroup compares the group sizes with those at batch entry (`snap`).
+// Groups that lost their last member are swap-removed in descending slot
+// order -- which comes to: the survivors behind the new end, in descending
+// slot order, fill the vacated slots in front of it, in descending slot order
+// -- with their statistics, cache entries and ids; every previously empty
+// group that gained members is replaced by a new empty one at the end, whose
+// statistics, cache entries and ids k_batch_finish writes (slots >= k_new).
+constexpr int kNormaliseBlock = 1024;
+struct NormaliseParams {
+    int F;
+    SlaveView feat[kMaxF];
+    int32_t * counts;
+    const int32_t * snap;
+    uint32_t * p2g;
+    int32_t * g2p;
+    DevState * dev;
+    int n_empty;         // invariant of the chain
+};
+__global__ __launch_bounds__(kNormaliseBlock) void k_normalise(
+        NormaliseParams P) {
+    // [K + 2] emptied-before (padded to 8 bytes) | [K / 2 + 1] {dst, src}
+    extern __shared__ int nm_lds[];
+    __shared__ int s_part[kNormaliseBlock / 64];
+    __shared__ int s_created, s_moves;
+    const int K = P.dev->K;
+    int * before = nm_lds;            // before[k] = emptied groups in [0, k)
+    int2 * moves = reinterpret_cast<int2 *>(nm_lds + ((K + 2) & ~1));
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) { s_created = 0; s_moves = 0; }
+    __syncthreads();
+    // each thread owns a contiguous slice of the slots
+    const int per = (K + kNormaliseBlock - 1) / kNormaliseBlock;
+    const int lo = min(K, tid * per), hi = min(K, lo + per);
+    int mine = 0, created = 0;
+    for (int k = lo; k < hi; ++k) {
+        const int was = P.snap[k], now = P.counts[k];
+        mine += (was > 0 && now == 0);
+        created += (was == 0 && now > 0);
+    }
+    int incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int up = __shfl_up(incl, off);
+        if (lane >= off) incl += up;
+    }
+    if (lane == 63) s_part[wave] = incl;
+    if (created) atomicAdd(&s_created, created);
+    __syncthreads();
+    int run = incl - mine;
+    for (int w = 0; w < wave; ++w) run += s_part[w];
+    for (int k = lo; k < hi; ++k) {
+        before[k] = run;
+        run += (P.snap[k] > 0 && P.counts[k] == 0);
+    }
+    if (hi == K && lo < K) before[K] = run;   // (the owner of the last slot)
+    __syncthreads();
+    const int removed = K > 0 ? before[K] : 0;
+    const int size = K - removed;
+    // the ids of the vanished groups retire (mixture.hpp:481-497) before any
+    // slot is overwritten
+    for (int k = lo; k < hi; ++k)
+        if (before[k + 1] != before[k]) P.g2p[P.p2g[k]] = -1;
+    // The i-th removal (descending slots, i = vanished groups behind it)
+    // pulls in whatever sits in slot K - 1 - i at that time: that slot's own
+    // group if it survives, else what THAT slot pulled in at its own, earlier
+    // removal.  A vacated slot in front of the new end follows this chain to
+    // the survivor it ends up with.
+    for (int k = lo; k < min(hi, size); ++k)
+        if (before[k + 1] != before[k]) {
+            int t = k;
+            do {
+                t = K - 1 - (removed - before[t + 1]);
+            } while (before[t + 1] != before[t]);
+            moves[atomicAdd(&s_moves, 1)] = int2{k, t};
+        }
+    __syncthreads();
+    const int n_moves = s_moves;
+    // Packed_::packed_remove for every such pair, all objects
+    for (int m = tid; m < n_moves; m += kNormaliseBlock) {
+        const int dst = moves[m].x, src = moves[m].y;
+        P.counts[dst] = P.counts[src];
+        const uint32_t gid = P.p2g[src];
+        P.p2g[dst] = gid;
+        P.g2p[gid] = dst;
+    }
+    for (int f = 0; f < P.F; ++f) {
+        const SlaveView & s = P.feat[f];
+        const int width = is_cat(s.kind) ? s.dim : 1;
+        for (int e = tid; e < n_moves * width; e += kNormaliseBlock) {
+            const int dst = moves[e / width].x, src = moves[e / width].y;
+            const int v = e % width;
+            if (is_cat(s.kind)) {
+                s.cnt[(size_t)dst * s.dim + v] = s.cnt[(size_t)src * s.dim + v];
+                s.S[(size_t)v * s.cap + dst] = s.S[(size_t)v * s.cap + src];
+            }
+            if (v == 0) {
+                s.i0[dst] = s.i0[src]; s.i1[dst] = s.i1[src];
+                s.f0[dst] = s.f0[src]; s.f1[dst] = s.f1[src];
+                s.c0[dst] = s.c0[src]; s.c1[dst] = s.c1[src];
+                s.c2[dst] = s.c2[src]; s.c3[dst] = s.c3[src];
+            }
+        }
+    }
+    if (tid == 0) {
+        const int n_created = s_created;
+        P.dev->k_new = size;
+        P.dev->created = n_created;
+        P.dev->removed = removed;
+        P.dev->K = size + n_created;
+        P.dev->first_new_global = P.dev->global_size;
+        P.dev->global_size += (uint32_t)n_created;
+        P.dev->nonempty = size + n_created - P.n_empty;
     }
 }
 
@@ -606,7 +751,13 @@ struct SweepParams {
     // global id, and old_packed / new_packed of the open batch
     const uint32_t * sorted_rows;
     const uint32_t * assign_pos;
+    // non-null: the group count of record is dev->K (K above is then only
+    // an upper bound the host sized its launches and buffers with)
+    const DevState * dev;
 };
+__device__ __forceinline__ int sweep_K(const SweepParams & P) {
+    return P.dev ? P.dev->K : P.K;
+}
 
 // the clustering model's score of the row's own group, which keeps
 // `remaining` >= 1 members once the row is out
@@ -770,7 +921,7 @@ struct RowScorer {
         g = P.g2p[global_id];
         const int n_g = P.counts[g];
         singleton = (n_g == 1);
-        Kl = P.K - singleton;
+        Kl = sweep_K(P) - singleton;
 #pragma unroll kUnroll
         for (int f = 0; f < nf(); ++f) {
             x[f] = P.values[f][row];
@@ -788,7 +939,7 @@ struct RowScorer {
             s_own = s;
         } else {
             // slot g holds what was the last group (per-lane index: plain loads)
-            const int src = P.K - 1;
+            const int src = sweep_K(P) - 1;
             float s = P.base_single[src];
 #pragma unroll kUnroll
             for (int f = 0; f < nf(); ++f) {
@@ -839,7 +990,7 @@ __global__ __launch_bounds__(kBlock) void k_sweep_sample(SweepParams P) {
     __syncthreads();
     const float ea = u2f(g_tables_dev.exp_ab[0]);
     const float eb = u2f(g_tables_dev.exp_ab[1]);
-    const int K = P.K;
+    const int K = sweep_K(P);
 
     const size_t stride = (size_t)gridDim.x * kBlock;
     const size_t n_items = P.row_list ? (size_t)*P.row_list_count
@@ -991,7 +1142,7 @@ __device__ __forceinline__ void program_score_block(
         const SweepParams & P, const ScoreProgram & prog,
         const uint32_t (&xv)[kMaxOps], int k0, int g, float s_own,
         float (&s)[kProgramBlock]) {
-    const int K = P.K;
+    const int K = sweep_K(P);
 #pragma unroll
     for (int j = 0; j < kProgramBlock; ++j) s[j] = as_uniform(P.base)[k0 + j];
 #pragma unroll
@@ -1037,7 +1188,7 @@ __global__ __launch_bounds__(kBlock) void k_sweep_program(
     __syncthreads();
     const float ea = u2f(g_tables_dev.exp_ab[0]);
     const float eb = u2f(g_tables_dev.exp_ab[1]);
-    const int K = P.K;
+    const int K = sweep_K(P);
     const size_t stride = (size_t)gridDim.x * kBlock;
     const size_t n_items = P.row_end - P.row_begin;
     const size_t n_round = (n_items + 63) / 64 * 64;
@@ -1168,7 +1319,7 @@ __global__ __launch_bounds__(kBlock) void k_rows_wave(SweepParams P) {
     __syncthreads();
     const float ea = u2f(g_tables_dev.exp_ab[0]);
     const float eb = u2f(g_tables_dev.exp_ab[1]);
-    const int K = P.K;
+    const int K = sweep_K(P);
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     float * sl = wave_lds + (size_t)wave * ((K + 63) & ~63);
@@ -1287,7 +1438,7 @@ __global__ __launch_bounds__(kBlock) void k_chain_rows(
     const float ea = u2f(g_tables_dev.exp_ab[0]);
     const float eb = u2f(g_tables_dev.exp_ab[1]);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int K = P.K;
+    const int K = sweep_K(P);
     const int nf = NF > 0 ? NF : P.F;
     const float shift = P.scalars->shift;
     float * sc = chain_lds;
@@ -1508,7 +1659,7 @@ __global__ __launch_bounds__(kBlock) void k_vs_prepare(
     const uint32_t x = blockIdx.x;
     SlaveView v = P.feat[0];
     v.kind = KIND;
-    const int K = P.K;
+    const int K = sweep_K(P);
     const float lf = KIND == DIST_GP ? fast_log_factorial(x) : 0.f;
     float * la = T.LA + (size_t)x * T.Kpad;
     float * lb = T.LB + (size_t)x * T.Kpad;
@@ -1878,7 +2029,7 @@ void k_vs_sample(
     const bool skip_b = !band && n_band_ids != 0 && T.band_mode[x] != 0;
     SlaveView v = P.feat[0];
     v.kind = KIND;
-    const int K = P.K;
+    const int K = sweep_K(P);
     const float shift = P.scalars->shift;
     const float M = T.M[x], mB = T.mB[x];
     const int amax = T.argmax[x];
@@ -2054,7 +2205,7 @@ void k_vs_stream(
     if (n == 0) return;
     SlaveView v = P.feat[0];
     v.kind = KIND;
-    const int K = P.K;
+    const int K = sweep_K(P);
     const float shift = P.scalars->shift;
     const float lf = KIND == DIST_GP ? fast_log_factorial(x) : 0.f;
 
@@ -2285,7 +2436,7 @@ __global__ __launch_bounds__(kVsApplyBlock) void k_vs_apply(
         uint32_t nvals, int refresh_cells, int sole_owner,
         int32_t * __restrict__ stage) {
     extern __shared__ int vs_lds[];
-    const int K = P.K;
+    const int K = sweep_K(P);
     int * delta = vs_lds;                 // [K]
     int * hist = vs_lds + K;              // [K]           (SORT)
     int * part = hist + K;                // [kVsApplyBlock / 64]  (SORT)
@@ -2415,7 +2566,7 @@ __global__ __launch_bounds__(kVsApplyBlock) void k_vs_apply_mixed(
         const uint32_t * __restrict__ p2g, uint32_t * __restrict__ assign_pos,
         int refresh_cells, int32_t * __restrict__ stage) {
     extern __shared__ int vs_lds[];
-    const int K = P.K;
+    const int K = sweep_K(P);
     int * delta = vs_lds;                 // [K]
     if (chunks[blockIdx.x].x != kVsMixedChunk) return;   // k_vs_apply's
     const uint32_t pos = chunks[blockIdx.x].pos;
@@ -2474,7 +2625,8 @@ __global__ __launch_bounds__(kVsReduceGroups * kVsReduceSlices)
 void k_vs_reduce(StatImage img, const int32_t * __restrict__ stage,
                  const VsTile * __restrict__ chunks, uint32_t n_chunks, int K,
                  uint32_t nvals, unsigned long long * host_pairs,
-                 unsigned int seq) {
+                 unsigned int seq, const DevState * dev) {
+    if (dev) K = dev->K;   // (see SweepParams::dev)
     __shared__ int s_a[kVsReduceSlices][kVsReduceGroups];
     __shared__ int s_b[kVsReduceSlices][kVsReduceGroups];
     const int kk = threadIdx.x % kVsReduceGroups;

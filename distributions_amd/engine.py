@@ -305,6 +305,12 @@ class ShardedGibbs(object):
             self.backend.sweep_sharded(self._comm, n_batches, batch_rows,
                                        seed_state, draw_base)
             return
+        if not self.collective and hasattr(self.backend, "sweep"):
+            # one rank, no exchange: the library's own loop (which queues the
+            # whole pass without a host round trip where it can)
+            self.backend.sweep(0, self.n_local, batch_rows, seed_state,
+                               draw_base)
+            return
         for b in range(n_batches):
             r0 = min(self.n_local, b * batch_rows)
             r1 = min(self.n_local, r0 + batch_rows)

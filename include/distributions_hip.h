@@ -394,8 +394,10 @@ size_t dist_gibbs_global_size(const dist_gibbs_t * g);
  * "running_sums_min_tiles" = launches of at least this many value tiles use
  * the per-value running sums and band tiles (default 2048);
  * "value_stream" = 0 (per-value tables always), 1 (auto: the table-free
- * kernel where a value has about one tile per batch), 2 (always).  None
- * changes a result. */
+ * kernel where a value has about one tile per batch), 2 (always);
+ * "device_normalise" = 1 (default: sweeps that stay on the value-sorted path
+ * with integer statistics normalise the group set on the device and run
+ * without a host round trip per batch) or 0.  None changes a result. */
 int dist_gibbs_set_option(dist_gibbs_t * g, const char * name, int value);
 /* how many batches each score+sample kernel has served */
 int dist_gibbs_path_counts(const dist_gibbs_t * g, uint64_t * value_sorted,
@@ -404,8 +406,9 @@ int dist_gibbs_path_counts(const dist_gibbs_t * g, uint64_t * value_sorted,
  * kernel, through the other kernels, launches with band tiles on, launches
  * with running sums on, values whose arg-max rows had their own tile in the
  * last value-sorted launch, rows that launch handed to the wave-per-row
- * kernel, value-sorted batches that took the table-free kernel (first
- * min(n, 7) entries are written) */
+ * kernel, value-sorted batches that took the table-free kernel, batches
+ * whose group set the device normalised itself (first min(n, 8) entries
+ * are written) */
 int dist_gibbs_debug_counts(dist_gibbs_t * g, uint64_t * out, size_t n);
 /* HIP-event time (ms) and launch count of the score+sample kernel since the
  * last reset, measured on the engine's stream */

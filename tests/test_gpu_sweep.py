@@ -165,6 +165,53 @@ def test_group_creation_and_removal(config, mode, empty):
     assert_same_state(orc, gpu, "dynamic sequential")
 
 
+@pytest.mark.parametrize("config,dim", [("dd", 16), ("dd_skew", 24), ("bb", None),
+                                        ("dpd", 40), ("bnb", None)])
+@pytest.mark.parametrize("stream", [0, 2])
+@pytest.mark.parametrize("empty", [1, 4])
+def test_device_side_normalisation_under_group_churn(config, dim, stream,
+                                                     empty):
+    """Sweeps that stay on the value-sorted path normalise the group set on
+    the device (k_normalise) and are queued without a host round trip.  Many
+    small groups and a large alpha make groups die and empty groups fill in
+    nearly every batch, several per batch: the device-normalised engine, the
+    host-normalised engine and the oracle agree bit for bit, ids included."""
+    from distributions_amd import engine
+    n, k = 6000, 900
+    osh, gsh, vals, assign = workloads.make(config, n, k, dim=dim)
+    orc = ol.OracleMixture(30.0, 0.6, osh)
+    orc.init_from_assignments(vals, assign, k, empty)
+    engines = []
+    for normalise in (1, 0):
+        gpu = engine.Gibbs(30.0, 0.6, gsh)
+        gpu.set_option("value_sorted", 2)
+        gpu.set_option("value_stream", stream)
+        gpu.set_option("device_normalise", normalise)
+        gpu.load_rows(vals, assign, k, empty)
+        engines.append(gpu)
+    seed = 4242
+    st = ol.oracle().orc_rng_seed(seed)
+    sizes = []
+    for sweep, batch in enumerate([1500, 1000, 6000, 700]):
+        for b in range(0, n, batch):
+            orc.gibbs_batch(b, min(n, b + batch), st, sweep * n)
+        sizes.append(len(orc))
+        for gpu in engines:
+            gpu.sweep(0, n, batch, seed, draw_base=sweep * n)
+            assert_same_state(orc, gpu, "%s sweep %d" % (config, sweep))
+            for slot in range(0, len(orc), 37):
+                assert gpu.core.packed_to_global(slot) == \
+                    orc.packed_to_global(slot)
+            assert gpu.core.global_size() == orc.global_size()
+    assert len(set(sizes)) > 1                    # the group set did change
+    assert engines[0].core.debug_counts()["device_normalised"] > 0
+    assert engines[1].core.debug_counts()["device_normalised"] == 0
+    # and the host-driven paths pick the state up where the device left it
+    st2 = orc.gibbs_sequential(0, 300, st)
+    assert engines[0].sweep_sequential(0, 300, st) == st2
+    assert_same_state(orc, engines[0], "sequential after device sweeps")
+
+
 def test_randomised_configurations():
     """random feature lists, group counts, hyper-parameters, batch sizes and
     seeds: every sweep bit-exact against the oracle"""
@@ -213,6 +260,7 @@ def test_randomised_configurations():
         gpu = engine.Gibbs(alpha, d, feats_g)
         gpu.set_option("value_sorted", int(rng.choice([0, 1, 2])))
         gpu.set_option("value_stream", int(rng.choice([0, 1, 2])))
+        gpu.set_option("device_normalise", int(rng.choice([0, 1])))
         gpu.load_rows(vals, assign, k, empty)
         seed = int(rng.integers(1, 2 ** 31))
         st = L.orc_rng_seed(seed)
