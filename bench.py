@@ -77,6 +77,9 @@ def parse():
     ap.add_argument("--value-stream", type=int, default=1,
                     help="the table-free value-sorted kernel: 0 never, "
                          "1 auto, 2 always")
+    ap.add_argument("--device-normalise", type=int, default=0,
+                    help="1: the group set is normalised on the device, no "
+                         "host round trip per sub-sweep (0: the default)")
     ap.add_argument("--other-batches", default="65536",
                     help="comma-separated sub-sweep sizes timed besides "
                          "--batch (a few steps each, reported in "
@@ -391,6 +394,7 @@ def run_rank(args):
         g = engine.Gibbs(args.alpha, args.d, shareds)
         g.set_option("value_sorted", args.value_sorted)
         g.set_option("value_stream", args.value_stream)
+        g.set_option("device_normalise", args.device_normalise)
         initial = assign.clone()   # the engine updates `assign` in place
         g.load_rows_torch(columns, assign, k, 1, row_offset=row_offset)
         sharded = engine.ShardedGibbs(

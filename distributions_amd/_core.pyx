@@ -194,6 +194,8 @@ cdef extern from "distributions_hip.h" nogil:
     int dist_gibbs_global_to_packed(const dist_gibbs_t *, uint32_t, uint32_t *)
     size_t dist_gibbs_global_size(const dist_gibbs_t *)
     int dist_gibbs_debug_counts(dist_gibbs_t *, uint64_t *, size_t)
+    int dist_gibbs_sharded_device_normalise_ok(const dist_gibbs_t *, size_t,
+                                               size_t, int *)
     int dist_gibbs_kernel_stats(dist_gibbs_t *, double *, uint64_t *,
                                 uint64_t *, int)
     int dist_gibbs_set_option(dist_gibbs_t *, const char *, int)
@@ -1048,6 +1050,12 @@ cdef class GibbsEngine:
 
     def global_size(self):
         return dist_gibbs_global_size(self.ptr)
+
+    def sharded_device_normalise_ok(self, size_t n_batches, size_t batch_rows):
+        cdef int ok = 0
+        check(dist_gibbs_sharded_device_normalise_ok(self.ptr, n_batches,
+                                                     batch_rows, &ok))
+        return bool(ok)
 
     def debug_counts(self):
         """dict of the engine's path diagnostics (dist_gibbs_debug_counts)"""

@@ -903,7 +903,8 @@ struct Gibbs {
     DeviceBuf<DevState> dev_state;
     DeviceBuf<int32_t> snap_counts;   // group sizes at batch entry
     bool async_active = false;
-    int device_normalise_mode = 1;    // 0 never, 1 where it applies
+    int device_normalise_mode = 0;    // 0 never (default), 1 where it applies
+    bool sharded_device_normalise = false;   // the ranks agreed on it
     uint64_t async_batches = 0;
     std::vector<hipEvent_t> ev_pool;
 
@@ -1402,28 +1403,16 @@ struct Gibbs {
         hipLaunchKernelGGL(k_vs_scatter, sort_grid, dim3(kBlock), 0, stream(),
                            values[0], r0, n, nv, cursor.p, c->sorted_rows.p);
         HIP_CHECK(hipGetLastError());
-        // A value's rows are kept sorted by group (k_vs_apply), so its j-th
-        // tile starts its total at the running sum of about the j-th part of
-        // the vector: early tiles run a nearly full first pass, late ones
-        // almost none.  Consecutive tile ids share a workgroup, ids 4 apart a
-        // SIMD: list a value's tiles four from the front, four from the
-        // back, ... so that every SIMD gets long and short ones alike.
+        // (Listing a value's tiles so that every SIMD gets tiles with long
+        // and with short first passes alike -- four from the front, four from
+        // the back -- was measured: 70.9 against 69.7 us per launch on C2.
+        // Consecutive tiles of one value share their scalar-cache lines.)
         std::vector<VsTile> tiles;
-        for (uint32_t x = 0; x < nv; ++x) {
-            const uint32_t T = (h[x] + 64 * kVsR - 1) / (64 * kVsR);
-            uint32_t front = 0, back = T;
-            bool from_front = true;
-            while (front < back) {
-                for (int q = 0; q < 4 && front < back; ++q) {
-                    const uint32_t j = from_front ? front++ : --back;
-                    const uint32_t off = j * 64 * kVsR;
-                    tiles.push_back(VsTile{x, start[x] + off,
-                                           std::min<uint32_t>(64 * kVsR,
-                                                              h[x] - off)});
-                }
-                from_front = !from_front;
-            }
-        }
+        for (uint32_t x = 0; x < nv; ++x)
+            for (uint32_t off = 0; off < h[x]; off += 64 * kVsR)
+                tiles.push_back(VsTile{x, start[x] + off,
+                                       std::min<uint32_t>(64 * kVsR,
+                                                          h[x] - off)});
         c->n_tiles = (uint32_t)tiles.size();
         c->tiles.upload(tiles.data(), tiles.size());
         for (uint32_t x = 0; x < nv; ++x) c->n_values_present += h[x] != 0;
@@ -1999,8 +1988,11 @@ struct Gibbs {
             push(a.i1[f], k);
             push(a.cnt[f], k * feats[f]->dim());
         }
-        unsigned long long * pairs = pairs_buffer();
-        pairs_ticket = ++publish_ticket;
+        unsigned long long * pairs = nullptr;
+        if (!async_active) {   // the host will want the new group sizes
+            pairs = pairs_buffer();
+            pairs_ticket = ++publish_ticket;
+        }
         LAUNCH(k_add_words, off, seg, delta_dev, off, clear ? 1 : 0, pairs,
                pairs_ticket);
         // the order-dependent statistics (NICH, GP log_prod) are not in the
@@ -2229,13 +2221,14 @@ struct Gibbs {
             tracker.g2p[i] = (int32_t)maps[maps_pcap + i];
         maps_dirty = false;   // the device's copy IS the state
     }
-    void sweep_async(size_t r0, size_t r1, size_t batch, uint32_t seed,
-                     uint64_t draw_base) {
-        const size_t n_batches = (r1 - r0 + batch - 1) / batch;
+    // Everything a device-normalised run of `n_batches` batches may grow
+    // into is reserved up front (growing a buffer synchronises), the state
+    // the kernels read is put on the device, and K() becomes the bound.
+    hipEvent_t async_own0 = nullptr, async_own1 = nullptr;
+    std::vector<size_t> async_rows;   // rows of each batch sampled (timing)
+    void async_begin(size_t n_batches) {
         const int K0 = K();
         const int bound = K0 + (int)n_batches * py.n_empty;
-        // room for everything the device may grow into, before the first
-        // launch (growing a buffer synchronises)
         py.reserve(bound);
         for (auto & s : feats) s->reserve(bound);
         if ((size_t)bound > base.cap || (size_t)bound > base_single.cap) {
@@ -2258,7 +2251,7 @@ struct Gibbs {
                                  (size_t)K0 * 4, hipMemcpyDeviceToDevice,
                                  stream()));
         if (!base_valid) {   // (with the true group count, before K() bounds)
-            SweepParams P0 = params(r0, r0, seed, draw_base);
+            SweepParams P0 = params(0, 0, 0, 0);
             prepare(P0, false);
         }
         while (ev_pool.size() < 2 * n_batches) {
@@ -2266,48 +2259,77 @@ struct Gibbs {
             HIP_CHECK(hipEventCreate(&e));
             ev_pool.push_back(e);
         }
-        hipEvent_t own0 = ev0, own1 = ev1;
-        // from here on K() is the bound
-        py.counts.resize((size_t)bound, 0);
+        async_own0 = ev0;
+        async_own1 = ev1;
+        async_rows.clear();
+        py.counts.resize((size_t)bound, 0);   // from here on K() is the bound
         async_active = true;
         pairs_ticket = 0;
-        size_t done = 0;
-        try {
-            for (size_t b = r0; b < r1; b += batch, ++done) {
-                const size_t e = std::min(r1, b + batch);
-                ev0 = ev_pool[2 * done];
-                ev1 = ev_pool[2 * done + 1];
-                batch_sample(b, e, seed, draw_base);
-                DIST_REQUIRE(batch_value_sorted,
-                             "internal: asynchronous sweep left its path");
-                apply_ints(live_image());
-                batch_finish_device();
-                async_batches += 1;
-            }
-        } catch (...) {
-            ev0 = own0;
-            ev1 = own1;
-            async_active = false;
-            timing_pending = false;
+    }
+    // sample one batch of a device-normalised run (its events from the pool)
+    void async_sample(size_t b, size_t e, uint32_t seed, uint64_t draw_base) {
+        const size_t i = async_rows.size();
+        ev0 = ev_pool[2 * i];
+        ev1 = ev_pool[2 * i + 1];
+        batch_sample(b, e, seed, draw_base);
+        DIST_REQUIRE(e == b || batch_value_sorted,
+                     "internal: device-normalised run left its path");
+        async_rows.push_back(e - b);
+        async_batches += 1;
+    }
+    // back to host-driven operation; `failed`: on the way out of an error
+    void async_end(bool failed) {
+        ev0 = async_own0;
+        ev1 = async_own1;
+        timing_pending = false;
+        if (failed) {
             batch_open = false;
             (void)hipStreamSynchronize(stream());
+            async_active = false;
             try { pull_host_state(); } catch (...) {}
-            throw;
+            return;
         }
-        ev0 = own0;
-        ev1 = own1;
         async_active = false;
-        timing_pending = false;
         pull_host_state();
-        for (size_t i = 0; i < done; ++i) {
+        for (size_t i = 0; i < async_rows.size(); ++i) {
+            if (!async_rows[i]) continue;
             float ms = 0.f;
             HIP_CHECK(hipEventElapsedTime(&ms, ev_pool[2 * i],
                                           ev_pool[2 * i + 1]));
             kernel_ms += ms;
             kernel_launches += 1;
-            kernel_rows += std::min(r1, r0 + (i + 1) * batch)
-                           - (r0 + i * batch);
+            kernel_rows += async_rows[i];
         }
+    }
+    void sweep_async(size_t r0, size_t r1, size_t batch, uint32_t seed,
+                     uint64_t draw_base) {
+        async_begin((r1 - r0 + batch - 1) / batch);
+        try {
+            for (size_t b = r0; b < r1; b += batch) {
+                async_sample(b, std::min(r1, b + batch), seed, draw_base);
+                apply_ints(live_image());
+                batch_finish_device();
+            }
+        } catch (...) {
+            async_end(true);
+            throw;
+        }
+        async_end(false);
+    }
+    // the sharded loop (dist_gibbs_sweep_sharded): rank-local conditions; the
+    // ranks must agree before they rely on it (engine.ShardedGibbs)
+    bool async_eligible_sharded(size_t n_batches, size_t batch) const {
+        if (device_normalise_mode == 0 || cluster != 0 || F() != 1) return false;
+        if (!n_batches || any_float_stats() || py.n_empty < 1) return false;
+        for (size_t b = 0; b < n_batches; ++b) {
+            const size_t r0 = std::min(n_rows, b * batch);
+            const size_t r1 = std::min(n_rows, r0 + batch);
+            if (r1 > r0 && !use_value_sorted(r1 - r0)) return false;
+            if (r1 - r0 < batch) break;   // (the rest are empty)
+        }
+        const size_t bound = (size_t)K() + n_batches * (size_t)py.n_empty;
+        if (normalise_lds((int)bound) > 150 * 1024) return false;
+        return bound * 4 <= 144 * 1024;
     }
 
     void sweep(size_t r0, size_t r1, size_t batch, uint32_t seed,
@@ -3221,26 +3243,41 @@ int dist_gibbs_sweep_sharded(dist_gibbs_t * g, dist_comm_t * c,
         DIST_REQUIRE(!e.any_float_stats(),
                      "order-dependent statistics are exchanged as rows "
                      "(dist_gibbs_batch_moves_dev / replay_ordered_dev)");
-        for (size_t b = 0; b < n_batches; ++b) {
-            const size_t r0 = std::min(e.n_rows, b * batch_rows);
-            const size_t r1 = std::min(e.n_rows, r0 + batch_rows);
-            e.batch_sample(r0, r1, seed_state, draw_base);
-            const size_t words = e.stat_words();
-            // the exchange buffer is zeroed once; k_add_words clears what it
-            // consumes, so it is all zero again before every batch
-            if (words > e.delta_image.cap || !e.delta_image.p) {
-                e.delta_image.reserve(grow_capacity(words), 0);
-                HIP_CHECK(hipMemsetAsync(e.delta_image.p, 0,
-                                         e.delta_image.cap * 4, stream()));
+        // the ranks agreed that every one of them can run this pass with the
+        // group set normalised on the device (engine.ShardedGibbs): no host
+        // round trip per batch on any of them
+        const bool on_device = e.sharded_device_normalise
+                               && e.async_eligible_sharded(n_batches,
+                                                           batch_rows);
+        if (on_device) e.async_begin(n_batches);
+        try {
+            for (size_t b = 0; b < n_batches; ++b) {
+                const size_t r0 = std::min(e.n_rows, b * batch_rows);
+                const size_t r1 = std::min(e.n_rows, r0 + batch_rows);
+                if (on_device) e.async_sample(r0, r1, seed_state, draw_base);
+                else e.batch_sample(r0, r1, seed_state, draw_base);
+                const size_t words = e.stat_words();
+                // the exchange buffer is zeroed once; k_add_words clears what
+                // it consumes, so it is all zero again before every batch
+                if (words > e.delta_image.cap || !e.delta_image.p) {
+                    e.delta_image.reserve(grow_capacity(words), 0);
+                    HIP_CHECK(hipMemsetAsync(e.delta_image.p, 0,
+                                             e.delta_image.cap * 4, stream()));
+                }
+                e.batch_delta(e.delta_image.p, true);
+                // in place, on the engine's stream: no hop to another stream
+                RCCL_CHECK(rccl().all_reduce(e.delta_image.p, e.delta_image.p,
+                                             words, ncclInt32, ncclSum,
+                                             c->comm, stream()));
+                e.batch_apply_delta(e.delta_image.p, true);
+                if (on_device) e.batch_finish_device();
+                else e.batch_finish();
             }
-            e.batch_delta(e.delta_image.p, true);
-            // in place, on the engine's stream: no hop to another stream
-            RCCL_CHECK(rccl().all_reduce(e.delta_image.p, e.delta_image.p,
-                                         words, ncclInt32, ncclSum, c->comm,
-                                         stream()));
-            e.batch_apply_delta(e.delta_image.p, true);
-            e.batch_finish();
+        } catch (...) {
+            if (on_device) e.async_end(true);
+            throw;
         }
+        if (on_device) e.async_end(false);
         sync();
     });
 }
@@ -3349,6 +3386,13 @@ int dist_gibbs_global_to_packed(const dist_gibbs_t * g, uint32_t global,
 size_t dist_gibbs_global_size(const dist_gibbs_t * g) {
     return g->impl->tracker.g2p.size();
 }
+int dist_gibbs_sharded_device_normalise_ok(const dist_gibbs_t * g,
+                                           size_t n_batches,
+                                           size_t batch_rows, int * ok_out) {
+    return guarded([&] {
+        *ok_out = g->impl->async_eligible_sharded(n_batches, batch_rows) ? 1 : 0;
+    });
+}
 int dist_gibbs_set_option(dist_gibbs_t * g, const char * name, int value) {
     return guarded([&] {
         const std::string key(name);
@@ -3362,9 +3406,17 @@ int dist_gibbs_set_option(dist_gibbs_t * g, const char * name, int value) {
         } else if (key == "device_normalise") {
             // sweeps whose batches all take the value-sorted path normalise
             // the group set on the device (no host round trip per batch):
-            // 0 never, 1 where it applies
+            // 0 never (default: on one GPU the host's look at the group
+            // sizes hides behind the kernels and costs less than the extra
+            // launch), 1 where it applies
             DIST_REQUIRE(value == 0 || value == 1, "device_normalise: 0 or 1");
             g->impl->device_normalise_mode = value;
+        } else if (key == "sharded_device_normalise") {
+            // dist_gibbs_sweep_sharded may normalise on the device: set on
+            // EVERY rank or on none (engine.ShardedGibbs agrees on it)
+            DIST_REQUIRE(value == 0 || value == 1,
+                         "sharded_device_normalise: 0 or 1");
+            g->impl->sharded_device_normalise = value != 0;
         } else if (key == "running_sums_min_tiles") {
             // launches of at least this many value tiles start each tile's
             // total from the per-value running sums (a tuning knob: results

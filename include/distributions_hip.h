@@ -388,6 +388,12 @@ int dist_gibbs_global_to_packed(const dist_gibbs_t * g, uint32_t global,
                                 uint32_t * packed_out);
 /* MixtureIdTracker::global_size (mixture.hpp:517): ids handed out so far */
 size_t dist_gibbs_global_size(const dist_gibbs_t * g);
+/* whether THIS rank could run a sharded pass of n_batches batches of
+ * batch_rows rows with the group set normalised on the device; the option
+ * "sharded_device_normalise" may be set to 1 only when every rank says yes */
+int dist_gibbs_sharded_device_normalise_ok(const dist_gibbs_t * g,
+                                           size_t n_batches,
+                                           size_t batch_rows, int * ok_out);
 /* options: "value_sorted" = 0 (generic kernel only), 1 (auto, default),
  * 2 (value-sorted kernel whenever the feature list allows it);
  * "sequential_chain" = 1 (device-resident chain kernel, default) or 0;
@@ -395,9 +401,11 @@ size_t dist_gibbs_global_size(const dist_gibbs_t * g);
  * the per-value running sums and band tiles (default 2048);
  * "value_stream" = 0 (per-value tables always), 1 (auto: the table-free
  * kernel where a value has about one tile per batch), 2 (always);
- * "device_normalise" = 1 (default: sweeps that stay on the value-sorted path
- * with integer statistics normalise the group set on the device and run
- * without a host round trip per batch) or 0.  None changes a result. */
+ * "device_normalise" = 1 (sweeps that stay on the value-sorted path with
+ * integer statistics normalise the group set on the device and run without a
+ * host round trip per batch) or 0 (default); "sharded_device_normalise" =
+ * the same for dist_gibbs_sweep_sharded, to be set on every rank or on none.
+ * None changes a result. */
 int dist_gibbs_set_option(dist_gibbs_t * g, const char * name, int value);
 /* how many batches each score+sample kernel has served */
 int dist_gibbs_path_counts(const dist_gibbs_t * g, uint64_t * value_sorted,

@@ -40,6 +40,7 @@ def worker(rank, port, out, config, mode, N):
     packed = torch.from_numpy(assign.view(np.int32).copy()).to(dev)
     gpu = engine.Gibbs(1.0, 0.2, gsh)
     gpu.set_option("value_sorted", mode)
+    gpu.set_option("device_normalise", 1)
     gpu.load_rows_torch(cols, packed.clone(), K, 2)
     sharded = engine.ShardedGibbs(gpu.core, N, 0, device=dev,
                                   force_collective=True,
@@ -50,6 +51,8 @@ def worker(rank, port, out, config, mode, N):
         sharded.sweep(BATCH, _core.rng_seed(SEED), draw_base=s * N)
     torch.cuda.synchronize()
     np.save(os.path.join(out, "native.npy"), np.array([int(native)]))
+    np.save(os.path.join(out, "on_device.npy"),
+            np.array([gpu.core.debug_counts()["device_normalised"]]))
     np.save(os.path.join(out, "assign.npy"), gpu.assignments())
     np.save(os.path.join(out, "counts.npy"), gpu.counts())
     np.save(os.path.join(out, "groups.npy"), np.stack([
@@ -81,6 +84,10 @@ def test_native_loop_equals_oracle(tmp_path, config, mode, N):
     # and the native loop must decline them (torch.distributed path is used)
     ordered = any(s.kind in (ol.NICH, ol.GP) for s in osh)
     assert native == (not ordered)
+    # the value-sorted single-feature passes also normalise the group set on
+    # the device (no host round trip between the all-reduces)
+    on_device = int(np.load(tmp_path / "on_device.npy")[0])
+    assert (on_device > 0) == (native and len(osh) == 1 and mode == 2)
     m = ol.OracleMixture(1.0, 0.2, osh)
     m.init_from_assignments(vals, assign, K, 2)
     for s in range(SWEEPS):
