@@ -11,7 +11,7 @@
 using namespace distributions_hip;
 
 int main() {
-    typedef DirichletDiscrete Model;
+    typedef DirichletDiscrete<> Model;
     rng_t rng = dist_rng_seed(1);
 
     Model::Shared shared;

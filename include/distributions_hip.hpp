@@ -27,7 +27,22 @@
 
 namespace distributions_hip {
 
-typedef uint32_t rng_t;   // minstd_rand0 state (random_fwd.hpp:34)
+// rng_t (random_fwd.hpp:34: std::default_random_engine == minstd_rand0 in
+// libstdc++): the engine state, advanced by the library (dist_rng_next).  A
+// default-constructed engine is seeded with 1 like the reference's; it also
+// satisfies UniformRandomBitGenerator, so <random> distributions drawing from
+// it give what they give over std::minstd_rand0.
+struct rng_t {
+    typedef uint32_t result_type;
+    uint32_t state;
+    rng_t() : state(1u) {}
+    rng_t(uint32_t engine_state) : state(engine_state) {}   // dist_rng_seed
+    void seed(uint32_t value) { state = dist_rng_seed(value); }
+    static constexpr result_type min() { return 1u; }
+    static constexpr result_type max() { return 2147483646u; }
+    result_type operator()() { return dist_rng_next(&state); }
+    operator uint32_t() const { return state; }
+};
 
 inline void check(int rc) {
     if (rc != 0) throw std::runtime_error(dist_last_error());
@@ -51,6 +66,30 @@ struct Model {
     struct Shared : dist_shared_t {
         Shared() { memset(static_cast<dist_shared_t *>(this), 0,
                           sizeof(dist_shared_t)); kind = KIND; }
+        // Shared::EXAMPLE() of the reference's models (dd.hpp:78-85 with
+        // `example_dim` categories, bb.hpp:70-75, gp.hpp:75-80, nich.hpp:87-94,
+        // bnb.hpp:79-85); DirichletProcessDiscrete's (dpd.hpp:141-152) needs
+        // storage for its betas: set dim / betas yourself
+        static Shared EXAMPLE(int example_dim = DIST_DD_MAX_DIM) {
+            Shared shared;
+            switch (KIND) {
+            case DIST_DD:
+                shared.dim = example_dim;
+                for (int i = 0; i < example_dim; ++i) shared.alphas[i] = 0.5f;
+                break;
+            case DIST_BB: shared.p[0] = 0.5f; shared.p[1] = 2.0f; break;
+            case DIST_GP: shared.p[0] = 1.0f; shared.p[1] = 1.0f; break;
+            case DIST_NICH:
+                shared.p[0] = 0.0f; shared.p[1] = 1.0f;
+                shared.p[2] = 1.0f; shared.p[3] = 1.0f;
+                break;
+            case DIST_BNB:
+                shared.p[0] = 1.0f; shared.p[1] = 1.0f; shared.p[2] = 1.0f;
+                break;
+            default: break;
+            }
+            return shared;
+        }
     };
 
     struct Group {
@@ -106,7 +145,13 @@ struct Model {
         Mixture(const Mixture &) = delete;
         Mixture & operator=(const Mixture &) = delete;
 
-        // groups().push_back(group) / groups().size() / groups(i)
+        // groups().resize(n) / groups()[i] / groups().push_back(group)
+        // BEFORE init(), as the reference's callers fill a mixture
+        // (benchmarks/mixture.cc:84-100): host-side groups that init() hands
+        // to the device.  Afterwards the statistics live in HBM and
+        // groups(shared, i) returns a copy.
+        std::vector<Group> & groups() { return staged_; }
+        const std::vector<Group> & groups() const { return staged_; }
         void append(const Shared & shared, const Group & group) {
             check(dist_mixture_append(handle(shared), group.words.data()));
         }
@@ -118,6 +163,11 @@ struct Model {
             return g;
         }
         void init(const Shared & shared, rng_t &) {
+            if (!staged_.empty()) {
+                check(dist_mixture_clear(handle(shared)));
+                for (const Group & group : staged_) append(shared, group);
+                staged_.clear();
+            }
             check(dist_mixture_init(handle(shared)));
         }
         void add_group(const Shared & shared, rng_t &) {
@@ -157,16 +207,17 @@ struct Model {
             return out;
         }
         // mixture.hpp:433-438: one score per candidate Shared
-        void score_data_grid(const std::vector<Shared> & shareds,
+        template <class SharedT>   // Shared, or a model's own (EXAMPLE-only)
+        void score_data_grid(const std::vector<SharedT> & shareds,
                              VectorFloat & scores_out, rng_t &) {
-            static_assert(sizeof(Shared) == sizeof(dist_shared_t),
+            static_assert(sizeof(SharedT) == sizeof(dist_shared_t),
                           "Shared adds no members");
             if (shareds.size() != scores_out.size())
                 throw std::invalid_argument("shareds.size() != scores_out.size()");
             if (shareds.empty()) return;
             check(dist_mixture_score_data_grid(
                 handle(shareds[0]),
-                static_cast<const dist_shared_t *>(shareds.data()),
+                reinterpret_cast<const dist_shared_t *>(shareds.data()),
                 shareds.size(), scores_out.data()));
         }
 
@@ -179,14 +230,31 @@ struct Model {
             return ptr_;
         }
         dist_mixture_t * ptr_;
+        std::vector<Group> staged_;
     };
 };
 
-typedef Model<DIST_DD, int> DirichletDiscrete;          // models/dd.hpp (max_dim 256)
+// models/dd.hpp:41-54: DirichletDiscrete<max_dim>; the library holds up to
+// 256 categories whatever max_dim says, which only sizes EXAMPLE()
+template <int max_dim_ = DIST_DD_MAX_DIM>
+struct DirichletDiscrete : Model<DIST_DD, int> {
+    static_assert(max_dim_ >= 1 && max_dim_ <= DIST_DD_MAX_DIM,
+                  "1 <= max_dim <= 256");
+    enum { max_dim = max_dim_ };
+    typedef Model<DIST_DD, int> Base;
+    struct Shared : Base::Shared {
+        static Shared EXAMPLE() {
+            Shared shared;
+            static_cast<Base::Shared &>(shared) = Base::Shared::EXAMPLE(max_dim);
+            return shared;
+        }
+    };
+};
 typedef Model<DIST_BB, bool> BetaBernoulli;              // models/bb.hpp
 typedef Model<DIST_GP, uint32_t> GammaPoisson;           // models/gp.hpp
 typedef Model<DIST_NICH, float> NormalInverseChiSq;      // models/nich.hpp
 typedef Model<DIST_DPD, uint32_t> DirichletProcessDiscrete;  // models/dpd.hpp
+typedef Model<DIST_BNB, uint32_t> BetaNegativeBinomial;      // models/bnb.hpp
 
 // Clustering<int>::PitmanYor (clustering.hpp:58-234)
 struct PitmanYor {
@@ -286,9 +354,49 @@ class MixtureIdTracker {
 // sample_from_scores_overwrite (random.hpp:361-366)
 inline size_t sample_from_scores_overwrite(rng_t & rng, VectorFloat & scores) {
     size_t sample = 0;
-    check(dist_sample_from_scores_overwrite(&rng, scores.size(), scores.data(),
-                                            &sample));
+    check(dist_sample_from_scores_overwrite(&rng.state, scores.size(),
+                                            scores.data(), &sample));
     return sample;
 }
 
 }  // namespace distributions_hip
+
+// ---------------------------------------------------------------------------
+// Opt-in: the reference's own names.  With DISTRIBUTIONS_HIP_AS_DISTRIBUTIONS
+// defined (the forwarding headers under include/compat/distributions/ define
+// it), `namespace distributions` holds everything above plus the templates and
+// helpers a caller of the reference's headers uses around the mixture path --
+// sample_int / sample_unif01 (random.hpp:42-50), vector_zero (vector_math.hpp:31), current_time_us
+// (timers.hpp:35), demangle (common.hpp:122) -- so that a file written against
+// benchmarks/mixture.cc:79-115 compiles with only its include path changed.
+#ifdef DISTRIBUTIONS_HIP_AS_DISTRIBUTIONS
+#include <cxxabi.h>
+#include <sys/time.h>
+
+#include <random>
+
+namespace distributions {
+using namespace distributions_hip;   // NOLINT
+
+inline int sample_int(rng_t & rng, int low, int high) {
+    std::uniform_int_distribution<> sampler(low, high);
+    return sampler(rng);
+}
+inline float sample_unif01(rng_t & rng) { return dist_rng_unif01(&rng.state); }
+inline void vector_zero(size_t size, float * data) {
+    for (size_t i = 0; i < size; ++i) data[i] = 0.f;
+}
+inline int64_t current_time_us() {
+    timeval t;
+    gettimeofday(&t, nullptr);
+    return (int64_t)t.tv_usec + 1000000LL * (int64_t)t.tv_sec;
+}
+inline std::string demangle(const char * name) {
+    int status = 0;
+    char * text = abi::__cxa_demangle(name, nullptr, nullptr, &status);
+    std::string out = (status == 0 && text) ? text : name;
+    free(text);
+    return out;
+}
+}  // namespace distributions
+#endif  // DISTRIBUTIONS_HIP_AS_DISTRIBUTIONS

@@ -29,6 +29,44 @@ def test_shim_example_compiles_and_links():
     assert os.path.exists(EXE)
 
 
+BENCH_EXE = os.path.join(ROOT, "examples", "mixture_bench")
+
+
+def build_bench():
+    """the reference-shaped benchmark: only the include path names this
+    library (include/compat first), no source-level mention of it"""
+    src = os.path.join(ROOT, "examples", "mixture_bench.cc")
+    text = open(src).read()
+    code = "\n".join(line for line in text.splitlines()
+                     if not line.lstrip().startswith("//"))
+    assert "distributions_hip" not in code and "dist_" not in code
+    subprocess.check_call(
+        ["g++", "-std=c++11", "-Wall", "-Werror",
+         "-I" + os.path.join(ROOT, "include", "compat"), src,
+         "-L" + os.path.join(ROOT, "distributions_amd"),
+         "-ldistributions_hip",
+         "-Wl,-rpath," + os.path.join(ROOT, "distributions_amd"),
+         "-o", BENCH_EXE])
+
+
+def test_reference_shaped_benchmark_compiles_with_the_include_path_changed():
+    build_bench()
+    assert os.path.exists(BENCH_EXE)
+
+
+@pytest.mark.gpu
+def test_reference_shaped_benchmark_runs():
+    """benchmarks/mixture.cc:104-115 through the compat headers: every model,
+    1 / 10 / 100 groups; the accumulated scores are finite"""
+    build_bench()
+    lines = subprocess.check_output([BENCH_EXE, "100"], text=True).splitlines()
+    sums = [float(x.split()[1]) for x in lines if x.startswith("checksum")]
+    assert len(sums) == 5 and all(np.isfinite(sums)) and any(sums)
+    rates = [float(x.split()[1]) for x in lines
+             if x and x.split()[0] in ("1", "10", "100")]
+    assert len(rates) == 15 and min(rates) > 0
+
+
 @pytest.mark.gpu
 def test_shim_example_reproduces_the_sequential_chain():
     build()
