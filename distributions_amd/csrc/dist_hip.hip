@@ -866,6 +866,7 @@ struct Gibbs {
     DeviceBuf<int32_t> vs_stage;   // [chunks][K] deltas of the open batch
     DeviceBuf<int> vsBandMode;     // VsTables::band_mode
     DeviceBuf<VsTile> vsBandTile;  // VsTables::band_tile
+    DeviceBuf<unsigned long long> vsStamps;   // diagnostics, see VsTables
     DeviceBuf<ChainResult> chain_result;
     DeviceBuf<int32_t> delta_image;         // dist_gibbs_sweep_sharded
     DeviceBuf<float> own_score;             // k_row_prepass
@@ -1489,14 +1490,23 @@ struct Gibbs {
                                c->n_other);
             HIP_CHECK(hipGetLastError());
             HIP_CHECK(hipEventRecord(self->ev0, stream()));
-            const uint32_t per = kVsSampleBlock / 64;   // tiles per workgroup
+            // a launch that cannot fill the chip spreads out: a wave per
+            // workgroup (no band tiles on such launches)
+            const bool small = !T.band_mode && c->n_tiles < 4096;
+            const uint32_t per =
+                small ? 1 : kVsSampleBlock / 64;   // tiles per workgroup
             // (band tiles first, a whole number of workgroups)
             const uint32_t band_ids =
                 T.band_mode ? (nv + per - 1) / per * per : 0;
-            const dim3 grid((band_ids + c->n_tiles + per - 1) / per),
-                block(kVsSampleBlock);
-            if (c->n_tiles)   // else every row's value lies beyond the table
-                hipLaunchKernelGGL((k_vs_sample<KIND>), grid, block, 0,
+            const dim3 grid((band_ids + c->n_tiles + per - 1) / per);
+            if (c->n_tiles && small)
+                hipLaunchKernelGGL((k_vs_sample<KIND, 64>), grid, dim3(64), 0,
+                                   stream(), *P, T, c->tiles.p, c->n_tiles,
+                                   band_ids, c->sorted_rows.p,
+                                   self->deferred.p, self->deferred_count.p);
+            else if (c->n_tiles)   // else every value lies beyond the table
+                hipLaunchKernelGGL((k_vs_sample<KIND, kVsSampleBlock>), grid,
+                                   dim3(kVsSampleBlock), 0,
                                    stream(), *P, T, c->tiles.p, c->n_tiles,
                                    band_ids, c->sorted_rows.p,
                                    self->deferred.p, self->deferred_count.p);
@@ -1627,13 +1637,29 @@ struct Gibbs {
                             prefix ? vsPB.p : nullptr,
                             bands ? vsBandMode.p : nullptr,
                             bands ? vsBandTile.p : nullptr, c.val_start.p,
-                            nv}};
+                            nv, nullptr}};
+        // DIST_VS_STAMPS=<file>: per-wave phase stamps of every launch (the
+        // last one stays in the file): tools/vs_stamps.py
+        static const char * stamps_path = getenv("DIST_VS_STAMPS");
+        if (stamps_path) {
+            vsStamps.reserve(((size_t)c.n_tiles + 4096) * 6, 0);
+            L.T.stamps = vsStamps.p;
+        }
         switch (feats[0]->sh.kind) {
         case DIST_DD: L.go<DIST_DD>(); break;
         case DIST_DPD: L.go<DIST_DPD>(); break;
         case DIST_GP: L.go<DIST_GP>(); break;
         case DIST_BNB: L.go<DIST_BNB>(); break;
         default: L.go<DIST_BB>(); break;
+        }
+        if (stamps_path) {
+            sync();
+            std::vector<unsigned long long> h(((size_t)c.n_tiles + 4096) * 6);
+            vsStamps.download(h.data(), h.size());
+            if (FILE * f = fopen(stamps_path, "wb")) {
+                fwrite(h.data(), 8, h.size(), f);
+                fclose(f);
+            }
         }
         launch_deferred(P);
     }

@@ -1623,6 +1623,9 @@ struct VsTables {
     VsTile * band_tile;           // [nvals]
     const uint32_t * val_start;   // [nvals + 1] positions of each value's rows
     uint32_t n_values;
+    // diagnostics (DIST_VS_STAMPS, tools/vs_stamps.py): per wave of
+    // k_vs_sample six s_memtime stamps and its SIMD; null otherwise
+    unsigned long long * stamps;
 };
 constexpr uint32_t kVsBandWalkRows = 8192;
 
@@ -2002,9 +2005,13 @@ __device__ __forceinline__ void vs_sum_and_scan(
     }
 }
 
+// BLOCK = kVsSampleBlock for launches that fill the chip (16 tiles per
+// workgroup, mostly of one value: they share their scalar-cache lines); 64
+// for small ones -- a 65 536-row batch is 512 tiles, which 1024-thread
+// workgroups would pile onto 32 of the 256 CUs, four waves to a SIMD.
 constexpr int kVsSampleBlock = 1024;
-template <int KIND>
-__global__ __launch_bounds__(kVsSampleBlock)
+template <int KIND, int BLOCK>
+__global__ __launch_bounds__(BLOCK)
 __attribute__((amdgpu_waves_per_eu(8, 8)))
 void k_vs_sample(
         SweepParams P, VsTables T, const VsTile * __restrict__ tiles,
@@ -2013,11 +2020,13 @@ void k_vs_sample(
         uint32_t * __restrict__ deferred, uint32_t * deferred_count) {
     const int lane = threadIdx.x & 63;
     const uint32_t id = __builtin_amdgcn_readfirstlane(
-        blockIdx.x * (kVsSampleBlock / 64) + (threadIdx.x >> 6));
+        blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6));
     // the first n_band_ids ids (a whole number of workgroups, resident from
     // the launch's first cycle) are the values' band tiles (VsTables); a band
     // tile samples the arg-max group's rows only, a regular tile of a value
     // with a band tile everything else
+    unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0;
+    if (T.stamps) st0 = __builtin_amdgcn_s_memtime();
     const bool band = id < n_band_ids;
     const VsTile * mine = band ? T.band_tile + id : tiles + (id - n_band_ids);
     if (band ? id >= T.n_values : id - n_band_ids >= n_tiles) return;
@@ -2087,6 +2096,7 @@ void k_vs_sample(
     // the slowest SIMD is the kernel's time); ahead of its neighbours it ends
     // with them.
     if (__any(anyA) && __any(anyB)) __builtin_amdgcn_s_setprio(3);
+    if (T.stamps) st1 = __builtin_amdgcn_s_memtime();
     if (__any(anyA)) {
         const float * vec = T.LA + (size_t)x * T.Kpad;
         int f[kVsR];
@@ -2097,6 +2107,7 @@ void k_vs_sample(
 #pragma unroll
         for (int r = 0; r < kVsR; ++r) g2[r] = inA[r] ? f[r] : g2[r];
     }
+    if (T.stamps) st2 = __builtin_amdgcn_s_memtime();
     if (__any(anyB)) {
         const float * vec = T.LB + (size_t)x * T.Kpad;
         int f[kVsR];
@@ -2107,6 +2118,7 @@ void k_vs_sample(
 #pragma unroll
         for (int r = 0; r < kVsR; ++r) g2[r] = inB[r] ? f[r] : g2[r];
     }
+    if (T.stamps) st3 = __builtin_amdgcn_s_memtime();
 #pragma unroll
     for (int r = 0; r < kVsR; ++r) {
         if (valid[r]) {
@@ -2114,6 +2126,16 @@ void k_vs_sample(
             P.old_packed[at] = (uint32_t)g[r];
             P.new_packed[at] = (uint32_t)g2[r];
         }
+    }
+    if (T.stamps && lane == 0) {
+        unsigned long long * out = T.stamps + (size_t)id * 6;
+        out[0] = st0; out[1] = st1; out[2] = st2; out[3] = st3;
+        out[4] = __builtin_amdgcn_s_memtime();
+        // HW_ID: wave, SIMD, CU, SH, SE and (XCC_ID) the XCD
+        out[5] = (unsigned long long)__builtin_amdgcn_s_getreg(
+                     (4 << 0) | (0 << 6) | (31 << 11))
+               | ((unsigned long long)__builtin_amdgcn_s_getreg(
+                     (20 << 0) | (0 << 6) | (3 << 11)) << 32);
     }
 }
 

@@ -5,22 +5,58 @@
  * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
  * load it.  Nothing under distributions_amd/ links, imports or calls it.
  *
- * Pinning status (see DESIGN.md "Oracle pinning"):
- *   - special functions, vector_math, MixtureDriver, MixtureIdTracker:
- *     PINNED bit-for-bit against oracle/_ref/libref.so, the real reference
- *     sources compiled here with the reference's release flags
- *     (tests/test_oracle_vs_ref.py, tests/golden/special_*.npz).
- *   - minstd_rand0 / sample_unif01: PINNED against libstdc++ <random>
- *     (oracle/check_libstdcxx.cc) and the reference-recorded probe values.
- *   - sampling (random.hpp/.cc), PitmanYor (clustering.hpp), component
- *     models (the models headers and src/models sources): these include random.hpp ->
- *     <eigen3/Eigen/Cholesky>, absent from this image, so the reference
- *     cannot be compiled for them ("parity unpinned" at the bit level for
- *     these functions).  They are restated from the source in source
- *     operation order and pinned by the reference's own tolerance tests
- *     (test_models.py:537-594, test_clustering.py:242-327), its known-answer
- *     tests (test_random.py:224-247) and an independent float64/scipy
- *     evaluation of the same predictive densities.
+ * Pinning status, function by function.  "_ref" = bit-for-bit against
+ * oracle/_ref/libref.so, the reference's own sources compiled here with its
+ * release flags (goldens under tests/golden/, tests/test_oracle_golden.py);
+ * "libstdc++" = against the <random> the reference calls
+ * (oracle/check_libstdcxx.cc, tests/golden/rng_libstdcxx.npz); "probe" =
+ * against values the survey recorded from the compiled reference (SURVEY.md
+ * section 8c); "UNPINNED" = the reference cannot be compiled for it in this
+ * image (the header chain reaches random.hpp:38, <eigen3/Eigen/Cholesky>,
+ * which the image lacks; no stand-in header was written), so the function is
+ * restated from the source in source operation order and held only to the
+ * reference's own tolerance tests (tests/test_oracle_models.py restates
+ * test_models.py:498-594, test_clustering.py:242-327, test_random.py:183-247)
+ * and an independent float64/scipy evaluation.  PARITY UNPINNED at the bit
+ * level for those: every "bit-exact" claim of the GPU path about them is
+ * "bit-exact against this restatement".
+ *
+ *   function(s) here                      reference                 pinned to
+ *   orc_fast_log/exp/lgamma/lgamma_nu/    special.hpp:53-273,       _ref
+ *     log_factorial, the tables           special.cc:35-269,
+ *                                         fmath.hpp:438-459
+ *   orc_vector_add_subtract(_scalar),     vector_math.cc:74-178     _ref
+ *     orc_vector_add, orc_vector_max,
+ *     orc_vector_sum
+ *   orc_rng_seed/next/jump,               random_fwd.hpp:34,        libstdc++,
+ *     orc_sample_unif01                   random.hpp:47-50          probe
+ *   orc_mix_driver_* (MixtureDriver:      mixture.hpp:48-163        _ref (the
+ *     sizes, empty set, add/remove flags)                           template)
+ *   orc_mix_tracker_*, orc_mix_packed_    mixture.hpp:460-521       _ref
+ *     to_global / global_to_packed
+ *   orc_scores_to_likelihoods,            random.cc:94-106,         UNPINNED
+ *     orc_sample_from_likelihoods,        random.hpp:316-333,       (probe: one
+ *     orc_sample_from_scores_*,           361-392; random.cc:77-92  vector, 8
+ *     orc_log_sum_exp, orc_sample_discrete                          draws)
+ *   orc_py_score_add_value/remove_value,  clustering.hpp:81-123,    UNPINNED
+ *     orc_mix_driver_score_value and the  195-230                   (probe:
+ *     shifted-score cache, orc_py_score_  clustering.cc:37-63,      score_counts
+ *     counts, orc_py_sample_assignments   152-183                   {5,3,1,0},
+ *                                                                   one draw)
+ *   orc_le_* (LowEntropy)                 clustering.hpp:245-331,   UNPINNED
+ *                                         clustering.cc:185-238     (table: own
+ *                                                                   derivation)
+ *   orc_mix_slave_* / orc_group_* :       dd.hpp:89-472, bb.hpp:    UNPINNED
+ *     Group add/remove, Scorer::init,     79-325, gp.hpp:84-334 +
+ *     score_value(_group), score_data     gp.cc:32-67, nich.hpp:98-
+ *     for DD, BB, GP, NICH, DPD, BNB      385 + nich.cc:33-66,
+ *                                         dpd.hpp:157-578, bnb.hpp
+ *   orc_mix_gibbs_sequential              examples/mixture/main.py: composition
+ *                                         236-244      of the above
+ *   orc_mix_batch_sample/apply_moves/     none: the batch semantics of
+ *     batch_finish/gibbs_batch,           DESIGN.md section 3 (a batch of one
+ *     orc_mix_load_state                  row == orc_mix_gibbs_sequential,
+ *                                         tests/test_oracle_models.py)
  *
  * Every function cites the reference file:line it follows
  * (paths relative to /root/reference).

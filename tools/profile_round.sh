@@ -33,12 +33,24 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/c3f -- pyt
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/c3w -- python3 $B $C3 > /dev/null 2>&1
 python3 tools/counters.py $out/counters.json \
     "k_vs_sample<dd>=k_vs_sample<0>:1000000:100000" \
-    "k_vs_sample<dpd>=k_vs_sample<4>:1000000:100000" \
-    "k_vs_prepare<dpd>=k_vs_prepare<4>:1000000:0" \
+    "k_vs_stream<dpd>=k_vs_stream<4>:1000000:100000" \
     "k_sweep_sample<gp_nich>=k_sweep_sample<2, 3, 2>:1000000:100000" \
     -- $out/sq $out/grbm $out/fetch $out/write $out/c5f $out/c5w $out/c5s $out/c3s $out/c3f $out/c3w > $out/counters.log 2>&1
 for d in sq grbm fetch write c5f c5w c5s c3s c3f c3w; do
   python3 tools/pmc_summary.py $out/$d k_ > $out/pmc_$d.txt 2>/dev/null
 done
+# the bench line of record (with the CPU baseline), the other configurations,
+# the VALU issue-rate microbenchmark
+python3 bench.py 2> $out/bench.log | tail -1 > $out/bench.json
+: > $out/bench_other_configs.jsonl
+for c in gp_nich nich gp bb mixed dd16; do
+  python3 bench.py --cpu-rows 0 --other-batches= --steps 3 --warmup 1 --config $c 2>/dev/null | tail -1 >> $out/bench_other_configs.jsonl
+done
+python3 bench.py --cpu-rows 0 --other-batches= --steps 3 --warmup 2 --config dpd --groups 8192 --dim 10000 2>/dev/null | tail -1 >> $out/bench_other_configs.jsonl
+python3 bench.py --cpu-rows 0 --other-batches= --steps 5 --values zipf 2>/dev/null | tail -1 >> $out/bench_other_configs.jsonl
+python3 bench.py --cpu-rows 0 --other-batches= --steps 5 --d 0 2>/dev/null | tail -1 >> $out/bench_other_configs.jsonl
+python3 bench.py --cpu-rows 0 --other-batches= --force-collective 2>/dev/null | tail -1 > $out/bench_collective_one_rank.json
+python3 bench.py --cpu-rows 0 --other-batches= --device-normalise 1 2>/dev/null | tail -1 > $out/bench_device_normalise.json
+(cd tools/microbench && /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -o valu_issue valu_issue.hip && ./valu_issue) > $out/valu_issue.txt 2>&1
 rm -rf $out/trace $out/sq $out/grbm $out/fetch $out/write $out/c5 $out/c5f $out/c5w $out/c5s $out/c3 $out/c3s $out/c3f $out/c3w
 ls -la $out

@@ -1,0 +1,106 @@
+"""Per-wave phase stamps of the last k_vs_sample launch (DIST_VS_STAMPS=<file>,
+dist_hip.hip): where a launch's cycles go.
+usage: DIST_VS_STAMPS=/tmp/st.bin python tools/vs_stamps.py run   # C2 probe
+       python tools/vs_stamps.py /tmp/st.bin"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def report(path):
+    a = np.fromfile(path, dtype=np.uint64).reshape(-1, 6)
+    a = a[a[:, 4] != 0]
+    st = a[:, :5].astype(np.int64)
+    hw = a[:, 5]
+    simd = ((hw >> 4) & 3).astype(np.int64)
+    cu = ((hw >> 8) & 15).astype(np.int64)
+    sh = ((hw >> 12) & 1).astype(np.int64)
+    se = ((hw >> 13) & 7).astype(np.int64)
+    xcc = ((hw >> 32) & 15).astype(np.int64)
+    # s_memtime bases differ between CUs: times relative to the first wave of
+    # the LAST launch on the same CU (a wave with nothing to do leaves the
+    # stamps of an older launch behind)
+    cukey = ((xcc * 8 + se) * 2 + sh) * 16 + cu
+    keep = np.zeros(len(st), bool)
+    for c in np.unique(cukey):
+        m = cukey == c
+        recent = m & (st[:, 0] >= st[m, 0].max() - 100_000)
+        st[recent] -= st[recent, 0].min()
+        keep |= recent
+    st, hw, simd, cu, sh, se, xcc = (v[keep] for v in (st, hw, simd, cu, sh,
+                                                       se, xcc))
+    key = (((xcc * 8 + se) * 2 + sh) * 16 + cu) * 4 + simd
+    span = st[:, 4].max()
+    print("%d waves on %d XCDs, launch spans %d cycles" % (
+        len(st), len(np.unique(xcc)), span))
+    names = ["setup (loads, own scores)", "vector A: sum + scan",
+             "vector B: sum + scan", "write back"]
+    for i, n in enumerate(names):
+        d = st[:, i + 1] - st[:, i]
+        print("  %-28s mean %8.0f  median %8.0f  p95 %8.0f  max %8.0f" % (
+            n, d.mean(), np.median(d), np.percentile(d, 95), d.max()))
+    life = st[:, 4] - st[:, 0]
+    print("  %-28s mean %8.0f  median %8.0f  p95 %8.0f  max %8.0f" % (
+        "wave lifetime", life.mean(), np.median(life),
+        np.percentile(life, 95), life.max()))
+    print("  wave start: median %d  p95 %d  max %d" % (
+        np.median(st[:, 0]), np.percentile(st[:, 0], 95), st[:, 0].max()))
+    print("  wave end:   p5 %d  median %d  p95 %d  max %d" % (
+        np.percentile(st[:, 4], 5), np.median(st[:, 4]),
+        np.percentile(st[:, 4], 95), st[:, 4].max()))
+    keys, inv = np.unique(key, return_inverse=True)
+    per = np.bincount(inv)
+    end = np.zeros(len(keys), np.int64)
+    np.maximum.at(end, inv, st[:, 4])
+    work = np.bincount(inv, weights=life)
+    print("  %d SIMDs seen; waves per SIMD: min %d median %d max %d" % (
+        len(keys), per.min(), np.median(per), per.max()))
+    print("  SIMD finish time: min %d  p5 %d  median %d  p95 %d  max %d" % (
+        end.min(), np.percentile(end, 5), np.median(end),
+        np.percentile(end, 95), end.max()))
+    print("  sum of wave lifetimes per SIMD / span: min %.2f median %.2f max "
+          "%.2f" % (work.min() / span, np.median(work) / span,
+                    work.max() / span))
+    grid = np.linspace(0, span, 11)
+    alive = [(int(((st[:, 0] <= t) & (st[:, 4] > t)).sum())) for t in grid]
+    print("  waves alive at 0%..100% of the span:", alive)
+    insetup = [(int(((st[:, 0] <= t) & (st[:, 1] > t)).sum())) for t in grid]
+    print("  of them still in setup:             ", insetup)
+    # the slowest waves: which phase makes them slow
+    slow = np.argsort(-st[:, 4])[:len(st) // 50]
+    print("  slowest 2%% of waves: start %.0f setup %.0f A %.0f B %.0f" % (
+        st[slow, 0].mean(), (st[slow, 1] - st[slow, 0]).mean(),
+        (st[slow, 2] - st[slow, 1]).mean(), (st[slow, 3] - st[slow, 2]).mean()))
+    cs = np.corrcoef(np.stack([life, st[:, 1] - st[:, 0],
+                               st[:, 2] - st[:, 1], st[:, 0]]))
+    print("  corr(lifetime, setup) %.2f  corr(lifetime, A) %.2f  "
+          "corr(lifetime, start) %.2f" % (cs[0, 1], cs[0, 2], cs[0, 3]))
+
+
+def run():
+    sys.path.insert(0, ROOT)
+    import torch
+    from distributions_amd import engine
+    n, k, dim = 10_000_000, 1024, 256
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1)
+    col = torch.randint(0, dim, (n,), generator=gen, device=dev,
+                        dtype=torch.int32)
+    assign = torch.arange(n, device=dev, dtype=torch.int64).remainder(k).to(
+        torch.int32)
+    g = engine.Gibbs(1.0, 0.2, [engine.dd_shared([0.5] * dim)])
+    g.load_rows_torch([col], assign, k, 1)
+    for s in range(3):
+        g.sweep(0, n, 1_000_000, 5, draw_base=s * n)
+    report(os.environ["DIST_VS_STAMPS"])
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "run":
+        run()
+    else:
+        report(sys.argv[1])
