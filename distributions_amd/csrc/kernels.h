@@ -1623,8 +1623,9 @@ struct VsTables {
     VsTile * band_tile;           // [nvals]
     const uint32_t * val_start;   // [nvals + 1] positions of each value's rows
     uint32_t n_values;
-    // diagnostics (DIST_VS_STAMPS, tools/vs_stamps.py): per wave of
-    // k_vs_sample six s_memtime stamps and its SIMD; null otherwise
+    // diagnostics (a -DDIST_VS_STAMPS build, `make stamps`, run with
+    // DIST_VS_STAMPS=<file>; tools/vs_stamps.py): per wave of k_vs_sample
+    // five s_memtime stamps and HW_ID; null otherwise
     unsigned long long * stamps;
 };
 constexpr uint32_t kVsBandWalkRows = 8192;
@@ -2025,8 +2026,10 @@ void k_vs_sample(
     // the launch's first cycle) are the values' band tiles (VsTables); a band
     // tile samples the arg-max group's rows only, a regular tile of a value
     // with a band tile everything else
+#ifdef DIST_VS_STAMPS   // diagnostic build only (make stamps): costs 3 us
     unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0;
     if (T.stamps) st0 = __builtin_amdgcn_s_memtime();
+#endif
     const bool band = id < n_band_ids;
     const VsTile * mine = band ? T.band_tile + id : tiles + (id - n_band_ids);
     if (band ? id >= T.n_values : id - n_band_ids >= n_tiles) return;
@@ -2096,7 +2099,9 @@ void k_vs_sample(
     // the slowest SIMD is the kernel's time); ahead of its neighbours it ends
     // with them.
     if (__any(anyA) && __any(anyB)) __builtin_amdgcn_s_setprio(3);
+#ifdef DIST_VS_STAMPS
     if (T.stamps) st1 = __builtin_amdgcn_s_memtime();
+#endif
     if (__any(anyA)) {
         const float * vec = T.LA + (size_t)x * T.Kpad;
         int f[kVsR];
@@ -2107,7 +2112,9 @@ void k_vs_sample(
 #pragma unroll
         for (int r = 0; r < kVsR; ++r) g2[r] = inA[r] ? f[r] : g2[r];
     }
+#ifdef DIST_VS_STAMPS
     if (T.stamps) st2 = __builtin_amdgcn_s_memtime();
+#endif
     if (__any(anyB)) {
         const float * vec = T.LB + (size_t)x * T.Kpad;
         int f[kVsR];
@@ -2118,7 +2125,9 @@ void k_vs_sample(
 #pragma unroll
         for (int r = 0; r < kVsR; ++r) g2[r] = inB[r] ? f[r] : g2[r];
     }
+#ifdef DIST_VS_STAMPS
     if (T.stamps) st3 = __builtin_amdgcn_s_memtime();
+#endif
 #pragma unroll
     for (int r = 0; r < kVsR; ++r) {
         if (valid[r]) {
@@ -2127,6 +2136,7 @@ void k_vs_sample(
             P.new_packed[at] = (uint32_t)g2[r];
         }
     }
+#ifdef DIST_VS_STAMPS
     if (T.stamps && lane == 0) {
         unsigned long long * out = T.stamps + (size_t)id * 6;
         out[0] = st0; out[1] = st1; out[2] = st2; out[3] = st3;
@@ -2137,6 +2147,7 @@ void k_vs_sample(
                | ((unsigned long long)__builtin_amdgcn_s_getreg(
                      (20 << 0) | (0 << 6) | (3 << 11)) << 32);
     }
+#endif
 }
 
 // ---------------------------------------------------------------------------

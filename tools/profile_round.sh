@@ -32,7 +32,7 @@ rocprofv3 --pmc $SQ --kernel-trace --output-format csv -d $out/c3s -- python3 $B
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/c3f -- python3 $B $C3 > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/c3w -- python3 $B $C3 > /dev/null 2>&1
 python3 tools/counters.py $out/counters.json \
-    "k_vs_sample<dd>=k_vs_sample<0>:1000000:100000" \
+    "k_vs_sample<dd>=k_vs_sample<0, 1024>:1000000:100000" \
     "k_vs_stream<dpd>=k_vs_stream<4>:1000000:100000" \
     "k_sweep_sample<gp_nich>=k_sweep_sample<2, 3, 2>:1000000:100000" \
     -- $out/sq $out/grbm $out/fetch $out/write $out/c5f $out/c5w $out/c5s $out/c3s $out/c3f $out/c3w > $out/counters.log 2>&1

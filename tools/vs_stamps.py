@@ -1,7 +1,10 @@
-"""Per-wave phase stamps of the last k_vs_sample launch (DIST_VS_STAMPS=<file>,
-dist_hip.hip): where a launch's cycles go.
-usage: DIST_VS_STAMPS=/tmp/st.bin python tools/vs_stamps.py run   # C2 probe
-       python tools/vs_stamps.py /tmp/st.bin"""
+"""Per-wave phase stamps of the last k_vs_sample launch: where a launch's cycles
+go.  Needs the diagnostic build of the library (the stamps cost 3 us per
+launch and are compiled out otherwise):
+    make -C distributions_amd/csrc stamps
+    DIST_VS_STAMPS=/tmp/st.bin python tools/vs_stamps.py run   # C2 probe
+    python tools/vs_stamps.py /tmp/st.bin
+    make -C distributions_amd/csrc          # back to the product build"""
 import os
 import sys
 
