@@ -264,6 +264,7 @@ def cpu_baseline(args, column_host):
                       "sample": "%d independent chains of %d rows, %.1f s"
                                 % (cores, n_par, dt_par)},
     }
+    out["c1"] = cpu_c1(args, ol)
     # the same file built for this host's own instruction set
     try:
         subprocess.check_call(["make", "-s", "-C",
@@ -285,6 +286,42 @@ def cpu_baseline(args, column_host):
     except (subprocess.CalledProcessError, OSError, AttributeError) as e:
         out["march_native"] = {"value": None, "error": str(e)[:200]}
     return out
+
+
+def cpu_c1(args, ol):
+    """BASELINE configs[0] on the host, next to the survey's probes of the
+    compiled reference: the full row update at
+    DirichletDiscrete(16), K = 64, N = 100 000 (probe: 1.83 M rows/s) and the
+    loop of benchmarks/mixture.cc:104-115 -- remove, score_value, add; its
+    "cells/us" -- for DirichletDiscrete<4> at K = 1000 (probe: 9.43)."""
+    import numpy as np
+    rng = np.random.default_rng(args.seed)
+    n, k, dim = 100_000, 64, 16
+    values = rng.integers(0, dim, n).astype(np.uint32)
+    orc = ol.OracleMixture(1.0, 0.0, [ol.make_shared(ol.DD,
+                                                     alphas=[0.5] * dim)])
+    orc.init_from_assignments([values], (np.arange(n) % k).astype(np.uint32),
+                              k, 1)
+    st = ol.oracle().orc_rng_seed(args.seed)
+    orc.gibbs_sequential(0, n, st)            # warm-up sweep
+    t0 = time.perf_counter()
+    orc.gibbs_sequential(0, n, st)
+    full = n / (time.perf_counter() - t0)
+    k2, n2, iters = 1000, 4000, 400_000
+    v2 = rng.integers(0, 4, n2).astype(np.uint32)
+    g2 = rng.integers(0, k2, n2).astype(np.uint32)
+    m = ol.OracleMixture(1.0, 0.0, [ol.make_shared(ol.DD, alphas=[0.5] * 4)])
+    m.init_from_assignments([v2], g2, k2, 1)
+    t0 = time.perf_counter()
+    m.L.orc_mixture_benchmark_loop(m.h, n2, v2, g2, iters)
+    loop = iters / (time.perf_counter() - t0) / 1e6
+    return {"full_row_update_dd16_k64_rows_per_s": full,
+            "reference_probe_rows_per_s": 1.83e6,
+            "mixture_cc_loop_dd4_k1000_cells_per_us": loop,
+            "reference_probe_cells_per_us": 9.43,
+            "note": "oracle/oracle.c on one host core; the probes are the "
+                    "compiled reference in the survey container (another "
+                    "CPU), BASELINE.md section 2"}
 
 
 def make_columns(args, torch, engine, dev, gen, n, k):
@@ -499,17 +536,21 @@ def run_rank(args):
         valu_cycles = (ctr["valu_busy_cycles"] * scale
                        if usable and ctr.get("valu_busy_cycles") is not None
                        else None)
-        hbm_bound = args.config == "dpd"
         secs = 1e-3 * avg_ms
         hbm_frac = (traffic / secs / 1e9 / HBM_PEAK_GBS
                     if traffic is not None else None)
         valu_frac = (valu_cycles / (SIMDS * CLOCK_GHZ * 1e9 * secs)
                      if valu_cycles is not None else None)
+        # the roof the kernel sits closer to, by the counters (every kernel
+        # measured so far is VALU-bound: C5, the configuration SURVEY 8d
+        # expected to be HBM-bound, included -- DESIGN.md section 4)
+        hbm_bound = (hbm_frac is not None and valu_frac is not None
+                     and hbm_frac > valu_frac)
         if hbm_bound:
             roof = {"bound": "hbm", "kernel": kernel,
-                    "achieved": (traffic / secs / 1e9
-                                 if traffic is not None else None),
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_frac}
+                    "achieved": traffic / secs / 1e9,
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_frac,
+                    "valu_frac": valu_frac}
         else:
             roof = {"bound": "valu", "kernel": kernel,
                     "achieved": (valu_cycles / secs / 1e9

@@ -1346,6 +1346,33 @@ void orc_mix_init_from_assignments(orc_mix * m, size_t n_rows,
     orc_ftz_restore(saved);
 }
 
+/* benchmarks/mixture.cc:104-115, the loop the reference's "cells/us" figure
+ * times: remove the value from its group, score_value accumulating into a
+ * vector that is zeroed every eight iterations, add it back.  Feature 0 of
+ * `m`; values[i] sits in group groups[i]; returns a checksum of the scores
+ * (so that the loop cannot be optimised away). */
+float orc_mixture_benchmark_loop(orc_mix * m, size_t n_values,
+                                 const uint32_t * values,
+                                 const uint32_t * groups, size_t iters) {
+    unsigned saved = orc_ftz_enable();
+    feat * f = &m->f[0];
+    float * scores = malloc(sizeof(float) * (f->K + 1));
+    float check = 0.f;
+    for (size_t i = 0; i < iters / 8; ++i) {
+        for (int k = 0; k < f->K; ++k) scores[k] = 0.f;
+        for (size_t j = 0; j < 8; ++j) {
+            const size_t at = (8 * i + j) % n_values;
+            orc_mix_slave_remove_value(m, 0, (int)groups[at], values[at]);
+            feat_score_value(f, values[at], scores);
+            orc_mix_slave_add_value(m, 0, (int)groups[at], values[at]);
+        }
+        check += scores[0];
+    }
+    free(scores);
+    orc_ftz_restore(saved);
+    return check;
+}
+
 /* Adopt a state that was produced elsewhere (tests: the engine's state after
  * some sweeps, so that the oracle can follow it from there): K groups in the
  * given slot order -- sizes, per-feature statistics as

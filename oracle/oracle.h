@@ -220,6 +220,10 @@ void orc_mix_init_from_assignments(orc_mix * m, size_t n_rows,
                                    const uint32_t * assign_packed,
                                    int nonempty_groups, int empty_groups,
                                    uint32_t * assign_global_out);
+/* benchmarks/mixture.cc:104-115 on feature 0 (bench.py's cpu_baseline) */
+float orc_mixture_benchmark_loop(orc_mix * m, size_t n_values,
+                                 const uint32_t * values,
+                                 const uint32_t * groups, size_t iters);
 /* adopt a state produced elsewhere: K groups in slot order with their sizes,
  * statistics (orc_mix_slave_get_group layout, K blocks per feature) and ids */
 void orc_mix_load_state(orc_mix * m, int K, const int32_t * counts,

@@ -156,6 +156,7 @@ def bind_oracle(path):
         c_u32p)
     sig("orc_mix_gibbs_sequential", None, vp, sz, sz, pp, c_u32p, u32ptr)
     sig("orc_mix_load_state", None, vp, ci, c_i32p, pp, c_u32p, u32)
+    sig("orc_mixture_benchmark_loop", f32, vp, sz, c_u32p, c_u32p, sz)
     sig("orc_mix_gibbs_batch", None, vp, sz, sz, pp, c_u32p, u32, u64)
     sig("orc_mix_batch_row_scores", ci, vp, c_u32p, u32, c_f32p)
     return L
