@@ -229,6 +229,9 @@ def cpu_baseline(args, column_host):
         return orc
 
     n = len(column_host)
+    if n < 8 * args.groups:
+        # (every group of the initial assignment i mod K needs rows)
+        raise SystemExit("bench.py: --cpu-rows must be at least 8 x --groups")
     values = np.ascontiguousarray(column_host, np.uint32)
     orc = chain(values)
     st = ol.oracle().orc_rng_seed(args.seed)
@@ -237,7 +240,7 @@ def cpu_baseline(args, column_host):
     dt = time.perf_counter() - t0
 
     model, cores = host_cpu()
-    n_par = max(10000, n // 8)
+    n_par = min(n, max(10 * args.groups, n // 8))
     chains = [chain(np.roll(values, 7919 * (i + 1))[:n_par].copy())
               for i in range(cores)]
     threads = [threading.Thread(target=c.gibbs_sequential, args=(0, n_par, st))

@@ -160,6 +160,29 @@ def test_steady_state_sub_sweep_at_full_size(batch):
     assert_same_state(orc, gpu, "sweep 2, second sub-sweep of %d" % batch)
 
 
+def test_c3_steady_state_sub_sweep_at_full_size():
+    """BASELINE configs[2] past its first sweep: GammaPoisson +
+    NormalInverseChiSq rows, N = 10M, K = 1024.  After a whole sweep on the
+    GPU (ordered replay of the Welford statistics and the log-products
+    included) the oracle adopts the engine's state -- float statistics bit
+    for bit -- and follows a sub-sweep of sweep 2."""
+    from distributions_amd import engine
+    osh, gsh, vals, assign = workloads.make("gp_nich", N, K)
+    gpu = engine.Gibbs(ALPHA, D, gsh)
+    gpu.load_rows(vals, assign, K, 1)
+    seed = 20240601
+    st = ol.oracle().orc_rng_seed(seed)
+    gpu.sweep(0, N, 1_000_000, seed, draw_base=0)
+    assert gpu.counts().sum() == N
+    orc = ol.OracleMixture(ALPHA, D, osh)
+    orc.adopt(gpu, vals)
+    assert_same_state(orc, gpu, "adopted state")
+    first = 150_000
+    orc.gibbs_batch(0, first, st, N)
+    gpu.sweep(0, first, first, seed, draw_base=N)
+    assert_same_state(orc, gpu, "C3 sweep 2, first %d rows" % first)
+
+
 def test_c1_dd16_k64_n100k():
     """BASELINE configs[0] (benchmarks/mixture.cc's model at its CPU size):
     DirichletDiscrete(dim=16), K = 64, N = 100 000 -- frozen sub-sweeps of
