@@ -80,6 +80,10 @@ def parse():
     ap.add_argument("--device-normalise", type=int, default=0,
                     help="1: the group set is normalised on the device, no "
                          "host round trip per sub-sweep (0: the default)")
+    ap.add_argument("--narrow-tiles", type=int, default=1,
+                    help="launches too small to fill the chip take tiles of "
+                         "64 rows with their vectors in LDS (k_vs_narrow): "
+                         "0 never, 1 auto, 2 whenever the vectors fit")
     ap.add_argument("--other-batches", default="65536",
                     help="comma-separated sub-sweep sizes timed besides "
                          "--batch (a few steps each, reported in "
@@ -435,6 +439,7 @@ def run_rank(args):
         g.set_option("value_sorted", args.value_sorted)
         g.set_option("value_stream", args.value_stream)
         g.set_option("device_normalise", args.device_normalise)
+        g.set_option("narrow_tiles", args.narrow_tiles)
         initial = assign.clone()   # the engine updates `assign` in place
         g.load_rows_torch(columns, assign, k, 1, row_offset=row_offset)
         sharded = engine.ShardedGibbs(
@@ -483,6 +488,7 @@ def run_rank(args):
     ms, launches, rows = g.kernel_stats()
     vs_batches, generic_batches = g.path_counts()
     streamed = g.core.debug_counts()["stream_batches"]
+    narrow = g.core.debug_counts()["narrow_batches"]
     draws = args.warmup + args.steps
 
     # the same job at other sub-sweep sizes (value depends on it: the
@@ -492,12 +498,19 @@ def run_rank(args):
         if b == args.batch or b <= 0:
             continue
         steps_b = max(1, min(args.steps, 5))
+        before = g.core.debug_counts()
         dt_b = timed(sharded, g, n, b, steps_b, 1, draws)
         draws += 1 + steps_b
         ms_b, launches_b, rows_b = g.kernel_stats()
+        after = g.core.debug_counts()
+        took = [name for key, name in (("narrow_batches", "k_vs_narrow"),
+                                       ("stream_batches", "k_vs_stream"),
+                                       ("value_sorted_batches", "k_vs_sample"))
+                if after[key] > before[key]]
         variants.append({
             "batch_rows": b, "value": float(n) * world * steps_b / dt_b,
             "ms_per_step": 1e3 * dt_b / steps_b, "steps": steps_b,
+            "kernel": took[0] if took else "k_sweep_sample",
             "kernel_avg_launch_ms": ms_b / max(launches_b, 1)})
 
     strong = None
@@ -521,6 +534,8 @@ def run_rank(args):
     total_rows = float(n) * world * args.steps
     if vs_batches and streamed:
         kernel = "k_vs_stream<%s>" % args.config
+    elif vs_batches and narrow:
+        kernel = "k_vs_narrow<%s>" % args.config
     elif vs_batches:
         kernel = "k_vs_sample<%s>" % args.config
     elif args.config == "mixed":

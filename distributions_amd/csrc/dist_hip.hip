@@ -819,6 +819,8 @@ struct Gibbs {
         DeviceBuf<uint32_t> sorted_rows;
         DeviceBuf<VsTile> tiles;
         uint32_t n_tiles = 0;
+        DeviceBuf<VsTile> narrow_tiles;    // <= 64 rows each (k_vs_narrow)
+        uint32_t n_narrow_tiles = 0;
         DeviceBuf<VsTile> chunks;          // apply work items, one value each
         uint32_t n_chunks = 0;
         bool one_chunk_per_value = false;  // every value's rows in ONE chunk
@@ -878,6 +880,17 @@ struct Gibbs {
     // 1 where a value has about a tile per batch, 2 always
     int value_stream_mode = 1;
     uint64_t stream_batches = 0;
+    // launches too small to fill the chip take tiles of 64 rows, one per lane,
+    // and their vectors from LDS (k_vs_narrow): 0 never, 1 below
+    // kVsNarrowBelowTiles regular tiles, 2 whenever the vectors fit
+    int narrow_mode = 1;
+    uint64_t narrow_batches = 0;
+    static constexpr uint32_t kVsNarrowBelowTiles = 2048;   // (measured)
+    bool use_narrow(const VsCache & c, int Kpad) const {
+        if (narrow_mode == 0 || Kpad > kVsNarrowMaxK || !c.n_narrow_tiles)
+            return false;
+        return narrow_mode == 2 || c.n_tiles < kVsNarrowBelowTiles;
+    }
     int running_sums_min_tiles = 2048;   // see sample_value_sorted
     int cu_count_cached = 0;
     int cu_count() {
@@ -1416,6 +1429,15 @@ struct Gibbs {
                                                           h[x] - off)});
         c->n_tiles = (uint32_t)tiles.size();
         c->tiles.upload(tiles.data(), tiles.size());
+        if (c->n_tiles < kVsNarrowBelowTiles || narrow_mode == 2) {
+            std::vector<VsTile> narrow;
+            for (uint32_t x = 0; x < nv; ++x)
+                for (uint32_t off = 0; off < h[x]; off += 64)
+                    narrow.push_back(VsTile{x, start[x] + off,
+                                            std::min<uint32_t>(64, h[x] - off)});
+            c->n_narrow_tiles = (uint32_t)narrow.size();
+            c->narrow_tiles.upload(narrow.data(), narrow.size());
+        }
         for (uint32_t x = 0; x < nv; ++x) c->n_values_present += h[x] != 0;
         // apply work items: up to kVsApplyRows rows of one value -- or, where
         // values have few rows each (the table-free kernel's case) and the
@@ -1481,6 +1503,7 @@ struct Gibbs {
         SweepParams * P;
         VsCache * c;
         VsTables T;
+        bool narrow;
         template <int KIND>
         void go() {
             const uint32_t nv = (uint32_t)self->vs_nvals();
@@ -1492,6 +1515,17 @@ struct Gibbs {
             HIP_CHECK(hipEventRecord(self->ev0, stream()));
             // a launch that cannot fill the chip spreads out: a wave per
             // workgroup (no band tiles on such launches)
+            if (narrow) {
+                hipLaunchKernelGGL(
+                    (k_vs_narrow<KIND>), dim3(c->n_narrow_tiles), dim3(64),
+                    2 * ((size_t)T.Kpad + 2 * kVsUnroll) * sizeof(float),
+                    stream(), *P, T, c->narrow_tiles.p, c->n_narrow_tiles,
+                    c->sorted_rows.p, self->deferred.p,
+                    self->deferred_count.p);
+                HIP_CHECK(hipGetLastError());
+                HIP_CHECK(hipEventRecord(self->ev1, stream()));
+                return;
+            }
             const bool small = !T.band_mode && c->n_tiles < 4096;
             const uint32_t per =
                 small ? 1 : kVsSampleBlock / 64;   // tiles per workgroup
@@ -1520,6 +1554,10 @@ struct Gibbs {
     bool use_stream(const VsCache & c) const {
         if (value_stream_mode == 0) return false;
         if (value_stream_mode == 2) return true;
+        // ... and where the tables are large: small ones are built in a few
+        // microseconds and serve every wave from the scalar cache or LDS,
+        // while a streaming tile evaluates K scores and exponentials per pass
+        if ((size_t)vs_nvals() * (size_t)K() < ((size_t)1 << 21)) return false;
         return (size_t)c.n_tiles * 2 <= (size_t)c.n_values_present * 3;
     }
     struct VsStreamLaunch {
@@ -1594,7 +1632,10 @@ struct Gibbs {
         vsArg.reserve(nv, 0);
         // chunk-boundary running sums: worth their serial pass in
         // k_vs_prepare once the sampling kernel is throughput-bound
-        const bool large = c.n_tiles >= (uint32_t)running_sums_min_tiles;
+        const bool narrow = use_narrow(c, Kpad);
+        narrow_batches += narrow ? 1 : 0;
+        const bool large = !narrow
+                           && c.n_tiles >= (uint32_t)running_sums_min_tiles;
         const bool prefix = large && Kpad <= 8192;
         // the arg-max group's rows get a tile of their own per value when the
         // launch is large (and group-sorted: k_vs_apply's LDS sort fits)
@@ -1637,12 +1678,12 @@ struct Gibbs {
                             prefix ? vsPB.p : nullptr,
                             bands ? vsBandMode.p : nullptr,
                             bands ? vsBandTile.p : nullptr, c.val_start.p,
-                            nv, nullptr}};
+                            nv, nullptr}, narrow};
         // DIST_VS_STAMPS=<file>: per-wave phase stamps of every launch (the
         // last one stays in the file): tools/vs_stamps.py
         static const char * stamps_path = getenv("DIST_VS_STAMPS");
         if (stamps_path) {
-            vsStamps.reserve(((size_t)c.n_tiles + 4096) * 6, 0);
+            vsStamps.reserve(((size_t)c.n_tiles * 2 + 4096) * 6, 0);
             L.T.stamps = vsStamps.p;
         }
         switch (feats[0]->sh.kind) {
@@ -1654,7 +1695,7 @@ struct Gibbs {
         }
         if (stamps_path) {
             sync();
-            std::vector<unsigned long long> h(((size_t)c.n_tiles + 4096) * 6);
+            std::vector<unsigned long long> h(((size_t)c.n_tiles * 2 + 4096) * 6);
             vsStamps.download(h.data(), h.size());
             if (FILE * f = fopen(stamps_path, "wb")) {
                 fwrite(h.data(), 8, h.size(), f);
@@ -3429,6 +3470,13 @@ int dist_gibbs_set_option(dist_gibbs_t * g, const char * name, int value) {
             // the table-free value-sorted kernel: 0 never, 1 auto, 2 always
             DIST_REQUIRE(value >= 0 && value <= 2, "value_stream: 0, 1 or 2");
             g->impl->value_stream_mode = value;
+        } else if (key == "narrow_tiles") {
+            // k_vs_narrow for launches that cannot fill the chip: 0 never,
+            // 1 auto, 2 whenever the vectors fit its LDS
+            DIST_REQUIRE(value >= 0 && value <= 2, "narrow_tiles: 0, 1 or 2");
+            g->impl->narrow_mode = value;
+            // (cached ranges carry their tile lists)
+            g->impl->drop_overlapping_caches(0, g->impl->n_rows, false);
         } else if (key == "device_normalise") {
             // sweeps whose batches all take the value-sorted path normalise
             // the group set on the device (no host round trip per batch):
@@ -3469,9 +3517,9 @@ int dist_gibbs_path_counts(const dist_gibbs_t * g, uint64_t * value_sorted,
 int dist_gibbs_debug_counts(dist_gibbs_t * g, uint64_t * out, size_t n) {
     return guarded([&] {
         Gibbs & e = *g->impl;
-        uint64_t v[8] = {e.vs_batches, e.generic_batches, e.band_batches,
+        uint64_t v[9] = {e.vs_batches, e.generic_batches, e.band_batches,
                          e.prefix_batches, 0, 0, e.stream_batches,
-                         e.async_batches};
+                         e.async_batches, e.narrow_batches};
         if (e.last_bands && !e.batch_open && e.vsBandMode.p) {
             // values whose arg-max group's rows had a tile of their own in
             // the last value-sorted launch
@@ -3484,7 +3532,7 @@ int dist_gibbs_debug_counts(dist_gibbs_t * g, uint64_t * out, size_t n) {
             e.deferred_count.download(&d, 1);
             v[5] = d;
         }
-        for (size_t i = 0; i < n && i < 8; ++i) out[i] = v[i];
+        for (size_t i = 0; i < n && i < 9; ++i) out[i] = v[i];
     });
 }
 int dist_gibbs_kernel_stats(dist_gibbs_t * g, double * ms_out,

@@ -2151,6 +2151,266 @@ void k_vs_sample(
 }
 
 // ---------------------------------------------------------------------------
+// k_vs_narrow: the value-sorted row update for launches that cannot fill the
+// chip (sub-sweeps of some 10^4..10^5 rows).  There a tile's wave is alone on
+// its SIMD, and what the launch takes is ONE wave's latency: every scalar load
+// of the likelihood vector a round trip to L2 that nothing hides, a dependent
+// packed add every 12.5 cycles, two full passes wherever rows of the value's
+// arg-max group sit next to others.  So: tiles of 64 rows, one per lane (twice
+// the waves; a plain dependent v_add_f32 comes back after 8.5 cycles); the
+// tile's vector(s) copied into LDS once, by coalesced loads issued before the
+// rows' gathers, and read from there a chunk AHEAD of its use into registers
+// (a wave alone has hundreds); rows of the arg-max group take their entries
+// from the second vector by a per-lane select in the same pass.  The float
+// operations per row and their order are k_vs_sample's: bit-identical.
+constexpr int kVsNarrowMaxK = 4096;   // two vectors of Kpad + 64 floats in LDS
+// (Handing a tile's few rows of the arg-max group to the wave-per-row kernel
+// instead -- the tile then keeps to one vector -- was measured: this kernel
+// 32 -> 27 us at 65 536 rows, the sub-sweep as a whole 10 % slower: a row
+// costs the wave-per-row kernel what a tile costs here.)
+
+template <bool DUAL, bool SCAN>
+__device__ __forceinline__ void vs_narrow_chunk(
+        float & acc, const float4 (&a)[kVsUnroll / 4],
+        const float4 (&b)[kVsUnroll / 4], bool is_b, bool own, int k0, int g,
+        float l_own) {
+    if (own) {   // (wave-uniform) a lane's own slot falls into this chunk
+#pragma unroll
+        for (int q = 0; q < kVsUnroll / 4; ++q) {
+            const float ea[4] = {a[q].x, a[q].y, a[q].z, a[q].w};
+            const float eb[4] = {b[q].x, b[q].y, b[q].z, b[q].w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float e = (DUAL && is_b) ? eb[i] : ea[i];
+                e = (k0 + 4 * q + i == g) ? l_own : e;
+                acc = SCAN ? acc - e : acc + e;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < kVsUnroll / 4; ++q) {
+            const float ea[4] = {a[q].x, a[q].y, a[q].z, a[q].w};
+            const float eb[4] = {b[q].x, b[q].y, b[q].z, b[q].w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float e = (DUAL && is_b) ? eb[i] : ea[i];
+                acc = SCAN ? acc - e : acc + e;
+            }
+        }
+    }
+}
+
+// the two recurrences of vs_sum_and_scan for one row per lane; va / vb: the
+// vectors in LDS (vb only read when DUAL), a chunk of slack behind each
+template <bool DUAL>
+__device__ __forceinline__ int vs_narrow_row(
+        const float * va, const float * vb, bool is_b, int K, int g,
+        float l_own, float u, bool active) {
+    const int nchunks = (K + kVsUnroll - 1) / kVsUnroll;
+    const int gchunk = active ? g / kVsUnroll : -1;
+    const float4 * a4 = reinterpret_cast<const float4 *>(va);
+    const float4 * b4 = reinterpret_cast<const float4 *>(vb);
+    float4 a0[kVsUnroll / 4], a1[kVsUnroll / 4];
+    float4 b0[kVsUnroll / 4], b1[kVsUnroll / 4];
+    auto fetch = [&](int c, float4 (&a)[kVsUnroll / 4],
+                     float4 (&b)[kVsUnroll / 4]) {
+#pragma unroll
+        for (int q = 0; q < kVsUnroll / 4; ++q) {
+            a[q] = a4[c * (kVsUnroll / 4) + q];
+            b[q] = DUAL ? b4[c * (kVsUnroll / 4) + q] : a[q];
+        }
+    };
+    // total = ((l_0 + l_1) + l_2) + ...                  random.cc:100-103
+    float acc = 0.f;
+    fetch(0, a0, b0);
+    for (int c = 0; c < nchunks; c += 2) {
+        fetch(c + 1, a1, b1);
+        vs_narrow_chunk<DUAL, false>(acc, a0, b0, is_b, __any(gchunk == c),
+                                     c * kVsUnroll, g, l_own);
+        fetch(c + 2, a0, b0);
+        if (c + 1 < nchunks)
+            vs_narrow_chunk<DUAL, false>(acc, a1, b1, is_b,
+                                         __any(gchunk == c + 1),
+                                         (c + 1) * kVsUnroll, g, l_own);
+    }
+    // t = total*u; t -= l_k until t <= 0                 random.hpp:323-330
+    float t = acc * u;
+    float t_start = t;
+    int npos = 0;
+    auto book = [&]() {
+        const bool pos = t > 0.f;
+        t_start = pos ? t : t_start;
+        npos += pos ? 1 : 0;
+        return __builtin_amdgcn_ballot_w64(active && pos) != 0;
+    };
+    fetch(0, a0, b0);
+    for (int c = 0; c < nchunks; c += 2) {
+        fetch(c + 1, a1, b1);
+        vs_narrow_chunk<DUAL, true>(t, a0, b0, is_b, __any(gchunk == c),
+                                    c * kVsUnroll, g, l_own);
+        if (!book()) break;
+        fetch(c + 2, a0, b0);
+        if (c + 1 < nchunks) {
+            vs_narrow_chunk<DUAL, true>(t, a1, b1, is_b,
+                                        __any(gchunk == c + 1),
+                                        (c + 1) * kVsUnroll, g, l_own);
+            if (!book()) break;
+        }
+    }
+    int f = K - 1;
+    if (active && npos < nchunks) {
+        // replay the crossing chunk (as vs_sum_and_scan does)
+        const float4 * chunk = reinterpret_cast<const float4 *>(
+            ((DUAL && is_b) ? vb : va) + npos * kVsUnroll);
+        float4 v[kVsUnroll / 4];
+#pragma unroll
+        for (int q = 0; q < kVsUnroll / 4; ++q) v[q] = chunk[q];
+        const int own = g - npos * kVsUnroll;   // in 0..31 or not
+        float tt = t_start;
+        int steps = 0;
+#pragma unroll
+        for (int q = 0; q < kVsUnroll / 4; ++q) {
+            const float e[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                tt -= (own == 4 * q + i) ? l_own : e[i];
+                steps += (tt > 0.f) ? 1 : 0;
+            }
+        }
+        f = npos * kVsUnroll + steps;
+    }
+    return f < K - 1 ? f : K - 1;
+}
+
+template <int KIND>
+__global__ __launch_bounds__(64) void k_vs_narrow(
+        SweepParams P, VsTables T, const VsTile * __restrict__ tiles,
+        uint32_t n_tiles, const uint32_t * __restrict__ sorted_rows,
+        uint32_t * __restrict__ deferred, uint32_t * deferred_count) {
+    extern __shared__ float4 s_narrow[];   // [2][(Kpad + 2 * kVsUnroll) / 4]
+    const int lane = threadIdx.x;
+    const uint32_t id = blockIdx.x;
+    if (id >= n_tiles) return;
+    const uint32_t x = __builtin_amdgcn_readfirstlane(tiles[id].x);
+    const uint32_t pos = __builtin_amdgcn_readfirstlane(tiles[id].pos);
+    const uint32_t n = __builtin_amdgcn_readfirstlane(tiles[id].n);
+    if (n == 0) return;
+#ifdef DIST_VS_STAMPS   // diagnostic build only (make stamps)
+    unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0;
+    if (T.stamps) st0 = __builtin_amdgcn_s_memtime();
+#endif
+    const int Kpad = T.Kpad;
+    const int quads = Kpad / 4;
+    const int stride = quads + 2 * kVsUnroll / 4;   // float4s per vector
+    // the vector of the rows outside the arg-max group: on its way before
+    // the rows' own gathers start
+    constexpr int kQ = kVsNarrowMaxK / 4 / 64;
+    const float4 * ga =
+        reinterpret_cast<const float4 *>(T.LA + (size_t)x * Kpad);
+    float4 stage[kQ];
+#pragma unroll
+    for (int q = 0; q < kQ; ++q)
+        if (64 * q < quads)   // (uniform; lanes past the end re-read its last)
+            stage[q] = ga[min(lane + 64 * q, quads - 1)];
+        else
+            stage[q] = float4{0.f, 0.f, 0.f, 0.f};
+
+    SlaveView v = P.feat[0];
+    v.kind = KIND;
+    const int K = sweep_K(P);
+    const float shift = P.scalars->shift;
+    const float M = T.M[x], mB = T.mB[x];
+    const int amax = T.argmax[x];
+    const float ea = u2f(g_tables_dev.exp_ab[0]);
+    const float eb = u2f(g_tables_dev.exp_ab[1]);
+    const float lf = KIND == DIST_GP ? fast_log_factorial(x) : 0.f;
+
+    bool valid = (uint32_t)lane < n;
+    const uint32_t at = pos + lane;
+    int g = -1;
+    float l_own = 0.f, u = 0.f;
+    bool is_b = false;
+    if (valid) {
+        const size_t row = P.row_begin + sorted_rows[at];
+        g = P.g2p[P.assign_pos[at]];
+        is_b = (g == amax);
+        const int n_g = P.counts[g];
+        const float m = is_b ? mB : M;
+        float s_own = 0.f;
+        bool defer = (n_g == 1);
+        if (!defer) {
+            s_own = vs_own_score(P, v, g, n_g, x, lf, shift);
+            defer = !is_b && s_own > M;   // table rounding lifted it
+        }
+        if (defer) {
+            deferred[atomicAdd(deferred_count, 1u)] = at;
+            valid = false;
+        } else {
+            l_own = fast_exp_nonpos(s_own - m, g_tables_dev.exp_table, ea, eb);
+            u = batch_row_unif01(P, row);
+        }
+    }
+    const bool any_a = __any(valid && !is_b), any_b = __any(valid && is_b);
+    if (!any_a && !any_b) return;
+#ifdef DIST_VS_STAMPS
+    if (T.stamps) st1 = __builtin_amdgcn_s_memtime();
+#endif
+    float4 * sa = s_narrow;
+    float4 * sb = s_narrow + stride;
+#pragma unroll
+    for (int q = 0; q < kQ; ++q)
+        if (lane + 64 * q < quads) sa[lane + 64 * q] = stage[q];
+    if (any_b) {
+        const float4 * gb =
+            reinterpret_cast<const float4 *>(T.LB + (size_t)x * Kpad);
+#pragma unroll
+        for (int q = 0; q < kQ; ++q)
+            if (64 * q < quads) stage[q] = gb[min(lane + 64 * q, quads - 1)];
+#pragma unroll
+        for (int q = 0; q < kQ; ++q)
+            if (lane + 64 * q < quads) sb[lane + 64 * q] = stage[q];
+    }
+    // (the slack behind each vector is read ahead, never used)
+    if (lane < 2 * kVsUnroll / 4) {
+        sa[quads + lane] = float4{0.f, 0.f, 0.f, 0.f};
+        sb[quads + lane] = float4{0.f, 0.f, 0.f, 0.f};
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#ifdef DIST_VS_STAMPS
+    if (T.stamps) st2 = __builtin_amdgcn_s_memtime();
+#endif
+    const float * fa = reinterpret_cast<const float *>(sa);
+    const float * fb = reinterpret_cast<const float *>(sb);
+    int g2;
+    if (any_a && any_b)
+        g2 = vs_narrow_row<true>(fa, fb, is_b, K, g, l_own, u, valid);
+    else
+        g2 = vs_narrow_row<false>(any_b ? fb : fa, fb, false, K, g, l_own, u,
+                                  valid);
+#ifdef DIST_VS_STAMPS
+    if (T.stamps) st3 = __builtin_amdgcn_s_memtime();
+#endif
+    if (valid) {
+        P.old_packed[at] = (uint32_t)g;
+        P.new_packed[at] = (uint32_t)g2;
+    }
+#ifdef DIST_VS_STAMPS
+    // phases: rows' set-up | vectors into LDS | the recurrences | write back
+    if (T.stamps && lane == 0) {
+        unsigned long long * out = T.stamps + (size_t)id * 6;
+        out[0] = st0; out[1] = st1; out[2] = st2; out[3] = st3;
+        out[4] = __builtin_amdgcn_s_memtime();
+        out[5] = (unsigned long long)__builtin_amdgcn_s_getreg(
+                     (4 << 0) | (0 << 6) | (31 << 11))
+               | ((unsigned long long)__builtin_amdgcn_s_getreg(
+                     (20 << 0) | (0 << 6) | (3 << 11)) << 32);
+    }
+#endif
+}
+
+// ---------------------------------------------------------------------------
 // The value-sorted row update WITHOUT per-value tables (k_vs_stream).
 //
 // The tables of k_vs_prepare pay when many tiles share a value's likelihood

@@ -401,6 +401,9 @@ int dist_gibbs_sharded_device_normalise_ok(const dist_gibbs_t * g,
  * the per-value running sums and band tiles (default 2048);
  * "value_stream" = 0 (per-value tables always), 1 (auto: the table-free
  * kernel where a value has about one tile per batch), 2 (always);
+ * "narrow_tiles" = 0 (never), 1 (auto, default: launches too small to fill
+ * the chip take tiles of 64 rows and their vectors from LDS), 2 (whenever
+ * the vectors fit);
  * "device_normalise" = 1 (sweeps that stay on the value-sorted path with
  * integer statistics normalise the group set on the device and run without a
  * host round trip per batch) or 0 (default); "sharded_device_normalise" =
@@ -415,8 +418,8 @@ int dist_gibbs_path_counts(const dist_gibbs_t * g, uint64_t * value_sorted,
  * with running sums on, values whose arg-max rows had their own tile in the
  * last value-sorted launch, rows that launch handed to the wave-per-row
  * kernel, value-sorted batches that took the table-free kernel, batches
- * whose group set the device normalised itself (first min(n, 8) entries
- * are written) */
+ * whose group set the device normalised itself, value-sorted batches that
+ * took the small-launch kernel (first min(n, 9) entries are written) */
 int dist_gibbs_debug_counts(dist_gibbs_t * g, uint64_t * out, size_t n);
 /* HIP-event time (ms) and launch count of the score+sample kernel since the
  * last reset, measured on the engine's stream */

@@ -18,8 +18,10 @@ VS_ELIGIBLE = ("dd", "dd_skew", "bb", "dpd", "dpd_other", "gp", "bnb")
 def both(config, n, k, alpha, d, empty=1, dim=None, seed=workloads.SEED,
          mode=None):
     """mode: None = library default; 0 = generic kernel only; 2 = the
-    value-sorted kernel (per-value tables) whenever the feature list allows
-    it; 3 = its table-free form (k_vs_stream) whenever it does."""
+    value-sorted kernel (per-value tables, tiles of 128 rows) whenever the
+    feature list allows it; 3 = its table-free form (k_vs_stream) whenever it
+    does; 4 = its small-launch form (k_vs_narrow: tiles of 64 rows, vectors in
+    LDS) whenever it does."""
     from distributions_amd import engine
     osh, gsh, vals, assign = workloads.make(config, n, k, seed=seed, dim=dim)
     orc = ol.OracleMixture(alpha, d, osh)
@@ -28,6 +30,7 @@ def both(config, n, k, alpha, d, empty=1, dim=None, seed=workloads.SEED,
     if mode is not None:
         gpu.set_option("value_sorted", min(mode, 2))
         gpu.set_option("value_stream", 2 if mode == 3 else 0)
+        gpu.set_option("narrow_tiles", 2 if mode == 4 else 0)
     gpu.load_rows(vals, assign, k, empty)
     return orc, gpu
 
@@ -74,7 +77,7 @@ def test_row_scores_match_oracle(config):
 
 @pytest.mark.parametrize("config", CONFIGS)
 @pytest.mark.parametrize("batch", [256, 1000, 4096])
-@pytest.mark.parametrize("mode", [0, 2, 3])
+@pytest.mark.parametrize("mode", [0, 2, 3, 4])
 def test_batch_sweeps_bit_exact(config, batch, mode):
     if mode >= 2 and config not in VS_ELIGIBLE:
         pytest.skip("value-sorted kernel needs one small-domain feature")
@@ -90,14 +93,15 @@ def test_batch_sweeps_bit_exact(config, batch, mode):
         assert_same_state(orc, gpu, "%s sweep %d batch %d" % (config, sweep, batch))
     vs, generic = gpu.path_counts()
     assert (vs > 0 and generic == 0) if mode >= 2 else (vs == 0)
-    streamed = gpu.core.debug_counts()["stream_batches"]
-    assert streamed == (vs if mode == 3 else 0)
+    counts = gpu.core.debug_counts()
+    assert counts["stream_batches"] == (vs if mode == 3 else 0)
+    assert counts["narrow_batches"] == (vs if mode == 4 else 0)
 
 
 @pytest.mark.parametrize("config,dim,k", [("dd", 256, 64), ("dd_skew", 64, 16),
                                           ("dpd_other", 300, 24), ("bb", None, 8),
                                           ("gp", None, 12)])
-@pytest.mark.parametrize("mode", [None, 3])
+@pytest.mark.parametrize("mode", [None, 2, 3, 4])
 def test_value_sorted_larger_batches(config, dim, k, mode):
     """default mode picks the value-sorted kernel for large batches; groups of
     very different sizes make rows sit in the arg-max group (class B)."""
@@ -187,6 +191,9 @@ def test_device_side_normalisation_under_group_churn(config, dim, stream,
         gpu.set_option("value_sorted", 2)
         gpu.set_option("value_stream", stream)
         gpu.set_option("device_normalise", normalise)
+        # (tables: one engine through k_vs_narrow, the other through the
+        # 128-row tiles)
+        gpu.set_option("narrow_tiles", 2 * normalise)
         gpu.load_rows(vals, assign, k, empty)
         engines.append(gpu)
     seed = 4242
@@ -260,6 +267,7 @@ def test_randomised_configurations():
         gpu = engine.Gibbs(alpha, d, feats_g)
         gpu.set_option("value_sorted", int(rng.choice([0, 1, 2])))
         gpu.set_option("value_stream", int(rng.choice([0, 1, 2])))
+        gpu.set_option("narrow_tiles", int(rng.choice([0, 1, 2])))
         gpu.set_option("device_normalise", int(rng.choice([0, 1])))
         gpu.load_rows(vals, assign, k, empty)
         seed = int(rng.integers(1, 2 ** 31))

@@ -2,7 +2,7 @@
 go.  Needs the diagnostic build of the library (the stamps cost 3 us per
 launch and are compiled out otherwise):
     make -C distributions_amd/csrc stamps
-    DIST_VS_STAMPS=/tmp/st.bin python tools/vs_stamps.py run   # C2 probe
+    DIST_VS_STAMPS=/tmp/st.bin python tools/vs_stamps.py run [rows per sub-sweep]   # C2 probe
     python tools/vs_stamps.py /tmp/st.bin
     make -C distributions_amd/csrc          # back to the product build"""
 import os
@@ -83,7 +83,7 @@ def report(path):
           "corr(lifetime, start) %.2f" % (cs[0, 1], cs[0, 2], cs[0, 3]))
 
 
-def run():
+def run(batch=1_000_000):
     sys.path.insert(0, ROOT)
     import torch
     from distributions_amd import engine
@@ -97,13 +97,16 @@ def run():
         torch.int32)
     g = engine.Gibbs(1.0, 0.2, [engine.dd_shared([0.5] * dim)])
     g.load_rows_torch([col], assign, k, 1)
+    # (small sub-sweeps go through k_vs_narrow; its four phases are the rows'
+    # set-up, the vectors into LDS, the recurrences, the write back)
+    rows = n if batch >= 1_000_000 else 40 * batch
     for s in range(3):
-        g.sweep(0, n, 1_000_000, 5, draw_base=s * n)
+        g.sweep(0, rows, batch, 5, draw_base=s * n)
     report(os.environ["DIST_VS_STAMPS"])
 
 
 if __name__ == "__main__":
     if sys.argv[1] == "run":
-        run()
+        run(*[int(a) for a in sys.argv[2:3]])
     else:
         report(sys.argv[1])
