@@ -884,8 +884,9 @@ struct Gibbs {
     // and their vectors from LDS (k_vs_narrow): 0 never, 1 below
     // kVsNarrowBelowTiles regular tiles, 2 whenever the vectors fit
     int narrow_mode = 1;
+    int narrow_read_ahead = 0;   // float4s per vector: 0 auto, 4 or 8
     uint64_t narrow_batches = 0;
-    static constexpr uint32_t kVsNarrowBelowTiles = 2048;   // (measured)
+    static constexpr uint32_t kVsNarrowBelowTiles = 4100;   // (measured)
     bool use_narrow(const VsCache & c, int Kpad) const {
         if (narrow_mode == 0 || Kpad > kVsNarrowMaxK || !c.n_narrow_tiles)
             return false;
@@ -1516,12 +1517,25 @@ struct Gibbs {
             // a launch that cannot fill the chip spreads out: a wave per
             // workgroup (no band tiles on such launches)
             if (narrow) {
-                hipLaunchKernelGGL(
-                    (k_vs_narrow<KIND>), dim3(c->n_narrow_tiles), dim3(64),
-                    2 * ((size_t)T.Kpad + 2 * kVsUnroll) * sizeof(float),
-                    stream(), *P, T, c->narrow_tiles.p, c->n_narrow_tiles,
-                    c->sorted_rows.p, self->deferred.p,
-                    self->deferred_count.p);
+                // (waves alone or in pairs on their SIMDs read a whole chunk
+                // ahead; more of them half a chunk, and four fit)
+                const size_t lds =
+                    2 * ((size_t)T.Kpad + 2 * kVsUnroll) * sizeof(float);
+#define VS_NARROW(HQ)                                                        \
+                hipLaunchKernelGGL(                                          \
+                    (k_vs_narrow<KIND, HQ>), dim3(c->n_narrow_tiles),        \
+                    dim3(64), lds, stream(), *P, T, c->narrow_tiles.p,       \
+                    c->n_narrow_tiles, c->sorted_rows.p, self->deferred.p,   \
+                    self->deferred_count.p)
+                const bool whole =
+                    self->narrow_read_ahead
+                        ? self->narrow_read_ahead == 8
+                        : c->n_narrow_tiles <= 8u * (uint32_t)self->cu_count();
+                if (whole)
+                    VS_NARROW(8);
+                else
+                    VS_NARROW(4);
+#undef VS_NARROW
                 HIP_CHECK(hipGetLastError());
                 HIP_CHECK(hipEventRecord(self->ev1, stream()));
                 return;
@@ -3477,6 +3491,11 @@ int dist_gibbs_set_option(dist_gibbs_t * g, const char * name, int value) {
             g->impl->narrow_mode = value;
             // (cached ranges carry their tile lists)
             g->impl->drop_overlapping_caches(0, g->impl->n_rows, false);
+        } else if (key == "narrow_read_ahead") {
+            // k_vs_narrow's instance: 0 by launch size, 4 or 8 float4s
+            DIST_REQUIRE(value == 0 || value == 4 || value == 8,
+                         "narrow_read_ahead: 0, 4 or 8");
+            g->impl->narrow_read_ahead = value;
         } else if (key == "device_normalise") {
             // sweeps whose batches all take the value-sorted path normalise
             // the group set on the device (no host round trip per batch):

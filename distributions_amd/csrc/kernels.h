@@ -2169,14 +2169,14 @@ constexpr int kVsNarrowMaxK = 4096;   // two vectors of Kpad + 64 floats in LDS
 // 32 -> 27 us at 65 536 rows, the sub-sweep as a whole 10 % slower: a row
 // costs the wave-per-row kernel what a tile costs here.)
 
-template <bool DUAL, bool SCAN>
-__device__ __forceinline__ void vs_narrow_chunk(
-        float & acc, const float4 (&a)[kVsUnroll / 4],
-        const float4 (&b)[kVsUnroll / 4], bool is_b, bool own, int k0, int g,
-        float l_own) {
+// 4 * HQ entries (a chunk, or half of one) of the recurrences, one row per lane
+template <bool DUAL, bool SCAN, int HQ>
+__device__ __forceinline__ void vs_narrow_part(
+        float & acc, const float4 (&a)[HQ], const float4 (&b)[HQ],
+        bool is_b, bool own, int k0, int g, float l_own) {
     if (own) {   // (wave-uniform) a lane's own slot falls into this chunk
 #pragma unroll
-        for (int q = 0; q < kVsUnroll / 4; ++q) {
+        for (int q = 0; q < HQ; ++q) {
             const float ea[4] = {a[q].x, a[q].y, a[q].z, a[q].w};
             const float eb[4] = {b[q].x, b[q].y, b[q].z, b[q].w};
 #pragma unroll
@@ -2188,7 +2188,7 @@ __device__ __forceinline__ void vs_narrow_chunk(
         }
     } else {
 #pragma unroll
-        for (int q = 0; q < kVsUnroll / 4; ++q) {
+        for (int q = 0; q < HQ; ++q) {
             const float ea[4] = {a[q].x, a[q].y, a[q].z, a[q].w};
             const float eb[4] = {b[q].x, b[q].y, b[q].z, b[q].w};
 #pragma unroll
@@ -2201,59 +2201,64 @@ __device__ __forceinline__ void vs_narrow_chunk(
 }
 
 // the two recurrences of vs_sum_and_scan for one row per lane; va / vb: the
-// vectors in LDS (vb only read when DUAL), a chunk of slack behind each
-template <bool DUAL>
+// vectors in LDS (vb only read when DUAL), slack behind each.  The vector is
+// read one part ahead of the part in use: a whole chunk (HQ = 8: 32 registers
+// per vector and buffer, two such waves per SIMD -- a wave alone needs that
+// distance to hide the read) or half of one (HQ = 4: four waves per SIMD).
+template <bool DUAL, int HQ>
 __device__ __forceinline__ int vs_narrow_row(
         const float * va, const float * vb, bool is_b, int K, int g,
         float l_own, float u, bool active) {
+    constexpr int parts = kVsUnroll / 4 / HQ;   // per chunk: 1 or 2
     const int nchunks = (K + kVsUnroll - 1) / kVsUnroll;
+    const int nsteps = nchunks * parts;
     const int gchunk = active ? g / kVsUnroll : -1;
     const float4 * a4 = reinterpret_cast<const float4 *>(va);
     const float4 * b4 = reinterpret_cast<const float4 *>(vb);
-    float4 a0[kVsUnroll / 4], a1[kVsUnroll / 4];
-    float4 b0[kVsUnroll / 4], b1[kVsUnroll / 4];
-    auto fetch = [&](int c, float4 (&a)[kVsUnroll / 4],
-                     float4 (&b)[kVsUnroll / 4]) {
+    float4 a0[HQ], a1[HQ], b0[HQ], b1[HQ];
+    auto fetch = [&](int s, float4 (&a)[HQ], float4 (&b)[HQ]) {
 #pragma unroll
-        for (int q = 0; q < kVsUnroll / 4; ++q) {
-            a[q] = a4[c * (kVsUnroll / 4) + q];
-            b[q] = DUAL ? b4[c * (kVsUnroll / 4) + q] : a[q];
+        for (int q = 0; q < HQ; ++q) {
+            a[q] = a4[s * HQ + q];
+            b[q] = DUAL ? b4[s * HQ + q] : a[q];
         }
     };
     // total = ((l_0 + l_1) + l_2) + ...                  random.cc:100-103
     float acc = 0.f;
     fetch(0, a0, b0);
-    for (int c = 0; c < nchunks; c += 2) {
-        fetch(c + 1, a1, b1);
-        vs_narrow_chunk<DUAL, false>(acc, a0, b0, is_b, __any(gchunk == c),
-                                     c * kVsUnroll, g, l_own);
-        fetch(c + 2, a0, b0);
-        if (c + 1 < nchunks)
-            vs_narrow_chunk<DUAL, false>(acc, a1, b1, is_b,
-                                         __any(gchunk == c + 1),
-                                         (c + 1) * kVsUnroll, g, l_own);
+    for (int s = 0; s < nsteps; s += 2) {
+        fetch(s + 1, a1, b1);
+        vs_narrow_part<DUAL, false, HQ>(acc, a0, b0, is_b,
+                                        __any(gchunk == s / parts),
+                                        s * 4 * HQ, g, l_own);
+        fetch(s + 2, a0, b0);
+        if (s + 1 < nsteps)
+            vs_narrow_part<DUAL, false, HQ>(acc, a1, b1, is_b,
+                                            __any(gchunk == (s + 1) / parts),
+                                            (s + 1) * 4 * HQ, g, l_own);
     }
     // t = total*u; t -= l_k until t <= 0                 random.hpp:323-330
     float t = acc * u;
     float t_start = t;
     int npos = 0;
-    auto book = [&]() {
+    auto book = [&]() {   // at the end of a chunk
         const bool pos = t > 0.f;
         t_start = pos ? t : t_start;
         npos += pos ? 1 : 0;
         return __builtin_amdgcn_ballot_w64(active && pos) != 0;
     };
     fetch(0, a0, b0);
-    for (int c = 0; c < nchunks; c += 2) {
-        fetch(c + 1, a1, b1);
-        vs_narrow_chunk<DUAL, true>(t, a0, b0, is_b, __any(gchunk == c),
-                                    c * kVsUnroll, g, l_own);
-        if (!book()) break;
-        fetch(c + 2, a0, b0);
-        if (c + 1 < nchunks) {
-            vs_narrow_chunk<DUAL, true>(t, a1, b1, is_b,
-                                        __any(gchunk == c + 1),
-                                        (c + 1) * kVsUnroll, g, l_own);
+    for (int s = 0; s < nsteps; s += 2) {
+        fetch(s + 1, a1, b1);
+        vs_narrow_part<DUAL, true, HQ>(t, a0, b0, is_b,
+                                       __any(gchunk == s / parts), s * 4 * HQ,
+                                       g, l_own);
+        if (parts == 1 && !book()) break;
+        fetch(s + 2, a0, b0);
+        if (s + 1 < nsteps) {
+            vs_narrow_part<DUAL, true, HQ>(t, a1, b1, is_b,
+                                           __any(gchunk == (s + 1) / parts),
+                                           (s + 1) * 4 * HQ, g, l_own);
             if (!book()) break;
         }
     }
@@ -2262,15 +2267,13 @@ __device__ __forceinline__ int vs_narrow_row(
         // replay the crossing chunk (as vs_sum_and_scan does)
         const float4 * chunk = reinterpret_cast<const float4 *>(
             ((DUAL && is_b) ? vb : va) + npos * kVsUnroll);
-        float4 v[kVsUnroll / 4];
-#pragma unroll
-        for (int q = 0; q < kVsUnroll / 4; ++q) v[q] = chunk[q];
         const int own = g - npos * kVsUnroll;   // in 0..31 or not
         float tt = t_start;
         int steps = 0;
 #pragma unroll
         for (int q = 0; q < kVsUnroll / 4; ++q) {
-            const float e[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+            const float4 v = chunk[q];
+            const float e[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 tt -= (own == 4 * q + i) ? l_own : e[i];
@@ -2282,7 +2285,8 @@ __device__ __forceinline__ int vs_narrow_row(
     return f < K - 1 ? f : K - 1;
 }
 
-template <int KIND>
+// HQ: float4s read ahead per vector (vs_narrow_row)
+template <int KIND, int HQ>
 __global__ __launch_bounds__(64) void k_vs_narrow(
         SweepParams P, VsTables T, const VsTile * __restrict__ tiles,
         uint32_t n_tiles, const uint32_t * __restrict__ sorted_rows,
@@ -2385,10 +2389,10 @@ __global__ __launch_bounds__(64) void k_vs_narrow(
     const float * fb = reinterpret_cast<const float *>(sb);
     int g2;
     if (any_a && any_b)
-        g2 = vs_narrow_row<true>(fa, fb, is_b, K, g, l_own, u, valid);
+        g2 = vs_narrow_row<true, HQ>(fa, fb, is_b, K, g, l_own, u, valid);
     else
-        g2 = vs_narrow_row<false>(any_b ? fb : fa, fb, false, K, g, l_own, u,
-                                  valid);
+        g2 = vs_narrow_row<false, HQ>(any_b ? fb : fa, fb, false, K, g, l_own,
+                                      u, valid);
 #ifdef DIST_VS_STAMPS
     if (T.stamps) st3 = __builtin_amdgcn_s_memtime();
 #endif

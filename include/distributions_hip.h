@@ -403,7 +403,8 @@ int dist_gibbs_sharded_device_normalise_ok(const dist_gibbs_t * g,
  * kernel where a value has about one tile per batch), 2 (always);
  * "narrow_tiles" = 0 (never), 1 (auto, default: launches too small to fill
  * the chip take tiles of 64 rows and their vectors from LDS), 2 (whenever
- * the vectors fit);
+ * the vectors fit); "narrow_read_ahead" = 0 (by launch size), 4 or 8 (that
+ * kernel's instance);
  * "device_normalise" = 1 (sweeps that stay on the value-sorted path with
  * integer statistics normalise the group set on the device and run without a
  * host round trip per batch) or 0 (default); "sharded_device_normalise" =

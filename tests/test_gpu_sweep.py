@@ -20,8 +20,8 @@ def both(config, n, k, alpha, d, empty=1, dim=None, seed=workloads.SEED,
     """mode: None = library default; 0 = generic kernel only; 2 = the
     value-sorted kernel (per-value tables, tiles of 128 rows) whenever the
     feature list allows it; 3 = its table-free form (k_vs_stream) whenever it
-    does; 4 = its small-launch form (k_vs_narrow: tiles of 64 rows, vectors in
-    LDS) whenever it does."""
+    does; 4, 5 = its small-launch form (k_vs_narrow: tiles of 64 rows, vectors
+    in LDS, read a whole / half a chunk ahead) whenever it does."""
     from distributions_amd import engine
     osh, gsh, vals, assign = workloads.make(config, n, k, seed=seed, dim=dim)
     orc = ol.OracleMixture(alpha, d, osh)
@@ -30,7 +30,8 @@ def both(config, n, k, alpha, d, empty=1, dim=None, seed=workloads.SEED,
     if mode is not None:
         gpu.set_option("value_sorted", min(mode, 2))
         gpu.set_option("value_stream", 2 if mode == 3 else 0)
-        gpu.set_option("narrow_tiles", 2 if mode == 4 else 0)
+        gpu.set_option("narrow_tiles", 2 if mode in (4, 5) else 0)
+        gpu.set_option("narrow_read_ahead", {4: 8, 5: 4}.get(mode, 0))
     gpu.load_rows(vals, assign, k, empty)
     return orc, gpu
 
@@ -77,7 +78,7 @@ def test_row_scores_match_oracle(config):
 
 @pytest.mark.parametrize("config", CONFIGS)
 @pytest.mark.parametrize("batch", [256, 1000, 4096])
-@pytest.mark.parametrize("mode", [0, 2, 3, 4])
+@pytest.mark.parametrize("mode", [0, 2, 3, 4, 5])
 def test_batch_sweeps_bit_exact(config, batch, mode):
     if mode >= 2 and config not in VS_ELIGIBLE:
         pytest.skip("value-sorted kernel needs one small-domain feature")
@@ -95,13 +96,13 @@ def test_batch_sweeps_bit_exact(config, batch, mode):
     assert (vs > 0 and generic == 0) if mode >= 2 else (vs == 0)
     counts = gpu.core.debug_counts()
     assert counts["stream_batches"] == (vs if mode == 3 else 0)
-    assert counts["narrow_batches"] == (vs if mode == 4 else 0)
+    assert counts["narrow_batches"] == (vs if mode in (4, 5) else 0)
 
 
 @pytest.mark.parametrize("config,dim,k", [("dd", 256, 64), ("dd_skew", 64, 16),
                                           ("dpd_other", 300, 24), ("bb", None, 8),
                                           ("gp", None, 12)])
-@pytest.mark.parametrize("mode", [None, 2, 3, 4])
+@pytest.mark.parametrize("mode", [None, 2, 3, 4, 5])
 def test_value_sorted_larger_batches(config, dim, k, mode):
     """default mode picks the value-sorted kernel for large batches; groups of
     very different sizes make rows sit in the arg-max group (class B)."""
@@ -194,6 +195,7 @@ def test_device_side_normalisation_under_group_churn(config, dim, stream,
         # (tables: one engine through k_vs_narrow, the other through the
         # 128-row tiles)
         gpu.set_option("narrow_tiles", 2 * normalise)
+        gpu.set_option("narrow_read_ahead", 4)
         gpu.load_rows(vals, assign, k, empty)
         engines.append(gpu)
     seed = 4242
@@ -268,6 +270,7 @@ def test_randomised_configurations():
         gpu.set_option("value_sorted", int(rng.choice([0, 1, 2])))
         gpu.set_option("value_stream", int(rng.choice([0, 1, 2])))
         gpu.set_option("narrow_tiles", int(rng.choice([0, 1, 2])))
+        gpu.set_option("narrow_read_ahead", int(rng.choice([0, 4, 8])))
         gpu.set_option("device_normalise", int(rng.choice([0, 1])))
         gpu.load_rows(vals, assign, k, empty)
         seed = int(rng.integers(1, 2 ** 31))

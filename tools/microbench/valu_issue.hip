@@ -13,7 +13,7 @@
 // reported.  (The round's first version divided the median wave's time by the
 // waves it ASSUMED shared a SIMD; two 1024-thread workgroups per CU ran one
 // after the other, so its eight-wave lines were four-wave lines.)
-// hipcc -O3 --offload-arch=gfx950 -o valu_issue valu_issue.hip
+// hipcc -O3 -std=c++17 --offload-arch=gfx950 -o valu_issue valu_issue.hip
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdio>

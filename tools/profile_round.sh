@@ -31,12 +31,18 @@ cp $(ls $out/c3/*/*kernel_stats.csv | head -1) $out/kernel_stats_c3_gp_nich.csv
 rocprofv3 --pmc $SQ --kernel-trace --output-format csv -d $out/c3s -- python3 $B $C3 > /dev/null 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/c3f -- python3 $B $C3 > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/c3w -- python3 $B $C3 > /dev/null 2>&1
+# the same workload in sub-sweeps of 65 536 rows (k_vs_narrow)
+SM="--batch 65536 --steps 2 --warmup 1"
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/sm -- python3 $B $SM > $out/bench_b65536_under_rocprof.json 2>/dev/null
+cp $(ls $out/sm/*/*kernel_stats.csv | head -1) $out/kernel_stats_b65536.csv
+rocprofv3 --pmc $SQ --kernel-trace --output-format csv -d $out/sms -- python3 $B $SM > /dev/null 2>&1
 python3 tools/counters.py $out/counters.json \
     "k_vs_sample<dd>=k_vs_sample<0, 1024>:1000000:100000" \
+    "k_vs_narrow<dd>=k_vs_narrow<0>:65536:60000" \
     "k_vs_stream<dpd>=k_vs_stream<4>:1000000:100000" \
     "k_sweep_sample<gp_nich>=k_sweep_sample<2, 3, 2>:1000000:100000" \
-    -- $out/sq $out/grbm $out/fetch $out/write $out/c5f $out/c5w $out/c5s $out/c3s $out/c3f $out/c3w > $out/counters.log 2>&1
-for d in sq grbm fetch write c5f c5w c5s c3s c3f c3w; do
+    -- $out/sq $out/grbm $out/fetch $out/write $out/sms $out/c5f $out/c5w $out/c5s $out/c3s $out/c3f $out/c3w > $out/counters.log 2>&1
+for d in sq grbm fetch write sms c5f c5w c5s c3s c3f c3w; do
   python3 tools/pmc_summary.py $out/$d k_ > $out/pmc_$d.txt 2>/dev/null
 done
 # the bench line of record (with the CPU baseline), the other configurations,
@@ -51,6 +57,6 @@ python3 bench.py --cpu-rows 0 --other-batches= --steps 5 --values zipf 2>/dev/nu
 python3 bench.py --cpu-rows 0 --other-batches= --steps 5 --d 0 2>/dev/null | tail -1 >> $out/bench_other_configs.jsonl
 python3 bench.py --cpu-rows 0 --other-batches= --force-collective 2>/dev/null | tail -1 > $out/bench_collective_one_rank.json
 python3 bench.py --cpu-rows 0 --other-batches= --device-normalise 1 2>/dev/null | tail -1 > $out/bench_device_normalise.json
-(cd tools/microbench && /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -o valu_issue valu_issue.hip && ./valu_issue) > $out/valu_issue.txt 2>&1
-rm -rf $out/trace $out/sq $out/grbm $out/fetch $out/write $out/c5 $out/c5f $out/c5w $out/c5s $out/c3 $out/c3s $out/c3f $out/c3w
+(cd tools/microbench && /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -o valu_issue valu_issue.hip && ./valu_issue) > $out/valu_issue.txt 2>&1
+rm -rf $out/sm $out/sms $out/trace $out/sq $out/grbm $out/fetch $out/write $out/c5 $out/c5f $out/c5w $out/c5s $out/c3 $out/c3s $out/c3f $out/c3w
 ls -la $out
