@@ -77,9 +77,11 @@ def parse():
     ap.add_argument("--value-stream", type=int, default=1,
                     help="the table-free value-sorted kernel: 0 never, "
                          "1 auto, 2 always")
-    ap.add_argument("--device-normalise", type=int, default=0,
-                    help="1: the group set is normalised on the device, no "
-                         "host round trip per sub-sweep (0: the default)")
+    ap.add_argument("--device-normalise", type=int, default=2,
+                    help="the group set is normalised on the device, no host "
+                         "round trip per sub-sweep: 0 never, 1 always, 2 "
+                         "(the library's default) for sub-sweeps of at most "
+                         "524 288 rows")
     ap.add_argument("--narrow-tiles", type=int, default=1,
                     help="launches too small to fill the chip take tiles of "
                          "64 rows with their vectors in LDS (k_vs_narrow): "

@@ -106,7 +106,7 @@ def trial(seed, large=False):
     gpu.set_option("value_stream", int(rng.choice([0, 1, 2])))
     gpu.set_option("narrow_tiles", int(rng.choice([0, 1, 2])))
     gpu.set_option("narrow_read_ahead", int(rng.choice([0, 4, 8])))
-    gpu.set_option("device_normalise", int(rng.choice([0, 1])))
+    gpu.set_option("device_normalise", int(rng.choice([0, 1, 2])))
     gpu.load_rows(vals, assign, k, empty)
     what = "seed %d: n=%d k=%d empty=%d feats=%s mode=%d %s" % (
         seed, n, k, empty, "+".join(desc), mode,

@@ -38,7 +38,7 @@ cp $(ls $out/sm/*/*kernel_stats.csv | head -1) $out/kernel_stats_b65536.csv
 rocprofv3 --pmc $SQ --kernel-trace --output-format csv -d $out/sms -- python3 $B $SM > /dev/null 2>&1
 python3 tools/counters.py $out/counters.json \
     "k_vs_sample<dd>=k_vs_sample<0, 1024>:1000000:100000" \
-    "k_vs_narrow<dd>=k_vs_narrow<0>:65536:60000" \
+    "k_vs_narrow<dd>=k_vs_narrow<0, 8>:65536:60000" \
     "k_vs_stream<dpd>=k_vs_stream<4>:1000000:100000" \
     "k_sweep_sample<gp_nich>=k_sweep_sample<2, 3, 2>:1000000:100000" \
     -- $out/sq $out/grbm $out/fetch $out/write $out/sms $out/c5f $out/c5w $out/c5s $out/c3s $out/c3f $out/c3w > $out/counters.log 2>&1
