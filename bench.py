@@ -79,13 +79,17 @@ def parse():
                          "1 auto, 2 always")
     ap.add_argument("--device-normalise", type=int, default=2,
                     help="the group set is normalised on the device, no host "
-                         "round trip per sub-sweep: 0 never, 1 always, 2 "
-                         "(the library's default) for sub-sweeps of at most "
-                         "524 288 rows")
+                         "round trip per sub-sweep: 0 never, 1 or 2 (the "
+                         "library's default) where it applies")
     ap.add_argument("--narrow-tiles", type=int, default=1,
                     help="launches too small to fill the chip take tiles of "
                          "64 rows with their vectors in LDS (k_vs_narrow): "
                          "0 never, 1 auto, 2 whenever the vectors fit")
+    ap.add_argument("--kernel-timing", type=int, default=8,
+                    help="HIP events around every n-th score+sample launch "
+                         "of the timed region (the roofline's duration is "
+                         "their average; two events cost a sub-sweep 8 us): "
+                         "1 all, 0 none")
     ap.add_argument("--other-batches", default="65536",
                     help="comma-separated sub-sweep sizes timed besides "
                          "--batch (a few steps each, reported in "
@@ -442,6 +446,7 @@ def run_rank(args):
         g.set_option("value_stream", args.value_stream)
         g.set_option("device_normalise", args.device_normalise)
         g.set_option("narrow_tiles", args.narrow_tiles)
+        g.set_option("kernel_timing", args.kernel_timing)
         initial = assign.clone()   # the engine updates `assign` in place
         g.load_rows_torch(columns, assign, k, 1, row_offset=row_offset)
         sharded = engine.ShardedGibbs(
@@ -557,6 +562,9 @@ def run_rank(args):
                        if usable and ctr.get("valu_busy_cycles") is not None
                        else None)
         secs = 1e-3 * avg_ms
+        if secs <= 0.0:   # (--kernel-timing 0: nothing was measured)
+            secs = float("nan")
+            traffic = valu_cycles = None
         hbm_frac = (traffic / secs / 1e9 / HBM_PEAK_GBS
                     if traffic is not None else None)
         valu_frac = (valu_cycles / (SIMDS * CLOCK_GHZ * 1e9 * secs)
@@ -581,15 +589,18 @@ def run_rank(args):
         roof.update({
             "traffic": traffic,
             "algorithmic_bytes_per_row": bytes_per_row,
-            "algorithmic_GBps": bytes_per_row * rows_per_launch / secs / 1e9,
+            "algorithmic_GBps": (bytes_per_row * rows_per_launch / secs / 1e9
+                                 if secs == secs else None),
             "rows_per_launch": rows_per_launch,
-            "avg_launch_ms": avg_ms,
+            "avg_launch_ms": avg_ms if secs == secs else None,
             "launches": launches,
             "counters": (None if ctr is None else
                          {"file": "profiles/r2_counters.json",
                           "stale": ctr["stale"],
                           "rows_per_launch": ctr["rows_per_launch"]}),
-            "note": "avg_launch_ms: HIP events on the launch stream, this "
+            "timed_every": args.kernel_timing,
+            "note": "avg_launch_ms: HIP events on the launch stream around "
+                    "every `timed_every`-th launch of the timed region, this "
                     "run.  frac: VALU-busy cycles (SQ_ACTIVE_INST_VALU x 4) "
                     "over 1024 SIMDs x 2.4 GHz x kernel time for the "
                     "VALU-bound kernels, HBM bytes (FETCH_SIZE + WRITE_SIZE) "

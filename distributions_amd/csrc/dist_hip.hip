@@ -918,13 +918,25 @@ struct Gibbs {
     DeviceBuf<DevState> dev_state;
     DeviceBuf<int32_t> snap_counts;   // group sizes at batch entry
     bool async_active = false;
-    // 0 never, 1 where it applies, 2 (default) where it applies and pays
+    // 0 never, 1 where it applies (2: the same; default)
     int device_normalise_mode = 2;
     bool sharded_device_normalise = false;   // the ranks agreed on it
     uint64_t async_batches = 0;
     std::vector<hipEvent_t> ev_pool;
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // The score+sample kernel of a batch sits between two events
+    // (dist_gibbs_kernel_stats).  An event is a packet of its own on the
+    // queue: around every batch they cost the headline workload 8 us of a
+    // sub-sweep's 134 (events attached to the dispatch itself,
+    // hipExtLaunchKernelGGL, cost the same).  "kernel_timing" = n times every
+    // n-th batch (1: all, the default; 0: none).
+    int kernel_timing = 1;
+    uint64_t timing_tick = 0;
+    bool timing_this_batch = true;
+    void mark(hipEvent_t e) {
+        if (timing_this_batch) HIP_CHECK(hipEventRecord(e, stream()));
+    }
     double kernel_ms = 0.0;
     uint64_t kernel_launches = 0, kernel_rows = 0;
 
@@ -1325,7 +1337,7 @@ struct Gibbs {
         deferred.reserve(std::max<size_t>(n, 1), 0);
         deferred_count.reserve(1, 0);
         HIP_CHECK(hipMemsetAsync(deferred_count.p, 0, 4, stream()));
-        HIP_CHECK(hipEventRecord(ev0, stream()));
+        mark(ev0);
         LAUNCH(k_row_prepass, n, P, prog, own_score.p, deferred.p,
                deferred_count.p);
         const unsigned blocks = (unsigned)std::min<size_t>(
@@ -1345,7 +1357,7 @@ struct Gibbs {
             DeferredLaunch D{&Q};
             dispatch(D);
         }
-        HIP_CHECK(hipEventRecord(ev1, stream()));
+        mark(ev1);
         return true;
     }
     struct SampleLaunch {
@@ -1357,11 +1369,11 @@ struct Gibbs {
             // >> 256 workgroups to fill 256 CUs; grid-stride beyond that
             const unsigned blocks = (unsigned)std::min<size_t>(
                 (n + kBlock - 1) / kBlock, 256 * 16);
-            HIP_CHECK(hipEventRecord(self->ev0, stream()));
+            self->mark(self->ev0);
             hipLaunchKernelGGL((k_sweep_sample<A, B, NF>), dim3(blocks),
                                dim3(kBlock), 0, stream(), *P);
             HIP_CHECK(hipGetLastError());
-            HIP_CHECK(hipEventRecord(self->ev1, stream()));
+            self->mark(self->ev1);
         }
     };
     struct RowScoreLaunch {
@@ -1514,7 +1526,7 @@ struct Gibbs {
                                stream(), *P, T, self->deferred_count.p,
                                c->n_other);
             HIP_CHECK(hipGetLastError());
-            HIP_CHECK(hipEventRecord(self->ev0, stream()));
+            self->mark(self->ev0);
             // a launch that cannot fill the chip spreads out: a wave per
             // workgroup (no band tiles on such launches)
             if (narrow) {
@@ -1538,7 +1550,7 @@ struct Gibbs {
                     VS_NARROW(4);
 #undef VS_NARROW
                 HIP_CHECK(hipGetLastError());
-                HIP_CHECK(hipEventRecord(self->ev1, stream()));
+                self->mark(self->ev1);
                 return;
             }
             const bool small = !T.band_mode && c->n_tiles < 4096;
@@ -1560,7 +1572,7 @@ struct Gibbs {
                                    band_ids, c->sorted_rows.p,
                                    self->deferred.p, self->deferred_count.p);
             HIP_CHECK(hipGetLastError());
-            HIP_CHECK(hipEventRecord(self->ev1, stream()));
+            self->mark(self->ev1);
         }
     };
 
@@ -1584,7 +1596,7 @@ struct Gibbs {
             const uint32_t per = kVsStreamBlock / 64;
             hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, stream(),
                                self->deferred_count.p, c->n_other);
-            HIP_CHECK(hipEventRecord(self->ev0, stream()));
+            self->mark(self->ev0);
             if (c->n_tiles)
                 hipLaunchKernelGGL((k_vs_stream<KIND>),
                                    dim3((c->n_tiles + per - 1) / per),
@@ -1592,7 +1604,7 @@ struct Gibbs {
                                    c->tiles.p, c->n_tiles, c->sorted_rows.p,
                                    self->deferred.p, self->deferred_count.p);
             HIP_CHECK(hipGetLastError());
-            HIP_CHECK(hipEventRecord(self->ev1, stream()));
+            self->mark(self->ev1);
         }
     };
     void sample_value_stream(SweepParams & P, VsCache & c) {
@@ -1758,6 +1770,8 @@ struct Gibbs {
         batch_value_sorted = false;
         moves_in_row_order = false;
         if (r0 == r1) return;
+        timing_this_batch =
+            kernel_timing > 0 && timing_tick++ % (uint64_t)kernel_timing == 0;
         upload_maps();
         SweepParams P = params(r0, r1, seed, draw_base);
         batch_value_sorted = use_value_sorted(r1 - r0);
@@ -1769,12 +1783,12 @@ struct Gibbs {
         } else if (r1 - r0 <= 2048 && wave_rows_fit()) {
             // a handful of rows (the sequential chain is one): a wave each
             prepare(P, false);
-            HIP_CHECK(hipEventRecord(ev0, stream()));
+            mark(ev0);
             WaveRowsLaunch L{&P, K(),
                              (unsigned)((r1 - r0 + kBlock / 64 - 1)
                                         / (kBlock / 64))};
             dispatch(L);
-            HIP_CHECK(hipEventRecord(ev1, stream()));
+            mark(ev1);
             generic_batches += 1;
         } else if (uses_runtime_kernel() && sample_by_program(P)) {
             generic_batches += 1;
@@ -1791,6 +1805,7 @@ struct Gibbs {
     void collect_timing() {
         if (!timing_pending) return;
         timing_pending = false;
+        if (!timing_this_batch) return;
         HIP_CHECK(hipEventSynchronize(ev1));
         float ms = 0.f;
         HIP_CHECK(hipEventElapsedTime(&ms, ev0, ev1));
@@ -2205,20 +2220,20 @@ struct Gibbs {
     }
     // Every batch of the sweep takes the value-sorted path, the statistics
     // are integers, and the bound on the group count fits the kernels' LDS.
-    // (measured, C2: sub-sweeps of 16 384 / 65 536 / 262 144 rows run 11 / 13 /
-    // 5 % faster when the host does not wait for each one; at 10^6 rows the
-    // host's look at the group sizes hides behind the kernels and the extra
-    // launch costs 2 %)
-    static constexpr size_t kAsyncAutoRows = 524288;
+    // (measured, C2: with the runs left open across sweeps -- settle() -- the
+    // host's wait for each sub-sweep's group sizes costs 6 % at 10^6 rows per
+    // sub-sweep and 18 % at 65 536; while every sweep pulled the state back it
+    // only paid below some 500 000 rows)
     bool async_eligible(size_t r0, size_t r1, size_t batch) const {
         if (device_normalise_mode == 0 || cluster != 0 || F() != 1) return false;
-        if (device_normalise_mode == 2 && batch > kAsyncAutoRows) return false;
         if (r1 <= r0 || any_float_stats() || py.n_empty < 1) return false;
         const size_t last = (r1 - r0) % batch;
         if (!use_value_sorted(std::min(batch, r1 - r0))) return false;
         if (last && !use_value_sorted(last)) return false;
         const size_t n_batches = (r1 - r0 + batch - 1) / batch;
-        const size_t bound = (size_t)K() + n_batches * (size_t)py.n_empty;
+        return async_bound_fits((size_t)K() + n_batches * (size_t)py.n_empty);
+    }
+    static bool async_bound_fits(size_t bound) {
         if (normalise_lds((int)bound) > 150 * 1024) return false;
         // k_vs_apply's plain form must fit (see apply_ints)
         return bound * 4 <= 144 * 1024;
@@ -2314,8 +2329,21 @@ struct Gibbs {
     // the kernels read is put on the device, and K() becomes the bound.
     hipEvent_t async_own0 = nullptr, async_own1 = nullptr;
     std::vector<size_t> async_rows;   // rows of each batch sampled (timing)
-    void async_begin(size_t n_batches) {
+    std::vector<char> async_timed;    // ... and whether its events were set
+    // A run stays open when its sweep returns (the host's mirrors are pulled
+    // by the next call that is not another such sweep: settle()), so that
+    // consecutive sweeps pay for the hand-over of the state once: room for
+    // kAsyncSweeps sweeps like the first is reserved where the kernels' LDS
+    // allows, and async_left counts the batches still covered.
+    static constexpr size_t kAsyncSweeps = 8;
+    size_t async_left = 0;
+    void async_begin(size_t n_first) {
         const int K0 = K();
+        size_t n_batches = kAsyncSweeps * n_first;
+        if (!async_bound_fits((size_t)K0 + n_batches * (size_t)py.n_empty)
+            || n_batches > 4096)
+            n_batches = n_first;
+        async_left = n_batches;
         const int bound = K0 + (int)n_batches * py.n_empty;
         py.reserve(bound);
         for (auto & s : feats) s->reserve(bound);
@@ -2350,6 +2378,7 @@ struct Gibbs {
         async_own0 = ev0;
         async_own1 = ev1;
         async_rows.clear();
+        async_timed.clear();
         py.counts.resize((size_t)bound, 0);   // from here on K() is the bound
         async_active = true;
         pairs_ticket = 0;
@@ -2363,6 +2392,7 @@ struct Gibbs {
         DIST_REQUIRE(e == b || batch_value_sorted,
                      "internal: device-normalised run left its path");
         async_rows.push_back(e - b);
+        async_timed.push_back(e > b && timing_this_batch ? 1 : 0);
         async_batches += 1;
     }
     // back to host-driven operation; `failed`: on the way out of an error
@@ -2380,7 +2410,7 @@ struct Gibbs {
         async_active = false;
         pull_host_state();
         for (size_t i = 0; i < async_rows.size(); ++i) {
-            if (!async_rows[i]) continue;
+            if (!async_rows[i] || !async_timed[i]) continue;
             float ms = 0.f;
             HIP_CHECK(hipEventElapsedTime(&ms, ev_pool[2 * i],
                                           ev_pool[2 * i + 1]));
@@ -2391,7 +2421,9 @@ struct Gibbs {
     }
     void sweep_async(size_t r0, size_t r1, size_t batch, uint32_t seed,
                      uint64_t draw_base) {
-        async_begin((r1 - r0 + batch - 1) / batch);
+        const size_t n_batches = (r1 - r0 + batch - 1) / batch;
+        if (!async_active) async_begin(n_batches);   // else: it goes on
+        async_left -= n_batches;
         try {
             for (size_t b = r0; b < r1; b += batch) {
                 async_sample(b, std::min(r1, b + batch), seed, draw_base);
@@ -2402,7 +2434,20 @@ struct Gibbs {
             async_end(true);
             throw;
         }
-        async_end(false);
+        // (left open: settle())
+    }
+    // may this sweep go on with the open device-normalised run?
+    bool async_continues(size_t r0, size_t r1, size_t batch) const {
+        if (device_normalise_mode == 0 || r1 <= r0) return false;
+        const size_t last = (r1 - r0) % batch;
+        if (!use_value_sorted(std::min(batch, r1 - r0))) return false;
+        if (last && !use_value_sorted(last)) return false;
+        return (r1 - r0 + batch - 1) / batch <= async_left;
+    }
+    // the host's mirrors are current again (every entry point but sweep()
+    // comes through here: dist_gibbs::impl)
+    void settle() {
+        if (async_active && !batch_open) async_end(false);
     }
     // the sharded loop (dist_gibbs_sweep_sharded): rank-local conditions; the
     // ranks must agree before they rely on it (engine.ShardedGibbs)
@@ -2425,6 +2470,13 @@ struct Gibbs {
                uint64_t draw_base) {
         DIST_REQUIRE(batch > 0, "batch_rows must be positive");
         DIST_REQUIRE(r0 <= r1 && r1 <= n_rows, "bad row range");
+        if (async_active) {   // an open run: go on with it, or close it
+            if (async_continues(r0, r1, batch)) {
+                sweep_async(r0, r1, batch, seed, draw_base);
+                return;
+            }
+            settle();
+        }
         if (async_eligible(r0, r1, batch)) {
             DIST_REQUIRE(!batch_open, "previous batch not finished");
             sweep_async(r0, r1, batch, seed, draw_base);
@@ -2542,7 +2594,26 @@ using namespace dist;
 struct dist_py_mixture { PyDriver impl; };
 struct dist_mixture { std::unique_ptr<Slave> impl; };
 struct dist_id_tracker { Tracker impl; };
-struct dist_gibbs { std::unique_ptr<Gibbs> impl; };
+// Every entry point reaches the engine through `impl->`, which first closes a
+// device-normalised run that a sweep left open (Gibbs::settle: the host's
+// mirrors of the group set are pulled from the device); dist_gibbs_sweep alone
+// takes `impl.open()` and may go on with it.
+struct GibbsRef {
+    std::unique_ptr<Gibbs> p;
+    // (a failure while pulling is recorded like any entry point's, and the
+    // call that follows meets the same broken device)
+    Gibbs * operator->() const {
+        (void)guarded([&] { p->settle(); });
+        return p.get();
+    }
+    Gibbs & operator*() const {
+        (void)guarded([&] { p->settle(); });
+        return *p;
+    }
+    Gibbs * open() const { return p.get(); }
+    void reset(Gibbs * q) { p.reset(q); }
+};
+struct dist_gibbs { GibbsRef impl; };
 
 extern "C" {
 
@@ -3234,7 +3305,8 @@ int dist_gibbs_sweep(dist_gibbs_t * g, size_t row_begin, size_t row_end,
                      size_t batch_rows, uint32_t seed_state,
                      uint64_t draw_base) {
     return guarded([&] {
-        g->impl->sweep(row_begin, row_end, batch_rows, seed_state, draw_base);
+        g->impl.open()->sweep(row_begin, row_end, batch_rows, seed_state,
+                              draw_base);
     });
 }
 // ---- RCCL, bound at run time ----------------------------------------------
@@ -3436,7 +3508,9 @@ int dist_gibbs_score_rows_dev(dist_gibbs_t * g, size_t row_begin,
 size_t dist_gibbs_group_count(const dist_gibbs_t * g) {
     return (size_t)g->impl->K();
 }
-size_t dist_gibbs_row_count(const dist_gibbs_t * g) { return g->impl->n_rows; }
+size_t dist_gibbs_row_count(const dist_gibbs_t * g) {
+    return g->impl.open()->n_rows;
+}
 int dist_gibbs_counts(const dist_gibbs_t * g, int * out) {
     return guarded([&] {
         std::vector<int> dev((size_t)g->impl->K());
@@ -3499,6 +3573,11 @@ int dist_gibbs_set_option(dist_gibbs_t * g, const char * name, int value) {
             g->impl->narrow_mode = value;
             // (cached ranges carry their tile lists)
             g->impl->drop_overlapping_caches(0, g->impl->n_rows, false);
+        } else if (key == "kernel_timing") {
+            // HIP events around the score+sample kernel of every n-th batch
+            // feed dist_gibbs_kernel_stats: 1 (default) all, 0 none
+            DIST_REQUIRE(value >= 0, "kernel_timing: >= 0");
+            g->impl->kernel_timing = value;
         } else if (key == "narrow_read_ahead") {
             // k_vs_narrow's instance: 0 by launch size, 4 or 8 float4s
             DIST_REQUIRE(value == 0 || value == 4 || value == 8,
@@ -3507,8 +3586,7 @@ int dist_gibbs_set_option(dist_gibbs_t * g, const char * name, int value) {
         } else if (key == "device_normalise") {
             // sweeps whose batches all take the value-sorted path normalise
             // the group set on the device (no host round trip per batch):
-            // 0 never, 1 where it applies, 2 (default) where it applies and
-            // the sub-sweeps are small enough for the host's wait to show
+            // 0 never, 1 where it applies (default; 2 is accepted as 1)
             DIST_REQUIRE(value >= 0 && value <= 2, "device_normalise: 0, 1 or 2");
             g->impl->device_normalise_mode = value;
         } else if (key == "sharded_device_normalise") {

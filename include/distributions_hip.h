@@ -405,12 +405,16 @@ int dist_gibbs_sharded_device_normalise_ok(const dist_gibbs_t * g,
  * the chip take tiles of 64 rows and their vectors from LDS), 2 (whenever
  * the vectors fit); "narrow_read_ahead" = 0 (by launch size), 4 or 8 (that
  * kernel's instance);
- * "device_normalise" = sweeps that stay on the value-sorted path with integer
- * statistics normalise the group set on the device and run without a host
- * round trip per batch: 0 never, 1 always, 2 (default) for sub-sweeps of at
- * most 524 288 rows; "sharded_device_normalise" = the same for
- * dist_gibbs_sweep_sharded (needs "device_normalise" = 1), to be set on every
- * rank or on none.
+ * "kernel_timing" = n: HIP events around the score+sample kernel of every
+ * n-th batch feed dist_gibbs_kernel_stats (1, the default: every batch; 0:
+ * none; two events cost a batch some 8 us);
+ * "device_normalise" = 1 (default): sweeps that stay on the value-sorted
+ * path with integer statistics normalise the group set on the device and run
+ * without a host round trip per batch; such a run stays open when
+ * dist_gibbs_sweep returns (the next sweep goes on with it, any other call
+ * pulls the host's mirrors first), so dist_gibbs_sweep returns before the
+ * device has finished; 0: never; "sharded_device_normalise" = the same for
+ * dist_gibbs_sweep_sharded, to be set on every rank or on none.
  * None changes a result. */
 int dist_gibbs_set_option(dist_gibbs_t * g, const char * name, int value);
 /* how many batches each score+sample kernel has served */

@@ -118,6 +118,47 @@ def test_value_sorted_larger_batches(config, dim, k, mode):
     assert gpu.path_counts()[0] == 9
 
 
+@pytest.mark.parametrize("empty", [1, 2])
+def test_device_normalised_runs_stay_open_across_sweeps(empty):
+    """A device-normalised sweep leaves its run open: the next sweep goes on
+    with it and the host's mirrors are pulled by the first call that needs
+    them.  Twenty sweeps without a look at the state (the room reserved for
+    eight is used up twice), then a different tiling, a sequential stretch
+    and more sweeps: the oracle agrees at every look."""
+    from distributions_amd import engine
+    n, k = 6000, 300
+    osh, gsh, vals, assign = workloads.make("dd", n, k, dim=16)
+    orc = ol.OracleMixture(20.0, 0.5, osh)
+    orc.init_from_assignments(vals, assign, k, empty)
+    gpu = engine.Gibbs(20.0, 0.5, gsh)
+    gpu.set_option("value_sorted", 2)
+    gpu.set_option("device_normalise", 1)
+    gpu.load_rows(vals, assign, k, empty)
+    seed = 31337
+    st = ol.oracle().orc_rng_seed(seed)
+    draws = 0
+
+    def sweeps(count, batch):
+        nonlocal draws
+        for _ in range(count):
+            for b in range(0, n, batch):
+                orc.gibbs_batch(b, min(n, b + batch), st, draws)
+            gpu.sweep(0, n, batch, seed, draw_base=draws)
+            draws += n
+    sweeps(20, 1500)
+    assert_same_state(orc, gpu, "after 20 unobserved sweeps")
+    sweeps(3, 1500)
+    sweeps(2, 1000)          # another tiling: the open run goes on or is closed
+    assert_same_state(orc, gpu, "after a change of tiling")
+    sweeps(1, 1500)
+    rng = ol.oracle().orc_rng_seed(7)
+    assert orc.gibbs_sequential(100, 160, rng) == gpu.sweep_sequential(
+        100, 160, rng)                   # (closes the open run first)
+    sweeps(2, 1500)
+    assert_same_state(orc, gpu, "after a sequential stretch")
+    assert gpu.core.debug_counts()["device_normalised"] >= 4 * 28
+
+
 @pytest.mark.parametrize("config,dim,k", [("dd", 256, 64), ("dd_skew", 64, 16),
                                           ("dpd_other", 300, 24), ("bb", None, 8),
                                           ("gp", None, 12), ("dd", 16, 700)])

@@ -134,9 +134,12 @@ def trial(seed, large=False):
                 orc.gibbs_batch(b0, min(n, b0 + batch), st, draw)
             gpu.sweep(0, n, batch, eng_seed, draw_base=draw)
             draw += n
-        err = same_state(orc, gpu)
-        if err:
-            return what + " step %d: %s" % (step, err)
+        # (not after every step: a device-normalised run stays open from one
+        # sweep to the next until somebody looks)
+        if step == 3 or rng.random() < 0.5:
+            err = same_state(orc, gpu)
+            if err:
+                return what + " step %d: %s" % (step, err)
     return None
 
 
