@@ -2031,13 +2031,28 @@ struct Gibbs {
             moves_in_row_order = true;
             P.old_packed = old_row.p;
             P.new_packed = new_row.p;
-            LAUNCH(k_apply_moves, n, P, img, d_p2g_ptr, assign);
+            apply_moves(n, P, img, d_p2g_ptr, assign);
             // assign[] is now current: refresh the position copy
             LAUNCH(k_pos_gather, n, assign + batch_begin, c.sorted_rows.p,
                    c.assign_pos.p, n);
         } else {
-            LAUNCH(k_apply_moves, n, P, img, d_p2g_ptr, assign);
+            apply_moves(n, P, img, d_p2g_ptr, assign);
         }
+    }
+    // the general rows' integer statistics: per-group totals through LDS
+    // where (1 + 2 F) K integers fit a workgroup's, else direct atomics
+    void apply_moves(size_t n, const SweepParams & P, const StatImage & img,
+                     const uint32_t * p2g, uint32_t * assign_out) {
+        const size_t lds = (size_t)(1 + 2 * F()) * K() * sizeof(int);
+        if (lds > 64 * 1024 || n < (size_t)4 * K()) {   // (too few to pay)
+            LAUNCH(k_apply_moves, n, P, img, p2g, assign_out);
+            return;
+        }
+        hipLaunchKernelGGL(
+            k_apply_moves_lds,
+            dim3((unsigned)((n + kApplyLdsRows - 1) / kApplyLdsRows)),
+            dim3(kApplyLdsBlock), lds, stream(), P, img, p2g, assign_out);
+        HIP_CHECK(hipGetLastError());
     }
     void batch_apply_local() {
         DIST_REQUIRE(batch_open, "no open batch");
