@@ -878,11 +878,17 @@ struct RowScorer {
         return e;
     }
 
-    // score of slot k from the caches (k wave-uniform)
+    // score of slot k from the caches (k wave-uniform).  PLAIN: no lane of
+    // the wave holds a row that is alone in its group (the usual case): the
+    // driver's score is one scalar operand instead of a per-lane select
+    template <bool PLAIN = false>
     __device__ __forceinline__ float cached(int k) const {
         const float b = as_uniform(P.base)[k];
-        const float bs = as_uniform(P.base_single)[k];
-        float s = singleton ? bs : b;
+        float s = b;
+        if (!PLAIN) {
+            const float bs = as_uniform(P.base_single)[k];
+            s = singleton ? bs : b;
+        }
 #pragma unroll kUnroll
         for (int f = 0; f < nf(); ++f) {
             const int kind = kind_of(f);
@@ -954,8 +960,9 @@ struct RowScorer {
 
     // score of local slot k (k < K, wave-uniform; slots >= Kl are not part of
     // the row's view and are masked by the caller)
+    template <bool PLAIN = false>
     __device__ __forceinline__ float at(int k) const {
-        const float s = cached(k);
+        const float s = cached<PLAIN>(k);
         return k == g ? s_own : s;
     }
 
@@ -1018,39 +1025,86 @@ __global__ __launch_bounds__(kBlock) void k_sweep_sample(SweepParams P) {
             global_id = P.assign[row];
         }
         const RowScorer<KIND0, KIND1, NF> rs(P, row, global_id);
-        const int Kl = rs.Kl;
-
-        // vector_max (vector_math.cc:74-83)
-        float m = rs.at(0);
-#pragma unroll kSweepUnroll
-        for (int k = 1; k < K; ++k) {
-            const float s = rs.at(k);
-            m = (k < Kl && s > m) ? s : m;
-        }
-        // scores_to_likelihoods: total in index order
-        float total = 0.f;
-#pragma unroll kSweepUnroll
-        for (int k = 0; k < K; ++k) {
-            const float l = fast_exp_nonpos(rs.at(k) - m, s_exp, ea, eb);
-            total += (k < Kl) ? l : 0.f;
-        }
-        // sample_from_likelihoods: subtracting non-negative terms never
-        // increases t, so the first index with t <= 0 is the number of steps
-        // after which t is still positive
-        float t = total * batch_row_unif01(P, row);
+        int Kl = rs.Kl;
         int steps = 0;
-        for (int k0 = 0; k0 < K; k0 += kSweepUnroll) {
-#pragma unroll
-            for (int j = 0; j < kSweepUnroll; ++j) {
-                const int k = k0 + j;
-                if (k < K) {
-                    const float l =
-                        fast_exp_nonpos(rs.at(k) - m, s_exp, ea, eb);
-                    t -= (k < Kl) ? l : 0.f;
-                    steps += (k < Kl && t > 0.f) ? 1 : 0;
-                }
+        // the three passes; PLAIN: no row of this wave is alone in its group,
+        // so every lane sees all K slots and the same driver scores (no
+        // per-lane select of the base score, no k < Kl masks)
+        auto passes = [&](auto plain_tag) {
+            constexpr bool PLAIN = decltype(plain_tag)::value;
+            const int Kv = PLAIN ? K : Kl;
+            // vector_max (vector_math.cc:74-83)
+            float m = rs.template at<PLAIN>(0);
+#pragma unroll kSweepUnroll
+            for (int k = 1; k < K; ++k) {
+                const float s = rs.template at<PLAIN>(k);
+                m = (k < Kv && s > m) ? s : m;
             }
-            if (!__any(live && t > 0.f)) break;
+            // scores_to_likelihoods: total in index order
+            float total = 0.f;
+#pragma unroll kSweepUnroll
+            for (int k = 0; k < K; ++k) {
+                const float l = fast_exp_nonpos(rs.template at<PLAIN>(k) - m,
+                                                s_exp, ea, eb);
+                total += (k < Kv) ? l : 0.f;
+            }
+            // sample_from_likelihoods: subtracting non-negative terms never
+            // increases t, so the first index with t <= 0 is the number of
+            // steps after which t is still positive
+            float t = total * batch_row_unif01(P, row);
+            for (int k0 = 0; k0 < K; k0 += kSweepUnroll) {
+#pragma unroll
+                for (int j = 0; j < kSweepUnroll; ++j) {
+                    const int k = k0 + j;
+                    if (k < K) {
+                        const float l = fast_exp_nonpos(
+                            rs.template at<PLAIN>(k) - m, s_exp, ea, eb);
+                        t -= (k < Kv) ? l : 0.f;
+                        steps += (k < Kv && t > 0.f) ? 1 : 0;
+                    }
+                }
+                if (!__any(live && t > 0.f)) break;
+            }
+        };
+        // (the second copy of the loops only where they stay small: with the
+        // count-valued kinds' out-of-line lgamma paths it costs the loops
+        // their registers -- GP+NICH: 88 -> 175 and spills -- and so does
+        // the lambda itself: those kinds keep the plain three loops)
+        constexpr bool kTwoCopies =
+            KIND0 >= 0 && KIND0 != DIST_GP && KIND0 != DIST_BNB
+            && KIND1 != DIST_GP && KIND1 != DIST_BNB;
+        if constexpr (kTwoCopies) {
+            if (__any(rs.singleton != 0))
+                passes(std::integral_constant<bool, false>{});
+            else
+                passes(std::integral_constant<bool, true>{});
+        } else {
+            float m = rs.at(0);
+#pragma unroll kSweepUnroll
+            for (int k = 1; k < K; ++k) {
+                const float s = rs.at(k);
+                m = (k < Kl && s > m) ? s : m;
+            }
+            float total = 0.f;
+#pragma unroll kSweepUnroll
+            for (int k = 0; k < K; ++k) {
+                const float l = fast_exp_nonpos(rs.at(k) - m, s_exp, ea, eb);
+                total += (k < Kl) ? l : 0.f;
+            }
+            float t = total * batch_row_unif01(P, row);
+            for (int k0 = 0; k0 < K; k0 += kSweepUnroll) {
+#pragma unroll
+                for (int j = 0; j < kSweepUnroll; ++j) {
+                    const int k = k0 + j;
+                    if (k < K) {
+                        const float l =
+                            fast_exp_nonpos(rs.at(k) - m, s_exp, ea, eb);
+                        t -= (k < Kl) ? l : 0.f;
+                        steps += (k < Kl && t > 0.f) ? 1 : 0;
+                    }
+                }
+                if (!__any(live && t > 0.f)) break;
+            }
         }
         int g2 = steps < Kl - 1 ? steps : Kl - 1;
         if (rs.singleton && g2 == rs.g) g2 = K - 1;   // slot g held group K-1
