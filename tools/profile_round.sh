@@ -14,6 +14,24 @@ B="bench.py --cpu-rows 0 --other-batches="
 SQ="SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $B > $out/bench_under_rocprof.json 2> $out/trace.log
 cp $(ls $out/trace/*/*kernel_stats.csv | head -1) $out/kernel_stats.csv
+# the same trace restricted to the timed region (the last 20 sweeps' launches:
+# kernel_stats.csv averages the two warm-up sweeps in, whose first runs on
+# tiles not yet sorted by group)
+python3 - $out <<'PY' > $out/kernel_stats_timed_region.txt
+import csv, glob, sys
+f = glob.glob(sys.argv[1] + "/trace/**/*kernel_trace.csv", recursive=True)[0]
+rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
+by = {}
+for r in rows:
+    by.setdefault(r["Kernel_Name"].split("(")[0], []).append(
+        int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+print("kernel, launches in the timed region (last 200 of each per-sub-sweep kernel), average us")
+for name, d in sorted(by.items(), key=lambda kv: -sum(kv[1][-200:])):
+    if len(d) < 200:
+        continue
+    last = d[-200:]
+    print("%-60s %4d %8.2f" % (name[:60], len(last), sum(last) / len(last) / 1e3))
+PY
 rocprofv3 --pmc $SQ --kernel-trace --output-format csv -d $out/sq -- python3 $B --steps 3 --warmup 2 > /dev/null 2> $out/sq.log
 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $out/grbm -- python3 $B --steps 3 --warmup 2 > /dev/null 2> $out/grbm.log
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/fetch -- python3 $B --steps 3 --warmup 2 > /dev/null 2> $out/fetch.log
