@@ -81,7 +81,14 @@ class Gibbs(object):
 
     # -- sweeps -------------------------------------------------------------
     def sweep(self, row_begin, row_end, batch_rows, seed, draw_base=0):
-        """One pass over rows [row_begin,row_end) in frozen batches."""
+        """One pass over rows [row_begin,row_end) in frozen batches.
+
+        Where the group set is normalised on the device (one feature with
+        integer statistics: the default) the pass is QUEUED when this returns;
+        the next sweep goes on without the host, and any other call on the
+        engine (counts(), assignments(), ...) first waits for the device and
+        pulls the host's copy of the group set.  `_core.synchronize()` waits
+        explicitly."""
         self.core.sweep(row_begin, row_end, batch_rows, _core.rng_seed(seed),
                         draw_base)
 
