@@ -159,6 +159,43 @@ def test_device_normalised_runs_stay_open_across_sweeps(empty):
     assert gpu.core.debug_counts()["device_normalised"] >= 4 * 28
 
 
+def test_open_run_is_closed_by_whatever_comes_next():
+    """options set, rows reloaded, the engine dropped while a device-normalised
+    run is open: each finds the state the oracle has"""
+    from distributions_amd import engine
+    n, k = 5000, 120
+    osh, gsh, vals, assign = workloads.make("dd", n, k, dim=16)
+    seed = 555
+    st = ol.oracle().orc_rng_seed(seed)
+
+    def fresh():
+        orc = ol.OracleMixture(5.0, 0.3, osh)
+        orc.init_from_assignments(vals, assign, k, 1)
+        gpu = engine.Gibbs(5.0, 0.3, gsh)
+        gpu.set_option("value_sorted", 2)
+        gpu.load_rows(vals, assign, k, 1)
+        return orc, gpu
+    orc, gpu = fresh()
+    for sweep in range(3):
+        for b in range(0, n, 1250):
+            orc.gibbs_batch(b, b + 1250, st, sweep * n)
+        gpu.sweep(0, n, 1250, seed, draw_base=sweep * n)
+    gpu.set_option("narrow_tiles", 0)          # (drops the cached ranges)
+    for b in range(0, n, 1250):
+        orc.gibbs_batch(b, b + 1250, st, 3 * n)
+    gpu.sweep(0, n, 1250, seed, draw_base=3 * n)
+    assert gpu.core.debug_counts()["device_normalised"] == 16
+    assert_same_state(orc, gpu, "after an option change between sweeps")
+    gpu.sweep(0, n, 1250, seed, draw_base=4 * n)
+    gpu.load_rows(vals, assign, k, 1)          # reload under an open run
+    orc2, _ = fresh()
+    assert_same_state(orc2, gpu, "after a reload")
+    gpu.sweep(0, n, 1250, seed, draw_base=0)
+    del gpu                                    # destroyed with the run open
+    _core_sync = __import__("distributions_amd._core", fromlist=["x"])
+    _core_sync.synchronize()
+
+
 @pytest.mark.parametrize("config,dim,k", [("dd", 256, 64), ("dd_skew", 64, 16),
                                           ("dpd_other", 300, 24), ("bb", None, 8),
                                           ("gp", None, 12), ("dd", 16, 700)])
