@@ -472,6 +472,10 @@ def run_rank(args):
         t0 = time.perf_counter()
         for i in range(steps):
             step(warmup + i)
+        # the host's copy of the group set is part of the job: a sweep may
+        # leave it to be pulled on demand (device-normalised runs stay open),
+        # so it is demanded here, inside the timed region
+        len(g)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -639,6 +643,11 @@ def run_rank(args):
                                 "library RCCL communicator" if native_comm
                                 else "torch.distributed (RCCL)"),
                 "comm_ranks": world if sharded_collective(world, args) else 0,
+                "group_set": ("normalised on the device, the host's copy "
+                              "pulled once at the end of the timed region"
+                              if g.core.debug_counts()["device_normalised"]
+                              else "normalised by the host after every "
+                                   "sub-sweep"),
             },
             "roofline": roof,
             "batch_variants": variants,
