@@ -159,6 +159,32 @@ def test_device_normalised_runs_stay_open_across_sweeps(empty):
     assert gpu.core.debug_counts()["device_normalised"] >= 4 * 28
 
 
+@pytest.mark.parametrize("normalise", [0, 1])
+def test_kernel_timing_samples_every_nth_batch(normalise):
+    """kernel_stats counts the batches whose score+sample kernel sat between
+    two events: every batch by default, every n-th with kernel_timing = n,
+    none with 0 -- and the results do not depend on it"""
+    from distributions_amd import engine
+    n, k = 8000, 50
+    osh, gsh, vals, assign = workloads.make("dd", n, k, dim=16)
+    finals = []
+    for every, want in ((1, 16), (4, 4), (0, 0)):
+        gpu = engine.Gibbs(1.0, 0.2, gsh)
+        gpu.set_option("value_sorted", 2)
+        gpu.set_option("device_normalise", normalise)
+        gpu.set_option("kernel_timing", every)
+        gpu.load_rows(vals, assign, k, 1)
+        gpu.kernel_stats(reset=True)
+        for sweep in range(2):
+            gpu.sweep(0, n, 1000, 99, draw_base=sweep * n)
+        ms, launches, rows = gpu.kernel_stats()
+        assert launches == want and rows == want * 1000
+        assert (ms > 0) == (want > 0)
+        finals.append(gpu.assignments().copy())
+    assert np.array_equal(finals[0], finals[1])
+    assert np.array_equal(finals[0], finals[2])
+
+
 def test_open_run_is_closed_by_whatever_comes_next():
     """options set, rows reloaded, the engine dropped while a device-normalised
     run is open: each finds the state the oracle has"""
