@@ -1974,8 +1974,7 @@ struct Gibbs {
                         (int)(LDS)));                                        \
                     have.store((LDS), std::memory_order_relaxed);            \
                 }                                                            \
-                hipLaunchKernelGGL((k_vs_apply<KIND, SORT>),                 \
-                                   dim3(grid.x, (SORT) ? 2 : 1), block,      \
+                hipLaunchKernelGGL((k_vs_apply<KIND, SORT>), grid, block,    \
                                    LDS, stream(), P, img, c.chunks.p,        \
                                    c.sorted_rows.p, d_p2g_ptr,               \
                                    c.assign_pos.p, (uint32_t)vs_nvals(),     \

@@ -2779,11 +2779,6 @@ constexpr int kVsApplyBlock = 1024;   // one workgroup per chunk: keep the CU bu
 // so almost every chunk of the likelihood vector is free of own slots (see
 // vs_sum_and_scan).  The order is a performance hint only: results do not
 // depend on it.
-// SORT launches run the two halves of the work as two workgroups per chunk
-// (blockIdx.y: 0 the statistics, 1 the re-sort).  They share nothing but the
-// moves they read, each is a chain of latency-bound phases, and a CU holds
-// both (54 registers, 72 KB of LDS each).  Sub-sweeps of 65 536 rows: 79 -> 75
-// us; of 10^6 rows (a chunk per CU already): 14.2 -> 13.5 us, no more.
 template <int KIND, bool SORT>
 __global__ __launch_bounds__(kVsApplyBlock) void k_vs_apply(
         SweepParams P, StatImage img, const VsTile * __restrict__ chunks,
@@ -2804,84 +2799,70 @@ __global__ __launch_bounds__(kVsApplyBlock) void k_vs_apply(
     const uint32_t pos = chunks[blockIdx.x].pos;
     const uint32_t n = chunks[blockIdx.x].n;
     if (x == 0xFFFFFFFEu) return;   // several values: k_vs_apply_mixed's
-    // the chunk of counts beyond the value table reads its rows' values
-    // through sorted_rows: it is left in the order it has
-    const bool beyond = (KIND == DIST_GP || KIND == DIST_BNB) && x >= nvals;
-    const bool stats_half = !SORT || blockIdx.y == 0;
-    const bool sort_half = SORT && blockIdx.y == 1 && !beyond;
-    const bool ids_here = SORT ? (blockIdx.y == 1 && beyond) : true;
-    if (stats_half) {
-        for (int k = threadIdx.x; k < K; k += kVsApplyBlock) delta[k] = 0;
-        __syncthreads();
-        for (uint32_t i = threadIdx.x; i < n; i += kVsApplyBlock) {
-            const uint32_t go = P.old_packed[pos + i],
-                           gn = P.new_packed[pos + i];
-            if (go != gn) {
-                atomicAdd(&delta[go], -1);
-                atomicAdd(&delta[gn], 1);
-                if (beyond) {
-                    // every row brings its own value to the sums
-                    const int32_t v = (int32_t)P.values[0][
-                        P.row_begin + sorted_rows[pos + i]];
-                    atomicAdd(&img.i1[0][go], -v);
-                    atomicAdd(&img.i1[0][gn], v);
-                }
-            }
-            if (!SORT) assign_pos[pos + i] = p2g[gn];
-        }
-        __syncthreads();
-        const int dim = P.feat[0].dim;
-        for (int k = threadIdx.x; k < K; k += kVsApplyBlock) {
-            const int dlt = delta[k];
-            if (stage) stage[(size_t)blockIdx.x * K + k] = dlt;
-            if (dlt == 0) continue;
-            if (!stage) {
-                atomicAdd(&img.counts[k], dlt);
-                if (KIND == DIST_BB) {
-                    atomicAdd(x ? &img.i0[0][k] : &img.i1[0][k], dlt);
-                } else {
-                    atomicAdd(&img.i0[0][k], dlt);     // count_sum / count
-                    if ((KIND == DIST_GP || KIND == DIST_BNB) && x < nvals)
-                        atomicAdd(&img.i1[0][k], dlt * (int32_t)x);   // sum
-                }
-            }
-            if (KIND == DIST_DD || KIND == DIST_DPD) {
-                int32_t * cell = &img.cnt[0][(size_t)k * dim + x];
-                int before;
-                if (sole_owner) {   // one chunk per value: nobody else is here
-                    before = *cell;
-                    *cell = before + dlt;
-                } else {
-                    before = atomicAdd(cell, dlt);
-                }
-                if (refresh_cells) {
-                    // this workgroup is the only one that touches cell (k, x)
-                    // (one chunk per value, live statistics): leave its cache
-                    // entry current (dd.hpp:458-467) and spare the batch's
-                    // tail a rebuild of all K * dim cells
-                    const SlaveView & s = P.feat[0];
-                    s.S[(size_t)x * s.cap + k] =
-                        fast_log(s.prior[x] + (float)(before + dlt));
-                }
-            }
-        }
-        return;
+    for (int k = threadIdx.x; k < K; k += kVsApplyBlock) {
+        delta[k] = 0;
+        if (SORT) hist[k] = 0;
     }
-    if (ids_here && SORT) {   // (unsorted chunk of a SORT launch)
-        for (uint32_t i = threadIdx.x; i < n; i += kVsApplyBlock)
-            assign_pos[pos + i] = p2g[P.new_packed[pos + i]];
-        return;
-    }
-    if (!sort_half) return;
-    for (int k = threadIdx.x; k < K; k += kVsApplyBlock) hist[k] = 0;
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < n; i += kVsApplyBlock) {
-        const uint32_t gn = P.new_packed[pos + i];
-        rows_l[i] = sorted_rows[pos + i];
-        gn_l[i] = gn;
-        atomicAdd(&hist[gn], 1);
+        const uint32_t go = P.old_packed[pos + i], gn = P.new_packed[pos + i];
+        if (go != gn) {
+            atomicAdd(&delta[go], -1);
+            atomicAdd(&delta[gn], 1);
+            if ((KIND == DIST_GP || KIND == DIST_BNB) && x >= nvals) {
+                // the chunk of counts beyond the value table: every row
+                // brings its own value to the sums
+                const int32_t v = (int32_t)P.values[0][P.row_begin
+                                                      + sorted_rows[pos + i]];
+                atomicAdd(&img.i1[0][go], -v);
+                atomicAdd(&img.i1[0][gn], v);
+            }
+        }
+        if (SORT) {
+            rows_l[i] = sorted_rows[pos + i];
+            gn_l[i] = gn;
+            atomicAdd(&hist[gn], 1);
+        } else {
+            assign_pos[pos + i] = p2g[gn];
+        }
     }
     __syncthreads();
+    const int dim = P.feat[0].dim;
+    for (int k = threadIdx.x; k < K; k += kVsApplyBlock) {
+        const int dlt = delta[k];
+        if (stage) stage[(size_t)blockIdx.x * K + k] = dlt;
+        if (dlt == 0) continue;
+        if (!stage) {
+            atomicAdd(&img.counts[k], dlt);
+            if (KIND == DIST_BB) {
+                atomicAdd(x ? &img.i0[0][k] : &img.i1[0][k], dlt);
+            } else {
+                atomicAdd(&img.i0[0][k], dlt);     // count_sum / count
+                if ((KIND == DIST_GP || KIND == DIST_BNB) && x < nvals)
+                    atomicAdd(&img.i1[0][k], dlt * (int32_t)x);   // sum
+            }
+        }
+        if (KIND == DIST_DD || KIND == DIST_DPD) {
+            int32_t * cell = &img.cnt[0][(size_t)k * dim + x];
+            int before;
+            if (sole_owner) {   // one chunk per value: nobody else is here
+                before = *cell;
+                *cell = before + dlt;
+            } else {
+                before = atomicAdd(cell, dlt);
+            }
+            if (refresh_cells) {
+                // this workgroup is the only one that touches cell (k, x)
+                // (one chunk per value, live statistics): leave its cache
+                // entry current (dd.hpp:458-467) and spare the batch's tail
+                // a rebuild of all K * dim cells
+                const SlaveView & s = P.feat[0];
+                s.S[(size_t)x * s.cap + k] =
+                    fast_log(s.prior[x] + (float)(before + dlt));
+            }
+        }
+    }
+    if (!SORT) return;
     // exclusive scan of hist over k: each thread owns a contiguous slice,
     // the slices are scanned within the wave by shuffles and the 16 wave
     // totals by every thread for itself (two barriers in all)
