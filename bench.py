@@ -85,6 +85,9 @@ def parse():
                     help="launches too small to fill the chip take tiles of "
                          "64 rows with their vectors in LDS (k_vs_narrow): "
                          "0 never, 1 auto, 2 whenever the vectors fit")
+    ap.add_argument("--stream-scratch", type=int, default=1,
+                    help="k_vs_stream keeps the first pass's likelihoods for "
+                         "the scan in a scratch row per tile: 1 or 0")
     ap.add_argument("--kernel-timing", type=int, default=8,
                     help="HIP events around every n-th score+sample launch "
                          "of the timed region (the roofline's duration is "
@@ -447,6 +450,7 @@ def run_rank(args):
         g.set_option("device_normalise", args.device_normalise)
         g.set_option("narrow_tiles", args.narrow_tiles)
         g.set_option("kernel_timing", args.kernel_timing)
+        g.set_option("stream_scratch", args.stream_scratch)
         initial = assign.clone()   # the engine updates `assign` in place
         g.load_rows_torch(columns, assign, k, 1, row_offset=row_offset)
         sharded = engine.ShardedGibbs(

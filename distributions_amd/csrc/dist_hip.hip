@@ -869,6 +869,8 @@ struct Gibbs {
     DeviceBuf<int> vsBandMode;     // VsTables::band_mode
     DeviceBuf<VsTile> vsBandTile;  // VsTables::band_tile
     DeviceBuf<unsigned long long> vsStamps;   // diagnostics, see VsTables
+    DeviceBuf<float> vsScratch;    // k_vs_stream: [tiles][K] likelihoods
+    int stream_scratch_mode = 1;   // 0: recompute them in the scan instead
     DeviceBuf<ChainResult> chain_result;
     DeviceBuf<int32_t> delta_image;         // dist_gibbs_sweep_sharded
     DeviceBuf<float> own_score;             // k_row_prepass
@@ -1597,12 +1599,24 @@ struct Gibbs {
             hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, stream(),
                                self->deferred_count.p, c->n_other);
             self->mark(self->ev0);
+            // a row of K likelihoods per tile between the total's pass and
+            // the scan (up to 2 GiB of scratch; beyond that they are computed
+            // again, as before)
+            const size_t stride = ((size_t)self->K() + 63) & ~(size_t)63;
+            float * scratch = nullptr;
+            if (self->stream_scratch_mode
+                && (size_t)c->n_tiles * stride <= ((size_t)1 << 29)) {
+                self->vsScratch.reserve(
+                    grow_capacity((size_t)c->n_tiles * stride), 0);
+                scratch = self->vsScratch.p;
+            }
             if (c->n_tiles)
                 hipLaunchKernelGGL((k_vs_stream<KIND>),
                                    dim3((c->n_tiles + per - 1) / per),
                                    dim3(kVsStreamBlock), 0, stream(), *P,
                                    c->tiles.p, c->n_tiles, c->sorted_rows.p,
-                                   self->deferred.p, self->deferred_count.p);
+                                   self->deferred.p, self->deferred_count.p,
+                                   scratch, (uint32_t)stride);
             HIP_CHECK(hipGetLastError());
             self->mark(self->ev1);
         }
@@ -3588,6 +3602,11 @@ int dist_gibbs_set_option(dist_gibbs_t * g, const char * name, int value) {
             g->impl->narrow_mode = value;
             // (cached ranges carry their tile lists)
             g->impl->drop_overlapping_caches(0, g->impl->n_rows, false);
+        } else if (key == "stream_scratch") {
+            // k_vs_stream keeps the first pass's likelihoods for the second
+            // in a scratch row per tile (1, default) or computes them again
+            DIST_REQUIRE(value == 0 || value == 1, "stream_scratch: 0 or 1");
+            g->impl->stream_scratch_mode = value;
         } else if (key == "kernel_timing") {
             // HIP events around the score+sample kernel of every n-th batch
             // feed dist_gibbs_kernel_stats: 1 (default) all, 0 none

@@ -2536,7 +2536,8 @@ __attribute__((amdgpu_waves_per_eu(8, 8)))
 void k_vs_stream(
         SweepParams P, const VsTile * __restrict__ tiles, uint32_t n_tiles,
         const uint32_t * __restrict__ sorted_rows,
-        uint32_t * __restrict__ deferred, uint32_t * deferred_count) {
+        uint32_t * __restrict__ deferred, uint32_t * deferred_count,
+        float * __restrict__ scratch, uint32_t scratch_stride) {
     __shared__ uint32_t s_exp[1024];
     __shared__ float s_strip[kVsStreamBlock / 64][kVsStreamChunk];
     for (int i = threadIdx.x; i < 1024; i += kVsStreamBlock)
@@ -2559,6 +2560,10 @@ void k_vs_stream(
     const int K = sweep_K(P);
     const float shift = P.scalars->shift;
     const float lf = KIND == DIST_GP ? fast_log_factorial(x) : 0.f;
+    // the tile's row of the scratch (null: none): the total's pass leaves
+    // its likelihoods there, the scan and the replay read them back instead
+    // of evaluating score and exponential a second and a third time
+    float * keep = scratch ? scratch + (size_t)id * scratch_stride : nullptr;
 
     // pass 0: (max, first arg-max, max of the rest) of the value's scores
     float m1 = -INFINITY, m2 = -INFINITY;
@@ -2662,10 +2667,14 @@ void k_vs_stream(
                 for (int j = 0; j < kVsStreamChunk / 64; ++j) {
                     const int k = k0 + lane + 64 * j;
                     float l = 0.f;
-                    if (k < K)
+                    if (pass == 1 && keep) {
+                        if (k < K) l = keep[k];
+                    } else if (k < K) {
                         l = fast_exp_nonpos(
                             vs_stream_score<KIND>(P, v, k, x, lf) - m, s_exp,
                             ea, eb);
+                        if (keep) keep[k] = l;
+                    }
                     strip[lane + 64 * j] = l;
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -2737,9 +2746,10 @@ void k_vs_stream(
                     if (k == g[r])
                         l = l_own[r];
                     else if (k < K)
-                        l = fast_exp_nonpos(
-                            vs_stream_score<KIND>(P, v, k, x, lf) - m, s_exp,
-                            ea, eb);
+                        l = keep ? keep[k]
+                                 : fast_exp_nonpos(
+                                       vs_stream_score<KIND>(P, v, k, x, lf)
+                                           - m, s_exp, ea, eb);
                     tt -= l;
                     steps += (tt > 0.f) ? 1 : 0;
                 }

@@ -375,6 +375,7 @@ def test_randomised_configurations():
         gpu.set_option("value_stream", int(rng.choice([0, 1, 2])))
         gpu.set_option("narrow_tiles", int(rng.choice([0, 1, 2])))
         gpu.set_option("narrow_read_ahead", int(rng.choice([0, 4, 8])))
+        gpu.set_option("stream_scratch", int(rng.choice([0, 1])))
         gpu.set_option("device_normalise", int(rng.choice([0, 1, 2])))
         gpu.load_rows(vals, assign, k, empty)
         seed = int(rng.integers(1, 2 ** 31))

@@ -106,6 +106,7 @@ def trial(seed, large=False):
     gpu.set_option("value_stream", int(rng.choice([0, 1, 2])))
     gpu.set_option("narrow_tiles", int(rng.choice([0, 1, 2])))
     gpu.set_option("narrow_read_ahead", int(rng.choice([0, 4, 8])))
+    gpu.set_option("stream_scratch", int(rng.choice([0, 1])))
     gpu.set_option("device_normalise", int(rng.choice([0, 1, 2])))
     gpu.load_rows(vals, assign, k, empty)
     what = "seed %d: n=%d k=%d empty=%d feats=%s mode=%d %s" % (
@@ -170,6 +171,7 @@ def trial_collective(seed):
     gpu.set_option("value_stream", int(rng.choice([0, 1, 2])))
     gpu.set_option("narrow_tiles", int(rng.choice([0, 1, 2])))
     gpu.set_option("narrow_read_ahead", int(rng.choice([0, 4, 8])))
+    gpu.set_option("stream_scratch", int(rng.choice([0, 1])))
     gpu.load_rows_torch(cols, a.clone(), k, 2)
     sharded = engine.ShardedGibbs(gpu.core, n, 0, device=dev,
                                   force_collective=True, columns=cols,
