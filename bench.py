@@ -97,6 +97,10 @@ def parse():
                     help="comma-separated sub-sweep sizes timed besides "
                          "--batch (a few steps each, reported in "
                          "`batch_variants`; empty = none)")
+    ap.add_argument("--opt", action="append", default=[],
+                    metavar="NAME=VALUE",
+                    help="any other engine option (dist_gibbs_set_option), "
+                         "e.g. rows_scratch=0; repeatable")
     ap.add_argument("--torch-collectives", action="store_true",
                     help="keep the per-batch all-reduce on torch.distributed "
                          "instead of the library's own RCCL communicator")
@@ -451,6 +455,9 @@ def run_rank(args):
         g.set_option("narrow_tiles", args.narrow_tiles)
         g.set_option("kernel_timing", args.kernel_timing)
         g.set_option("stream_scratch", args.stream_scratch)
+        for item in args.opt:
+            key, _, val = item.partition("=")
+            g.set_option(key.strip(), int(val))
         initial = assign.clone()   # the engine updates `assign` in place
         g.load_rows_torch(columns, assign, k, 1, row_offset=row_offset)
         sharded = engine.ShardedGibbs(
@@ -504,6 +511,7 @@ def run_rank(args):
     vs_batches, generic_batches = g.path_counts()
     streamed = g.core.debug_counts()["stream_batches"]
     narrow = g.core.debug_counts()["narrow_batches"]
+    scratched = g.core.debug_counts()["scratch_batches"]
     draws = args.warmup + args.steps
 
     # the same job at other sub-sweep sizes (value depends on it: the
@@ -518,7 +526,8 @@ def run_rank(args):
         draws += 1 + steps_b
         ms_b, launches_b, rows_b = g.kernel_stats()
         after = g.core.debug_counts()
-        took = [name for key, name in (("narrow_batches", "k_vs_narrow"),
+        took = [name for key, name in (("scratch_batches", "k_rows_scratch"),
+                                       ("narrow_batches", "k_vs_narrow"),
                                        ("stream_batches", "k_vs_stream"),
                                        ("value_sorted_batches", "k_vs_sample"))
                 if after[key] > before[key]]
@@ -553,6 +562,8 @@ def run_rank(args):
         kernel = "k_vs_narrow<%s>" % args.config
     elif vs_batches:
         kernel = "k_vs_sample<%s>" % args.config
+    elif scratched:
+        kernel = "k_rows_scratch<%s>" % args.config
     elif args.config == "mixed":
         kernel = "k_sweep_program"
     else:

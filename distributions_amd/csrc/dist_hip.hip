@@ -874,6 +874,20 @@ struct Gibbs {
     DeviceBuf<ChainResult> chain_result;
     DeviceBuf<int32_t> delta_image;         // dist_gibbs_sweep_sharded
     DeviceBuf<float> own_score;             // k_row_prepass
+    // k_rows_scratch (general rows): 0 = round 2's k_sweep_program /
+    // k_sweep_sample, 1 = likelihoods kept in a scratch column between total
+    // and scan, 2 = scores kept between max and total as well, 3 = the same
+    // lean loops without a scratch (default: measured fastest)
+    int rows_scratch_mode = 3;
+    int rows_scratch_lds_log = 1;     // FastLog's table in LDS where NICH scores
+    int rows_scratch_block = 512;     // threads per workgroup
+    // 1: every batch the value-sorted kernels do not take goes through the
+    // score program when its tables exist (0: only feature lists without a
+    // compile-time instance of k_sweep_sample, as in round 2)
+    int program_all = 1;
+    DeviceBuf<float> rows_scratch;          // [resident waves][Kpad][64]
+    DeviceBuf<float> rows_gtab;             // [Kpad][W], see k_rows_gtab
+    uint64_t scratch_batches = 0;
     int sequential_mode = 1;   // 0: every row as a batch of one (diagnostic)
     DeviceBuf<int> vsArg;
     DeviceBuf<uint32_t> deferred, deferred_count;
@@ -1287,7 +1301,9 @@ struct Gibbs {
             P.ktab_nv[f] = 0;
             if (!nv) continue;
             const size_t n = (size_t)K() * nv;
-            ktab[f].reserve(grow_capacity(n), 0);
+            // (+ a block of padding groups: k_rows_scratch scores whole
+            // blocks of kRowsBlock groups and masks afterwards)
+            ktab[f].reserve(grow_capacity(n + (size_t)kRowsBlock * nv), 0);
             LAUNCH(k_build_ktab, n, feats[f]->view(), ktab[f].p, nv, K());
             P.ktab[f] = ktab[f].p;
             P.ktab_nv[f] = nv;
@@ -1302,6 +1318,144 @@ struct Gibbs {
         if (F() == 2 && k0 == DIST_GP && k1 == DIST_NICH) return false;
         return F() >= 2;
     }
+    // k_rows_scratch over the open batch: a grid of exactly the workgroups
+    // that are resident at once (each wave keeps a block of the scratch and
+    // walks the rows grid-stride).  false: program or scratch do not fit.
+    bool launch_rows_scratch(SweepParams & P, const ScoreProgram & prog,
+                             size_t n) {
+        RowsArgs A;
+        memset(&A, 0, sizeof(A));
+        GtabSource src;
+        memset(&src, 0, sizeof(src));
+        bool nich = false;
+        int next = 1;   // slot 0: the driver's score
+        int shape = 0, n_ops = 0;
+        const int K8 = (K() + kRowsBlock - 1) / kRowsBlock * kRowsBlock;
+        for (int o = 0; o < prog.n; ++o) {
+            const ScoreOp & op = prog.op[o];
+            if (n_ops == kRowsMaxOps) return false;
+            RowsOp & r = A.op[n_ops];
+            r.values = P.values[op.f];
+            if (op.type == OP_GATHER_ADD) {
+                r.type = ROP_GATHER;
+                r.tab = op.p0;
+                r.row_bytes = op.nv * 4u;
+                // (prepare() allocates the padding groups' rows)
+                const size_t bytes = (size_t)K8 * op.nv * 4;
+                if (bytes >= ((size_t)1 << 31)) return false;
+                r.tab_bytes = (uint32_t)bytes;
+                if (o + 1 < prog.n && prog.op[o + 1].type == OP_VEC_SUB
+                    && prog.op[o + 1].f == op.f) {
+                    // a categorical feature: (acc + S[x][k]) - shift[k]
+                    r.type = ROP_CAT;
+                    r.slot = next;
+                    src.p[src.n++] = prog.op[o + 1].p0;
+                    next += 1;
+                    o += 1;
+                }
+            } else if (op.type == OP_NICH) {
+                nich = true;
+                r.type = ROP_NICH;
+                r.slot = next;
+                src.p[src.n++] = op.p0; src.p[src.n++] = op.p1;
+                src.p[src.n++] = op.p2; src.p[src.n++] = op.p3;
+                next += 4;
+            } else {
+                return false;   // (a shift without its table: not a program
+                                //  sample_by_program builds)
+            }
+            if (n_ops < 4) {
+                int mul = 1;
+                for (int i = 0; i < n_ops; ++i) mul *= 4;
+                shape += (1 + r.type) * mul;
+            }
+            n_ops += 1;
+        }
+        const int W = next;
+        if (W > kRowsMaxW) return false;
+        const bool lds_log = nich && rows_scratch_lds_log != 0;
+        // 0 likelihoods in the scratch, 1 scores as well, 2 no scratch
+        const int mode = rows_scratch_mode == 2 ? 1
+                         : rows_scratch_mode == 3 ? 2 : 0;
+        const int block = rows_scratch_block;
+        // the program's shape at compile time where an instance exists
+        if (n_ops > 4) shape = 0;
+        const void * fn = nullptr;
+        int shape_id = 0;
+#define ROWS_SCRATCH_M(M, SHAPE)                                             \
+        do {                                                                 \
+            if (lds_log)                                                     \
+                fn = (const void *)&k_rows_scratch<M, true, SHAPE>;          \
+            else                                                             \
+                fn = (const void *)&k_rows_scratch<M, false, SHAPE>;         \
+        } while (0)
+#define ROWS_SCRATCH(ID, SHAPE)                                              \
+        do {                                                                 \
+            shape_id = ID;                                                   \
+            if (mode == 0) ROWS_SCRATCH_M(0, SHAPE);                         \
+            else if (mode == 1) ROWS_SCRATCH_M(1, SHAPE);                    \
+            else ROWS_SCRATCH_M(2, SHAPE);                                   \
+        } while (0)
+        if (shape == kShapeGN) ROWS_SCRATCH(1, kShapeGN);
+        else if (shape == kShapeN) ROWS_SCRATCH(2, kShapeN);
+        else if (shape == kShapeNN) ROWS_SCRATCH(3, kShapeNN);
+        else if (shape == kShapeG) ROWS_SCRATCH(4, kShapeG);
+        else if (shape == kShapeC) ROWS_SCRATCH(5, kShapeC);
+        else ROWS_SCRATCH(0, 0);
+#undef ROWS_SCRATCH
+#undef ROWS_SCRATCH_M
+        int dev = 0;
+        HIP_CHECK(hipGetDevice(&dev));
+        // workgroups of `block` threads resident per CU, per instance
+        static std::atomic<int> per_cu[3][2][6][64];
+        std::atomic<int> & cached =
+            per_cu[mode][lds_log ? 1 : 0][shape_id][dev & 63];
+        int resident = cached.load(std::memory_order_relaxed);
+        if (resident == 0 || resident / 4096 != block) {
+            int nb = 0;
+            HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(
+                &nb, fn, block, 0));
+            DIST_REQUIRE(nb >= 1, "k_rows_scratch does not fit a CU");
+            resident = block * 4096 + nb;
+            cached.store(resident, std::memory_order_relaxed);
+        }
+        const int wgs_per_cu = resident % 4096;
+        // (the scan requests two runs of kRowsScan rows ahead)
+        const int Kpad = (K() + 2 * kRowsScan - 1) / (2 * kRowsScan)
+                         * (2 * kRowsScan) + 2 * kRowsScan;
+        size_t blocks = std::min<size_t>((n + block - 1) / block,
+                                         (size_t)wgs_per_cu * cu_count());
+        const size_t per_block = (size_t)(block / 64) * Kpad * 64;   // floats
+        // at most 16 GiB of scratch
+        const size_t limit = ((size_t)4 << 30) / std::max<size_t>(per_block, 1);
+        if (limit < 1) return false;
+        blocks = std::max<size_t>(1, std::min(blocks, limit));
+        if (mode != 2) rows_scratch.reserve(blocks * per_block, 0);
+        rows_gtab.reserve(grow_capacity((size_t)Kpad * W), 0);
+        LAUNCH(k_rows_gtab, (size_t)Kpad, P.base, src, rows_gtab.p, Kpad, K(),
+               P.dev);
+        A.n_ops = n_ops;
+        A.W = W;
+        A.K = K();
+        A.Kpad = Kpad;
+        A.dev = P.dev;
+        A.gtab = rows_gtab.p;
+        A.slot = P.old_packed;
+        A.own = own_score.p;
+        A.new_packed = P.new_packed;
+        A.row_begin = P.row_begin;
+        A.n_items = n;
+        A.seed_batch = P.seed_batch;
+        A.pow_lo = P.pow_lo;
+        A.pow_hi = P.pow_hi;
+        A.scratch = rows_scratch.p;
+        void * args[] = {&A};
+        HIP_CHECK(hipLaunchKernel(fn, dim3((unsigned)blocks), dim3(block),
+                                  args, 0, stream()));
+        scratch_batches += 1;
+        return true;
+    }
+
     // Rows of mixed type: compile the feature list into a ScoreProgram over
     // this batch's tables (kernels.h) and sample with k_sweep_program; rows it
     // hands over go to the wave-per-row kernel.  false: a table is missing
@@ -1342,11 +1496,13 @@ struct Gibbs {
         mark(ev0);
         LAUNCH(k_row_prepass, n, P, prog, own_score.p, deferred.p,
                deferred_count.p);
-        const unsigned blocks = (unsigned)std::min<size_t>(
-            (n + kBlock - 1) / kBlock, 256 * 16);
-        hipLaunchKernelGGL(k_sweep_program, dim3(blocks), dim3(kBlock), 0,
-                           stream(), P, prog, own_score.p);
-        HIP_CHECK(hipGetLastError());
+        if (rows_scratch_mode == 0 || !launch_rows_scratch(P, prog, n)) {
+            const unsigned blocks = (unsigned)std::min<size_t>(
+                (n + kBlock - 1) / kBlock, 256 * 16);
+            hipLaunchKernelGGL(k_sweep_program, dim3(blocks), dim3(kBlock), 0,
+                               stream(), P, prog, own_score.p);
+            HIP_CHECK(hipGetLastError());
+        }
         // the handed-over rows (listed by batch row, in row order)
         SweepParams Q = P;
         Q.row_list = deferred.p;
@@ -1804,7 +1960,8 @@ struct Gibbs {
             dispatch(L);
             mark(ev1);
             generic_batches += 1;
-        } else if (uses_runtime_kernel() && sample_by_program(P)) {
+        } else if ((uses_runtime_kernel() || (program_all && F() >= 1))
+                   && sample_by_program(P)) {
             generic_batches += 1;
         } else {
             prepare(P);
@@ -3635,6 +3792,27 @@ int dist_gibbs_set_option(dist_gibbs_t * g, const char * name, int value) {
             // do not depend on it)
             DIST_REQUIRE(value >= 0, "running_sums_min_tiles: >= 0");
             g->impl->running_sums_min_tiles = value;
+        } else if (key == "rows_scratch") {
+            // general rows: 0 every pass scores again (k_sweep_program),
+            // 1 the likelihoods stay in a scratch column between total and
+            // scan (default), 2 the scores between max and total as well,
+            // 3 k_rows_scratch's lean loops without the scratch
+            DIST_REQUIRE(value >= 0 && value <= 3, "rows_scratch: 0 to 3");
+            g->impl->rows_scratch_mode = value;
+        } else if (key == "rows_scratch_lds_log") {
+            DIST_REQUIRE(value == 0 || value == 1,
+                         "rows_scratch_lds_log: 0 or 1");
+            g->impl->rows_scratch_lds_log = value;
+        } else if (key == "rows_scratch_block") {
+            DIST_REQUIRE(value >= 64 && value <= kScratchMaxBlock
+                             && value % 64 == 0,
+                         "rows_scratch_block: a multiple of 64 up to 1024");
+            g->impl->rows_scratch_block = value;
+        } else if (key == "program_all") {
+            // 1 (default): every batch outside the value-sorted path is
+            // scored by the program kernels when its tables exist
+            DIST_REQUIRE(value == 0 || value == 1, "program_all: 0 or 1");
+            g->impl->program_all = value;
         } else if (key == "sequential_chain") {
             // 1 (default): the device-resident chain kernel; 0: every row
             // as a batch of one
@@ -3655,9 +3833,10 @@ int dist_gibbs_path_counts(const dist_gibbs_t * g, uint64_t * value_sorted,
 int dist_gibbs_debug_counts(dist_gibbs_t * g, uint64_t * out, size_t n) {
     return guarded([&] {
         Gibbs & e = *g->impl;
-        uint64_t v[9] = {e.vs_batches, e.generic_batches, e.band_batches,
-                         e.prefix_batches, 0, 0, e.stream_batches,
-                         e.async_batches, e.narrow_batches};
+        uint64_t v[10] = {e.vs_batches, e.generic_batches, e.band_batches,
+                          e.prefix_batches, 0, 0, e.stream_batches,
+                          e.async_batches, e.narrow_batches,
+                          e.scratch_batches};
         if (e.last_bands && !e.batch_open && e.vsBandMode.p) {
             // values whose arg-max group's rows had a tile of their own in
             // the last value-sorted launch
@@ -3670,7 +3849,7 @@ int dist_gibbs_debug_counts(dist_gibbs_t * g, uint64_t * out, size_t n) {
             e.deferred_count.download(&d, 1);
             v[5] = d;
         }
-        for (size_t i = 0; i < n && i < 9; ++i) out[i] = v[i];
+        for (size_t i = 0; i < n && i < 10; ++i) out[i] = v[i];
     });
 }
 int dist_gibbs_kernel_stats(dist_gibbs_t * g, double * ms_out,

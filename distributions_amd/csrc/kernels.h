@@ -1301,6 +1301,471 @@ __global__ __launch_bounds__(kBlock) void k_sweep_program(
     }
 }
 
+// ---------------------------------------------------------------------------
+// k_rows_scratch: general rows with the likelihoods kept between the passes.
+//
+// The three recurrences of a row (max, in-order total, subtractive scan:
+// random.cc:94-106, random.hpp:316-333) each need every group's score; the
+// kernels above evaluate score and exponential again in each pass.  Here the
+// total's pass leaves l[k] = fast_exp(s[k] - max) in a scratch column of K
+// floats per row and the scan reads it back (MODE 0: two score evaluations,
+// one exponential, 8 B of HBM traffic per (row, group)); MODE 1 also keeps
+// the scores of the max pass for the total's pass (one evaluation, 16 B).
+// Same float operations in the same order as k_sweep_program: bit-identical.
+//
+// Scratch layout: one block of Kpad x 64 floats per resident WAVE,
+// [k / 4][lane][4]: a lane's four consecutive groups are 16 contiguous bytes,
+// so a pass streams its block with one 1-KiB dwordx4 store / load per four
+// groups; a wave re-uses its block for every 64 rows it takes (grid-stride),
+// so the scratch is (resident waves) x Kpad x 256 B whatever the batch size.
+//
+// The per-group parameters of the whole program sit in one per-batch table
+// (gtab[slot][Kpad]: slot 0 the driver's score, then each op's cache entries,
+// one slot each), so a block of eight groups costs one 32-byte scalar load
+// per slot, consecutive groups land in adjacent scalar registers (the
+// operands of the packed instructions the compiler forms over groups 2p,
+// 2p + 1), and the kernel takes a lean argument block instead of SweepParams
+// (whose pointers alone exceed the scalar registers).  Table gathers are
+// buffer loads: a scalar row offset plus the lane's value, no address
+// arithmetic, and reads beyond the table (the padding groups of the last
+// block) return zero.
+// LDSLOG: FastLog's 64 KiB table is copied into LDS (the per-lane gather of
+// nich.cc:60-66 then leaves the vector-memory path to the scratch stream).
+constexpr int kScratchMaxBlock = 1024;
+constexpr int kRowsBlock = 8;       // groups scored at a time, in registers
+constexpr int kRowsMaxW = 64;       // floats per gtab row
+constexpr int kRowsMaxOps = 8;      // = kMaxF: one op per feature
+// rows of scratch a wave block is padded to (the scan reads two runs of
+// kRowsScan rows ahead)
+constexpr int kRowsScan = 16;
+
+enum { ROP_GATHER = 0,   // s += tab[k][x]           BB, GP, BNB
+       ROP_CAT = 1,      // s = (s + tab[k][x]) - shift[k]   DD, DPD
+       ROP_NICH = 2 };
+struct RowsOp {
+    int type;
+    int slot;                  // first float of the op's parameters in a row
+    uint32_t tab_bytes;        // ROP_GATHER / ROP_CAT: K * nv * 4
+    uint32_t row_bytes;        // nv * 4
+    const float * tab;         // [K][nv]
+    const uint32_t * values;   // the feature's column
+};
+struct RowsArgs {
+    int n_ops;
+    int W;                     // slots of gtab
+    int K;                     // groups (an upper bound when dev != null)
+    int Kpad;                  // scratch rows per wave block
+    const DevState * dev;
+    const float * gtab;        // [W][Kpad]
+    const uint32_t * slot;     // k_row_prepass: own slot or 0xFFFFFFFF
+    const float * own;         // k_row_prepass: own-slot score
+    uint32_t * new_packed;
+    size_t row_begin;
+    size_t n_items;
+    uint32_t seed_batch;
+    int pad;
+    const uint32_t * pow_lo;
+    const uint32_t * pow_hi;
+    float * scratch;
+    RowsOp op[kRowsMaxOps];
+};
+
+// gtab slot layout: { base, (per op in order) ROP_CAT: shift;
+//                     ROP_NICH: c0, c1, c2, c3 }; groups beyond the group
+// count are zero
+struct GtabSource {
+    int n;                          // slots after the first
+    const float * p[kRowsMaxW];
+};
+__global__ void k_rows_gtab(const float * __restrict__ base, GtabSource src,
+                            float * __restrict__ gtab, int Kpad, int K_bound,
+                            const DevState * dev) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= Kpad) return;
+    const int K = dev ? dev->K : K_bound;
+    const bool in = k < K;
+    gtab[k] = in ? base[k] : 0.f;
+    for (int i = 0; i < src.n; ++i)
+        gtab[(size_t)(i + 1) * Kpad + k] = in ? src.p[i][k] : 0.f;
+}
+
+// fast_exp of a non-positive argument with the table in LDS, its entries
+// already carrying the exponent bias: ((u + 127) << 23) | tbl[v] ==
+// (u << 23) + (tbl[v] | 127 << 23).  The argument is in [-88, 0], so the
+// nearest integer of x * a is exactly representable and float(r) is the
+// rounded product itself (fmath.hpp:438-459, release-build order).
+__device__ __forceinline__ float fast_exp_biased(float x,
+                                                 const uint32_t * tab_biased,
+                                                 float a, float b) {
+    x = fmaxf(x, -88.0f);
+    const float rf = __builtin_rintf(x * a);
+    const int32_t r = (int32_t)rf;
+    const uint32_t bits =
+        ((uint32_t)(r >> 10) << 23) + tab_biased[(uint32_t)r & 1023u];
+    return ((x + 1.0f) - rf * b) * u2f(bits);
+}
+
+// tab[k][x] for the block's groups: buffer loads with the row's byte offset
+// as the scalar offset and the lane's value (times four) as the vector offset
+__device__ __forceinline__ void rows_gather(const RowsOp & op, uint32_t xoff,
+                                            int k0, float (&gv)[kRowsBlock]) {
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(op.tab), 0, (int)op.tab_bytes, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < kRowsBlock; ++j)
+        gv[j] = __builtin_bit_cast(
+            float, __builtin_amdgcn_raw_buffer_load_b32(
+                       rsrc, (int)xoff, (int)((uint32_t)(k0 + j) * op.row_bytes),
+                       0));
+}
+
+// one op over kRowsBlock consecutive groups; gt = gtab + k0 (slot i of group
+// k0 + j at gt[i * Kpad + j]).  xv: the row's value (ROP_NICH: its float
+// bits; the gathers: the value times four)
+template <int TYPE, bool LDSLOG>
+__device__ __forceinline__ void rows_op(const RowsOp & op, int slot,
+                                        uint32_t xv, uniform_fp gt, int Kpad,
+                                        int k0, const uint32_t * log_tab,
+                                        float (&s)[kRowsBlock]) {
+#define GT(j, i) gt[(size_t)(i) * Kpad + (j)]
+    if (TYPE == ROP_GATHER || TYPE == ROP_CAT) {
+        float gv[kRowsBlock];
+        rows_gather(op, xv, k0, gv);
+#pragma unroll
+        for (int j = 0; j < kRowsBlock; ++j) s[j] = s[j] + gv[j];
+        if (TYPE == ROP_CAT) {   // dd.hpp:433-445: (acc + S) - shift
+#pragma unroll
+            for (int j = 0; j < kRowsBlock; ++j) s[j] = s[j] - GT(j, slot);
+        }
+    } else {
+        const float x = u2f(xv);
+        float temp[kRowsBlock], tl[kRowsBlock];
+#pragma unroll
+        for (int j = 0; j < kRowsBlock; ++j) {
+            const float d = x - GT(j, slot + 3);
+            temp[j] = 1.f + GT(j, slot + 2) * (d * d);
+        }
+        // FastLog::log (special.hpp:57-67): the table reads of the block
+        // issued together
+#pragma unroll
+        for (int j = 0; j < kRowsBlock; ++j) {
+            const uint32_t man = (f2u(temp[j]) >> 9) & 0x3FFFu;
+            tl[j] = u2f(LDSLOG ? log_tab[man]
+                               : g_tables_dev.log_table[man]);
+        }
+        // float(exponent - 127) in two instructions: the biased exponent is
+        // shifted into the mantissa of 2^23 (temp >= 1: no sign bit), and
+        // 2^23 + 127 comes off exactly
+#pragma unroll
+        for (int j = 0; j < kRowsBlock; ++j) {
+            const float e = u2f(__builtin_amdgcn_alignbit(
+                                0x258000u, f2u(temp[j]), 23)) - 8388735.0f;
+            const float lg = (e + tl[j]) * 0.69314718055994529f;
+            s[j] = s[j] + (GT(j, slot) + GT(j, slot + 1) * lg);
+        }
+    }
+#undef GT
+}
+
+// SHAPE: the program's op types at compile time, base-4 digits from the first
+// op (1 + type each; 0 ends the list); 0 = any program of up to kRowsMaxOps
+// ops, their types tested at run time (wave-uniform branches)
+constexpr int rows_shape_digit(int shape, int i) {
+    return i == 0 ? shape % 4 : rows_shape_digit(shape / 4, i - 1);
+}
+constexpr int rows_shape_len(int shape) {
+    return shape == 0 ? 0 : 1 + rows_shape_len(shape / 4);
+}
+// a program's gtab layout: slot 0 the driver's score, then per op ROP_CAT one
+// slot, ROP_NICH four
+constexpr int rows_shape_slot(int shape, int i) {   // first slot of op i
+    int next = 1;
+    for (int o = 0; o < i; ++o) {
+        const int t = rows_shape_digit(shape, o) - 1;
+        if (t == ROP_CAT) next += 1;
+        if (t == ROP_NICH) next += 4;
+    }
+    return next;
+}
+constexpr int kShapeN = 1 + ROP_NICH;                      // one real
+constexpr int kShapeG = 1 + ROP_GATHER;                    // GP / BB / BNB
+constexpr int kShapeC = 1 + ROP_CAT;                       // DD / DPD
+constexpr int kShapeGN = kShapeG + 4 * (1 + ROP_NICH);     // GP + NICH
+constexpr int kShapeNN = kShapeN + 4 * (1 + ROP_NICH);     // two reals
+constexpr int kRowsXv = 8;   // a row's values in registers
+
+template <int SHAPE, int I, bool LDSLOG>
+__device__ __forceinline__ void rows_shape_ops(
+        const RowsArgs & A, const uint32_t (&xv)[kRowsXv], uniform_fp gt,
+        int k0, const uint32_t * log_tab, float (&s)[kRowsBlock]) {
+    if constexpr (I < rows_shape_len(SHAPE)) {
+        rows_op<rows_shape_digit(SHAPE, I) - 1, LDSLOG>(
+            A.op[I], rows_shape_slot(SHAPE, I), xv[I], gt, A.Kpad, k0,
+            log_tab, s);
+        rows_shape_ops<SHAPE, I + 1, LDSLOG>(A, xv, gt, k0, log_tab, s);
+    }
+}
+
+// scores of groups [k0, k0 + kRowsBlock) for one row per lane; groups beyond
+// the last take whatever their zeroed parameters give (the callers mask)
+template <int SHAPE, bool LDSLOG>
+__device__ __forceinline__ void rows_score_block(
+        const RowsArgs & A, const uint32_t (&xv)[kRowsXv], int k0, int g,
+        float s_own, const uint32_t * log_tab, float (&s)[kRowsBlock]) {
+    uniform_fp gt = as_uniform(A.gtab) + k0;
+    const int W = A.Kpad;   // (the slot stride, as rows_op's GT wants it)
+#pragma unroll
+    for (int j = 0; j < kRowsBlock; ++j) s[j] = gt[j];
+    if constexpr (SHAPE != 0) {
+        rows_shape_ops<SHAPE, 0, LDSLOG>(A, xv, gt, k0, log_tab, s);
+    } else {
+        // (a rolled loop: the row's values are picked from their registers
+        // by the wave-uniform op index, the op bodies exist once)
+        for (int o = 0; o < A.n_ops; ++o) {
+            const RowsOp & op = A.op[o];
+            const uint32_t x = xv[o];
+            if (op.type == ROP_GATHER)
+                rows_op<ROP_GATHER, LDSLOG>(op, 0, x, gt, W, k0, log_tab, s);
+            else if (op.type == ROP_CAT)
+                rows_op<ROP_CAT, LDSLOG>(op, op.slot, x, gt, W, k0, log_tab,
+                                         s);
+            else
+                rows_op<ROP_NICH, LDSLOG>(op, op.slot, x, gt, W, k0, log_tab,
+                                          s);
+        }
+    }
+    // the row's own slot (wave-uniform test first: most blocks hold no lane's)
+    const int gl = g - k0;
+    if (__any((unsigned)gl < (unsigned)kRowsBlock)) {
+#pragma unroll
+        for (int j = 0; j < kRowsBlock; ++j) s[j] = gl == j ? s_own : s[j];
+    }
+}
+
+// what a lane keeps of its row between the passes
+struct RowsRow {
+    uint32_t xv[kRowsXv];
+    size_t out;        // batch-relative index (results, entropy)
+    int g;             // own slot, -1 for a lane without a live row
+    float s_own;
+    bool live;
+};
+
+// MODE 0: likelihoods in the scratch, and the scan of a wave's row tile i
+//         runs inside the max pass of its tile i + 1 (the scan only loads and
+//         subtracts, the max pass only computes: fused, the wave has memory
+//         requests in flight while it scores);
+// MODE 1: scores kept for the total's pass as well (one evaluation, 16 B);
+// MODE 2: no scratch: the scan evaluates score and exponential again (rows
+//         whose score is cheap -- one feature -- are faster this way).
+template <int MODE, bool LDSLOG, int SHAPE>
+__global__ __launch_bounds__(kScratchMaxBlock) void k_rows_scratch(RowsArgs A) {
+    __shared__ uint32_t s_exp[1024];                  // biased, see above
+    __shared__ uint32_t s_log[LDSLOG ? 16384 : 1];
+    for (int i = threadIdx.x; i < 1024; i += blockDim.x)
+        s_exp[i] = g_tables_dev.exp_table[i] | 0x3F800000u;
+    if (LDSLOG)
+        for (int i = threadIdx.x; i < 16384; i += blockDim.x)
+            s_log[i] = g_tables_dev.log_table[i];
+    __syncthreads();
+    const float ea = u2f(g_tables_dev.exp_ab[0]);
+    const float eb = u2f(g_tables_dev.exp_ab[1]);
+    // (wave-uniform values the compiler cannot see as such are pinned to
+    // scalar registers: loop control and table offsets stay on the scalar unit)
+    const int K = __builtin_amdgcn_readfirstlane(A.dev ? A.dev->K : A.K);
+    const int lane = threadIdx.x & 63;
+    const size_t wave_slot =
+        (size_t)blockIdx.x * (blockDim.x >> 6)
+        + (size_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // this wave's block of the scratch; groups 4q .. 4q + 3 of the lane's row
+    // at col[q * 64]
+    float4 * col = MODE == 2
+                       ? nullptr
+                       : reinterpret_cast<float4 *>(
+                             A.scratch + wave_slot * (size_t)A.Kpad * 64)
+                             + lane;
+    const int K8 = (K + kRowsBlock - 1) & ~(kRowsBlock - 1);
+    const int K16 = (K + kRowsScan - 1) & ~(kRowsScan - 1);
+
+    auto load_row = [&](size_t item, RowsRow & r) {
+        const bool in = item < A.n_items;
+        r.out = in ? item : 0;
+        const size_t row = A.row_begin + r.out;
+        const uint32_t slot = A.slot[r.out];   // k_row_prepass
+        // (a handed-over row idles along on value 0: its own values may lie
+        // outside the tables)
+        r.live = in && slot != 0xFFFFFFFFu;
+        r.g = r.live ? (int)slot : -1;
+        r.s_own = A.own[r.out];
+#pragma unroll
+        for (int o = 0; o < kRowsXv; ++o) {
+            r.xv[o] = 0;
+            const bool used = SHAPE != 0 ? o < rows_shape_len(SHAPE)
+                                         : o < A.n_ops;
+            if (used && r.live) {
+                const bool nich =
+                    SHAPE != 0 ? rows_shape_digit(SHAPE, o) - 1 == ROP_NICH
+                               : A.op[o].type == ROP_NICH;
+                r.xv[o] = A.op[o].values[row] * (nich ? 1u : 4u);
+            }
+        }
+    };
+    // one block of the max pass (vector_max, vector_math.cc:74-83; max is
+    // order-free); groups beyond the last score -inf
+    auto max_block = [&](const RowsRow & r, int k0, float & m) {
+        float s[kRowsBlock];
+        rows_score_block<SHAPE, LDSLOG>(A, r.xv, k0, r.g, r.s_own, s_log, s);
+        if (k0 + kRowsBlock > K) {
+#pragma unroll
+            for (int j = 0; j < kRowsBlock; ++j)
+                s[j] = k0 + j < K ? s[j] : -INFINITY;
+        }
+        if (MODE == 1) {
+            col[(size_t)(k0 >> 2) * 64] = make_float4(s[0], s[1], s[2], s[3]);
+            col[(size_t)((k0 >> 2) + 1) * 64] =
+                make_float4(s[4], s[5], s[6], s[7]);
+        }
+#pragma unroll
+        for (int j = 0; j < kRowsBlock; ++j) m = fmaxf(m, s[j]);
+    };
+    // the likelihoods of one block (scores_to_likelihoods, random.cc:94-106),
+    // +0 beyond the last group
+    auto like_block = [&](const RowsRow & r, int k0, float m,
+                          float (&s)[kRowsBlock]) {
+        if (MODE == 1) {
+            const float4 a = col[(size_t)(k0 >> 2) * 64];
+            const float4 b = col[(size_t)((k0 >> 2) + 1) * 64];
+            s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w;
+            s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w;
+        } else {
+            rows_score_block<SHAPE, LDSLOG>(A, r.xv, k0, r.g, r.s_own, s_log,
+                                            s);
+        }
+#pragma unroll
+        for (int j = 0; j < kRowsBlock; ++j)
+            s[j] = fast_exp_biased(s[j] - m, s_exp, ea, eb);
+        if (k0 + kRowsBlock > K) {
+#pragma unroll
+            for (int j = 0; j < kRowsBlock; ++j)
+                s[j] = k0 + j < K ? s[j] : 0.f;
+        }
+    };
+    // sample_from_likelihoods (random.hpp:316-333) over a run of entries:
+    // t never increases, so the index is the number of steps after which t is
+    // still positive (entries beyond K are +0: they count only once t stayed
+    // positive through K - 1, which the final clamp maps to K - 1 as well)
+    auto scan_run = [&](const float (&l)[kRowsScan], float & t, int & steps) {
+#pragma unroll
+        for (int j = 0; j < kRowsScan; ++j) {
+            t -= l[j];
+            steps += t > 0.f ? 1 : 0;
+        }
+    };
+    // a run of kRowsScan likelihoods of the lane's row, from group k0
+    auto load_run = [&](int k0, float (&l)[kRowsScan]) {
+#pragma unroll
+        for (int q = 0; q < kRowsScan / 4; ++q) {
+            const float4 v = col[(size_t)((k0 >> 2) + q) * 64];
+            l[4 * q] = v.x; l[4 * q + 1] = v.y;
+            l[4 * q + 2] = v.z; l[4 * q + 3] = v.w;
+        }
+    };
+    auto draw = [&](const RowsRow & r) {
+        uint32_t xs = lcg_mulmod(A.seed_batch, A.pow_lo[r.out & 4095]);
+        xs = lcg_mulmod(xs, A.pow_hi[r.out >> 12]);
+        return lcg_unif01(xs);
+    };
+
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t tile = wave_slot * 64;   // first row of the wave's 64 (uniform)
+    if (tile >= A.n_items) return;
+    RowsRow cur;
+    load_row(tile + lane, cur);
+    float m = -INFINITY;
+    for (int k0 = 0; k0 < K8; k0 += kRowsBlock) max_block(cur, k0, m);
+    for (;;) {
+        // total in index order (random.cc:100-103); the likelihoods stay
+        // behind in the scratch column
+        float total = 0.f;
+        for (int k0 = 0; k0 < K8; k0 += kRowsBlock) {
+            float l[kRowsBlock];
+            like_block(cur, k0, m, l);
+#pragma unroll
+            for (int j = 0; j < kRowsBlock; ++j) total += l[j];
+            if (MODE != 2) {
+                col[(size_t)(k0 >> 2) * 64] =
+                    make_float4(l[0], l[1], l[2], l[3]);
+                col[(size_t)((k0 >> 2) + 1) * 64] =
+                    make_float4(l[4], l[5], l[6], l[7]);
+            }
+        }
+        if (MODE != 2)   // (the scan reads runs of kRowsScan rows)
+            for (int k = K8; k < K16; k += 4)
+                col[(size_t)(k >> 2) * 64] = make_float4(0.f, 0.f, 0.f, 0.f);
+        float t = total * draw(cur);
+        int steps = 0;
+        const size_t next_tile = tile + stride;
+        const bool more = next_tile < A.n_items;
+        RowsRow nxt;
+        float m_next = -INFINITY;
+        if (MODE == 2) {
+            for (int k0 = 0; k0 < K8; k0 += kRowsBlock) {
+                float l[kRowsBlock];
+                like_block(cur, k0, m, l);
+#pragma unroll
+                for (int j = 0; j < kRowsBlock; ++j) {
+                    t -= l[j];
+                    steps += t > 0.f ? 1 : 0;
+                }
+                if (!__any(cur.live && t > 0.f)) break;
+            }
+        } else if (MODE == 0 && more) {
+            // the scan of this tile inside the max pass of the next one: a
+            // run's loads are requested, two blocks are scored, then the run
+            // is consumed
+            load_row(next_tile + lane, nxt);
+            for (int k0 = 0; k0 < K16; k0 += kRowsScan) {
+                float l[kRowsScan];
+                load_run(k0, l);
+                __builtin_amdgcn_sched_barrier(0);   // requests stay up here
+                max_block(nxt, k0, m_next);
+                if (k0 + kRowsBlock < K8)
+                    max_block(nxt, k0 + kRowsBlock, m_next);
+                __builtin_amdgcn_sched_barrier(0);
+                scan_run(l, t, steps);
+            }
+        } else {
+            // two runs in flight: the next is requested before the current
+            // one is consumed (requests past the last run fall into the
+            // block's padding rows and are never used)
+            float la[kRowsScan], lb[kRowsScan];
+            load_run(0, la);
+            for (int k0 = 0; k0 < K; k0 += 2 * kRowsScan) {
+                load_run(k0 + kRowsScan, lb);
+                __builtin_amdgcn_sched_barrier(0);
+                scan_run(la, t, steps);
+                if (k0 + kRowsScan >= K || !__any(cur.live && t > 0.f)) break;
+                load_run(k0 + 2 * kRowsScan, la);
+                __builtin_amdgcn_sched_barrier(0);
+                scan_run(lb, t, steps);
+                if (!__any(cur.live && t > 0.f)) break;
+            }
+        }
+        if (cur.live)
+            A.new_packed[cur.out] = (uint32_t)(steps < K - 1 ? steps : K - 1);
+        if (!more) break;
+        tile = next_tile;
+        if (MODE == 0) {
+            cur = nxt;
+            m = m_next;
+        } else {
+            load_row(tile + lane, cur);
+            m = -INFINITY;
+            for (int k0 = 0; k0 < K8; k0 += kRowsBlock) max_block(cur, k0, m);
+        }
+    }
+}
+
 // The two order-sensitive recurrences over a likelihood strip in LDS, computed
 // redundantly by every lane of a wave (uniform-address LDS reads broadcast):
 //   total = ((l_0 + l_1) + l_2) + ...              random.cc:100-103

@@ -99,6 +99,42 @@ def test_batch_sweeps_bit_exact(config, batch, mode):
     assert counts["narrow_batches"] == (vs if mode in (4, 5) else 0)
 
 
+@pytest.mark.parametrize("config", CONFIGS + ["nich2"])
+@pytest.mark.parametrize("scratch,lds_log,block", [(0, 1, 512), (1, 1, 512),
+                                                   (1, 0, 256), (2, 1, 1024),
+                                                   (2, 0, 64), (3, 1, 512),
+                                                   (1, 1, 64)])
+@pytest.mark.parametrize("k", [31, 40])
+def test_general_rows_scratch_kernel_bit_exact(config, scratch, lds_log, block,
+                                               k):
+    """k_rows_scratch (the likelihoods of the total's pass kept for the scan;
+    mode 2: the scores of the max pass kept as well; mode 3: its loops without
+    the scratch; small workgroups give every wave several row tiles, i.e. the
+    scan of one tile inside the max pass of the next) against the oracle, on
+    every feature list, with group counts on either side of its blocks of 8
+    and 16 groups; rows_scratch = 0 is round 2's k_sweep_program."""
+    n = 6000
+    from distributions_amd import engine
+    osh, gsh, vals, assign = workloads.make(config, n, k)
+    orc = ol.OracleMixture(1.0, 0.2, osh)
+    orc.init_from_assignments(vals, assign, k, 1)
+    gpu = engine.Gibbs(1.0, 0.2, gsh)
+    gpu.set_option("value_sorted", 0)
+    gpu.set_option("rows_scratch", scratch)
+    gpu.set_option("rows_scratch_lds_log", lds_log)
+    gpu.set_option("rows_scratch_block", block)
+    gpu.load_rows(vals, assign, k, 1)
+    seed = 4242
+    st = ol.oracle().orc_rng_seed(seed)
+    for sweep in range(2):
+        for b in range(0, n, 3000):
+            orc.gibbs_batch(b, b + 3000, st, sweep * n)
+        gpu.sweep(0, n, 3000, seed, draw_base=sweep * n)
+        assert_same_state(orc, gpu, "%s sweep %d" % (config, sweep))
+    counts = gpu.core.debug_counts()
+    assert counts["scratch_batches"] == (4 if scratch else 0)
+
+
 @pytest.mark.parametrize("config,dim,k", [("dd", 256, 64), ("dd_skew", 64, 16),
                                           ("dpd_other", 300, 24), ("bb", None, 8),
                                           ("gp", None, 12)])

@@ -55,6 +55,13 @@ def make(config, n, k, seed=SEED, dim=None):
                ol.make_shared(ol.NICH, mu=0.0, kappa=1.0, sigmasq=1.0, nu=1.0)]
         gsh = [engine.gp_shared(1.0, 1.0),
                engine.nich_shared(0.0, 1.0, 1.0, 1.0)]
+    elif config == "nich2":
+        vals = [rng.normal(0, 1, n).astype(np.float32),
+                rng.normal(3, 2, n).astype(np.float32)]
+        osh = [ol.make_shared(ol.NICH, mu=0.0, kappa=1.0, sigmasq=1.0, nu=1.0),
+               ol.make_shared(ol.NICH, mu=1.0, kappa=0.5, sigmasq=2.0, nu=3.0)]
+        gsh = [engine.nich_shared(0.0, 1.0, 1.0, 1.0),
+               engine.nich_shared(1.0, 0.5, 2.0, 3.0)]
     elif config == "dpd":
         dim = dim or 100
         betas = np.full(dim, 1.0 / dim, np.float32)
