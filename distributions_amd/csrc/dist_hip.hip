@@ -886,7 +886,49 @@ struct Gibbs {
     // compile-time instance of k_sweep_sample, as in round 2)
     int program_all = 1;
     DeviceBuf<float> rows_scratch;          // [resident waves][Kpad][64]
-    DeviceBuf<float> rows_gtab;             // [Kpad][W], see k_rows_gtab
+    DeviceBuf<float> rows_gtab;             // [W][Kpad], see k_rows_gtab
+    // folding (kernels.h, FoldSpec): 0 off, 1 where the joint domain of the
+    // leading discrete features leaves >= kFoldRowsPerCode rows per value
+    int rows_fold_mode = 1;
+    static constexpr size_t kFoldRowsPerCode = 128;
+    struct FoldCache {
+        size_t r0 = 0, r1 = 0;
+        int n_fold = 0;
+        uint32_t J = 0;
+        DeviceBuf<uint32_t> sorted_rows;
+        DeviceBuf<uint4> tiles;
+        uint32_t n_tiles = 0;
+    };
+    std::vector<std::unique_ptr<FoldCache>> fold_cache;
+    DeviceBuf<float> rows_fold;             // [J][Kpad]
+    uint64_t fold_batches = 0;
+    FoldCache & fold_get(size_t r0, size_t r1, const FoldSpec & F, uint32_t J) {
+        for (auto & c : fold_cache)
+            if (c->r0 == r0 && c->r1 == r1 && c->n_fold == F.n && c->J == J)
+                return *c;
+        std::unique_ptr<FoldCache> c(new FoldCache());
+        c->r0 = r0; c->r1 = r1; c->n_fold = F.n; c->J = J;
+        const size_t n = r1 - r0;
+        DeviceBuf<uint32_t> codes, index, codes_sorted;
+        codes.reserve(n, 0); index.reserve(n, 0); codes_sorted.reserve(n, 0);
+        c->sorted_rows.reserve(n, 0);
+        LAUNCH(k_fold_codes, n, F, r0, n, J, codes.p, index.p);
+        int bits = 1;
+        while ((1ull << bits) < (unsigned long long)J + 1) bits += 1;
+        const size_t tb = sort_pairs_temp_bytes(n, bits);
+        DeviceBuf<unsigned char> temp;
+        temp.reserve(tb + 256, 0);
+        sort_pairs(temp.p, tb, codes.p, codes_sorted.p, index.p,
+                   c->sorted_rows.p, n, bits, stream());
+        c->tiles.reserve(n / 64 + (size_t)J + 2, 0);
+        DeviceBuf<uint32_t> count;
+        count.reserve(1, 0);   // zero-filled
+        LAUNCH(k_fold_tiles, n, codes_sorted.p, n, c->tiles.p, count.p);
+        count.download(&c->n_tiles, 1);   // (also drains the stream)
+        if (fold_cache.size() >= 64) fold_cache.erase(fold_cache.begin());
+        fold_cache.push_back(std::move(c));
+        return *fold_cache.back();
+    }
     uint64_t scratch_batches = 0;
     int sequential_mode = 1;   // 0: every row as a batch of one (diagnostic)
     DeviceBuf<int> vsArg;
@@ -1204,6 +1246,7 @@ struct Gibbs {
         // value tables of the count-valued ones)
         max_value.assign((size_t)F(), 0);
         vs_cache.clear();
+        fold_cache.clear();
         for (int f = 0; f < F(); ++f) {
             const int kind = feats[f]->sh.kind;
             if (kind == DIST_NICH || !n) continue;
@@ -1327,9 +1370,9 @@ struct Gibbs {
         memset(&A, 0, sizeof(A));
         GtabSource src;
         memset(&src, 0, sizeof(src));
-        bool nich = false;
-        int next = 1;   // slot 0: the driver's score
-        int shape = 0, n_ops = 0;
+        int n_ops = 0;
+        const float * par[kRowsMaxOps][4];   // an op's per-group parameters
+        memset(par, 0, sizeof(par));
         const int K8 = (K() + kRowsBlock - 1) / kRowsBlock * kRowsBlock;
         for (int o = 0; o < prog.n; ++o) {
             const ScoreOp & op = prog.op[o];
@@ -1348,28 +1391,79 @@ struct Gibbs {
                     && prog.op[o + 1].f == op.f) {
                     // a categorical feature: (acc + S[x][k]) - shift[k]
                     r.type = ROP_CAT;
-                    r.slot = next;
-                    src.p[src.n++] = prog.op[o + 1].p0;
-                    next += 1;
+                    par[n_ops][0] = prog.op[o + 1].p0;
                     o += 1;
                 }
             } else if (op.type == OP_NICH) {
-                nich = true;
                 r.type = ROP_NICH;
-                r.slot = next;
-                src.p[src.n++] = op.p0; src.p[src.n++] = op.p1;
-                src.p[src.n++] = op.p2; src.p[src.n++] = op.p3;
-                next += 4;
+                par[n_ops][0] = op.p0; par[n_ops][1] = op.p1;
+                par[n_ops][2] = op.p2; par[n_ops][3] = op.p3;
             } else {
                 return false;   // (a shift without its table: not a program
                                 //  sample_by_program builds)
             }
-            if (n_ops < 4) {
+            n_ops += 1;
+        }
+        // fold the leading table ops into a per-(joint value, group) base
+        FoldSpec F;
+        memset(&F, 0, sizeof(F));
+        uint32_t J = 1;
+        const int Kpad = (K() + 2 * kRowsScan - 1) / (2 * kRowsScan)
+                         * (2 * kRowsScan) + 2 * kRowsScan;
+        if (rows_fold_mode == 2 || (rows_fold_mode == 1 && n >= 8192)) {
+            const size_t per_code = rows_fold_mode == 2 ? 1 : kFoldRowsPerCode;
+            for (int o = 0; o < n_ops; ++o) {
+                const RowsOp & r = A.op[o];
+                if (r.type == ROP_NICH) break;
+                const uint32_t nv = r.row_bytes / 4u;
+                const size_t Jn = (size_t)J * nv;
+                if (Jn * per_code > n || Jn > 65536
+                    || Jn * Kpad * 4 > ((size_t)256 << 20))
+                    break;
+                F.nv[F.n] = nv;
+                F.values[F.n] = r.values;
+                F.tab[F.n] = r.tab;
+                F.shift[F.n] = r.type == ROP_CAT ? par[o][0] : nullptr;
+                F.n += 1;
+                J = (uint32_t)Jn;
+            }
+            // the first folded feature is the most significant digit
+            uint32_t stride = J;
+            for (int o = 0; o < F.n; ++o) {
+                stride /= F.nv[o];
+                F.stride[o] = stride;
+            }
+        }
+        if (F.n) {   // the remaining ops move to the front
+            for (int o = F.n; o < n_ops; ++o) {
+                A.op[o - F.n] = A.op[o];
+                for (int i = 0; i < 4; ++i) par[o - F.n][i] = par[o][i];
+            }
+            n_ops -= F.n;
+            for (int o = n_ops; o < kRowsMaxOps; ++o)
+                memset(&A.op[o], 0, sizeof(RowsOp));
+        }
+        // the gtab slots and the shape of what remains
+        bool nich = false;
+        int next = 1;   // slot 0: the driver's score
+        int shape = 0;
+        for (int o = 0; o < n_ops; ++o) {
+            RowsOp & r = A.op[o];
+            if (r.type == ROP_CAT) {
+                r.slot = next;
+                src.p[src.n++] = par[o][0];
+                next += 1;
+            } else if (r.type == ROP_NICH) {
+                nich = true;
+                r.slot = next;
+                for (int i = 0; i < 4; ++i) src.p[src.n++] = par[o][i];
+                next += 4;
+            }
+            if (o < 4) {
                 int mul = 1;
-                for (int i = 0; i < n_ops; ++i) mul *= 4;
+                for (int i = 0; i < o; ++i) mul *= 4;
                 shape += (1 + r.type) * mul;
             }
-            n_ops += 1;
         }
         const int W = next;
         if (W > kRowsMaxW) return false;
@@ -1420,20 +1514,31 @@ struct Gibbs {
             cached.store(resident, std::memory_order_relaxed);
         }
         const int wgs_per_cu = resident % 4096;
-        // (the scan requests two runs of kRowsScan rows ahead)
-        const int Kpad = (K() + 2 * kRowsScan - 1) / (2 * kRowsScan)
-                         * (2 * kRowsScan) + 2 * kRowsScan;
-        size_t blocks = std::min<size_t>((n + block - 1) / block,
-                                         (size_t)wgs_per_cu * cu_count());
+        size_t blocks = (size_t)wgs_per_cu * cu_count();
         const size_t per_block = (size_t)(block / 64) * Kpad * 64;   // floats
         // at most 16 GiB of scratch
         const size_t limit = ((size_t)4 << 30) / std::max<size_t>(per_block, 1);
         if (limit < 1) return false;
         blocks = std::max<size_t>(1, std::min(blocks, limit));
+        const size_t blocks_cap = blocks;
         if (mode != 2) rows_scratch.reserve(blocks * per_block, 0);
         rows_gtab.reserve(grow_capacity((size_t)Kpad * W), 0);
         LAUNCH(k_rows_gtab, (size_t)Kpad, P.base, src, rows_gtab.p, Kpad, K(),
                P.dev);
+        size_t n_work = (n + 63) / 64;
+        if (F.n) {
+            FoldCache & fc = fold_get(P.row_begin, P.row_end, F, J);
+            rows_fold.reserve(grow_capacity((size_t)J * Kpad), 0);
+            LAUNCH(k_rows_fold, (size_t)J * Kpad, F, P.base, rows_fold.p, J,
+                   Kpad, K(), P.dev);
+            A.fold = rows_fold.p;
+            A.sorted_rows = fc.sorted_rows.p;
+            A.tiles = fc.tiles.p;
+            A.n_tiles = fc.n_tiles;
+            A.fold_codes = J;
+            n_work = fc.n_tiles;
+            fold_batches += 1;
+        }
         A.n_ops = n_ops;
         A.W = W;
         A.K = K();
@@ -1449,6 +1554,9 @@ struct Gibbs {
         A.pow_lo = P.pow_lo;
         A.pow_hi = P.pow_hi;
         A.scratch = rows_scratch.p;
+        blocks = std::max<size_t>(
+            1, std::min(blocks_cap,
+                        (n_work + block / 64 - 1) / (size_t)(block / 64)));
         void * args[] = {&A};
         HIP_CHECK(hipLaunchKernel(fn, dim3((unsigned)blocks), dim3(block),
                                   args, 0, stream()));
@@ -3808,6 +3916,12 @@ int dist_gibbs_set_option(dist_gibbs_t * g, const char * name, int value) {
                              && value % 64 == 0,
                          "rows_scratch_block: a multiple of 64 up to 1024");
             g->impl->rows_scratch_block = value;
+        } else if (key == "rows_fold") {
+            // general rows: the leading discrete features' scores from a
+            // per-(joint value, group) table, rows sorted by joint value
+            // (2: whenever the joint domain is no larger than the batch)
+            DIST_REQUIRE(value >= 0 && value <= 2, "rows_fold: 0, 1 or 2");
+            g->impl->rows_fold_mode = value;
         } else if (key == "program_all") {
             // 1 (default): every batch outside the value-sorted path is
             // scored by the program kernels when its tables exist
@@ -3833,10 +3947,10 @@ int dist_gibbs_path_counts(const dist_gibbs_t * g, uint64_t * value_sorted,
 int dist_gibbs_debug_counts(dist_gibbs_t * g, uint64_t * out, size_t n) {
     return guarded([&] {
         Gibbs & e = *g->impl;
-        uint64_t v[10] = {e.vs_batches, e.generic_batches, e.band_batches,
+        uint64_t v[11] = {e.vs_batches, e.generic_batches, e.band_batches,
                           e.prefix_batches, 0, 0, e.stream_batches,
                           e.async_batches, e.narrow_batches,
-                          e.scratch_batches};
+                          e.scratch_batches, e.fold_batches};
         if (e.last_bands && !e.batch_open && e.vsBandMode.p) {
             // values whose arg-max group's rows had a tile of their own in
             // the last value-sorted launch
@@ -3849,7 +3963,7 @@ int dist_gibbs_debug_counts(dist_gibbs_t * g, uint64_t * out, size_t n) {
             e.deferred_count.download(&d, 1);
             v[5] = d;
         }
-        for (size_t i = 0; i < n && i < 10; ++i) out[i] = v[i];
+        for (size_t i = 0; i < n && i < 11; ++i) out[i] = v[i];
     });
 }
 int dist_gibbs_kernel_stats(dist_gibbs_t * g, double * ms_out,

@@ -1367,8 +1367,94 @@ struct RowsArgs {
     const uint32_t * pow_lo;
     const uint32_t * pow_hi;
     float * scratch;
+    // folded leading ops (see FoldSpec): the wave's rows share one joint
+    // value `code`, their score before the first remaining op is
+    // fold[code][k]; work items are tiles of the code-sorted row list
+    const float * fold;            // [J][Kpad], null: no folding
+    const uint32_t * sorted_rows;  // batch-relative row indices by code
+    const uint4 * tiles;           // {code, first position, rows, 0}
+    uint32_t n_tiles;
+    uint32_t fold_codes;           // J
     RowsOp op[kRowsMaxOps];
 };
+
+// Folding.  The ops of a program before its first ROP_NICH read only small
+// tables: for a row they depend on the row's discrete values alone.  Rows of
+// a batch range are sorted once by the joint value of those features (values
+// never change), a wave takes <= 64 rows of ONE joint value, and the score up
+// to the first remaining op comes from a per-batch table fold[code][k] built
+// with the very float operations, in the same order, that the unfolded ops
+// perform -- by scalar loads, contiguous in k, instead of one gather per
+// feature, row, group and pass.
+struct FoldSpec {
+    int n;                               // folded ops
+    uint32_t nv[kRowsMaxOps];            // table widths
+    uint32_t stride[kRowsMaxOps];        // code = sum x_f * stride_f
+    const uint32_t * values[kRowsMaxOps];
+    const float * tab[kRowsMaxOps];      // [K][nv]
+    const float * shift[kRowsMaxOps];    // ROP_CAT: shift[k]; else null
+};
+// joint value of every row of [row_begin, row_begin + n): J for a row with a
+// value outside a table (such rows are handed to the wave-per-row kernel)
+__global__ void k_fold_codes(FoldSpec F, size_t row_begin, size_t n,
+                             uint32_t J, uint32_t * __restrict__ codes,
+                             uint32_t * __restrict__ index) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t code = 0;
+    bool inside = true;
+    for (int o = 0; o < F.n; ++o) {
+        const uint32_t x = F.values[o][row_begin + i];
+        inside = inside && x < F.nv[o];
+        code += x * F.stride[o];
+    }
+    codes[i] = inside ? code : J;
+    index[i] = (uint32_t)i;
+}
+// tiles of <= 64 equal-coded positions of the sorted list, in any order
+__global__ void k_fold_tiles(const uint32_t * __restrict__ keys, size_t n,
+                             uint4 * __restrict__ tiles,
+                             uint32_t * tile_count) {
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const uint32_t key = keys[p];
+    // first position of the key's run (the keys are sorted)
+    size_t lo = 0, hi = p;
+    while (lo < hi) {
+        const size_t mid = (lo + hi) >> 1;
+        if (keys[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    if ((p - lo) % 64 != 0) return;
+    size_t a = p, b = n;   // one past the run's last position
+    while (a < b) {
+        const size_t mid = (a + b) >> 1;
+        if (keys[mid] <= key) a = mid + 1; else b = mid;
+    }
+    const uint32_t rows = (uint32_t)(a - p < 64 ? a - p : 64);
+    tiles[atomicAdd(tile_count, 1u)] =
+        make_uint4(key, (uint32_t)p, rows, 0u);
+}
+// fold[code][k]: the folded ops applied to base[k] in program order
+__global__ void k_rows_fold(FoldSpec F, const float * __restrict__ base,
+                            float * __restrict__ fold, uint32_t J, int Kpad,
+                            int K_bound, const DevState * dev) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)J * Kpad) return;
+    const int K = dev ? dev->K : K_bound;
+    const int k = (int)(i % Kpad);
+    uint32_t code = (uint32_t)(i / Kpad);
+    float s = 0.f;
+    if (k < K) {
+        s = base[k];
+        for (int o = 0; o < F.n; ++o) {
+            const uint32_t x = code / F.stride[o];
+            code -= x * F.stride[o];
+            s = s + F.tab[o][(size_t)k * F.nv[o] + x];
+            if (F.shift[o]) s = s - F.shift[o][k];   // dd.hpp:433-445
+        }
+    }
+    fold[i] = s;
+}
 
 // gtab slot layout: { base, (per op in order) ROP_CAT: shift;
 //                     ROP_NICH: c0, c1, c2, c3 }; groups beyond the group
@@ -1510,12 +1596,13 @@ __device__ __forceinline__ void rows_shape_ops(
 // the last take whatever their zeroed parameters give (the callers mask)
 template <int SHAPE, bool LDSLOG>
 __device__ __forceinline__ void rows_score_block(
-        const RowsArgs & A, const uint32_t (&xv)[kRowsXv], int k0, int g,
-        float s_own, const uint32_t * log_tab, float (&s)[kRowsBlock]) {
+        const RowsArgs & A, uniform_fp basep, const uint32_t (&xv)[kRowsXv],
+        int k0, int g, float s_own, const uint32_t * log_tab,
+        float (&s)[kRowsBlock]) {
     uniform_fp gt = as_uniform(A.gtab) + k0;
     const int W = A.Kpad;   // (the slot stride, as rows_op's GT wants it)
 #pragma unroll
-    for (int j = 0; j < kRowsBlock; ++j) s[j] = gt[j];
+    for (int j = 0; j < kRowsBlock; ++j) s[j] = basep[k0 + j];
     if constexpr (SHAPE != 0) {
         rows_shape_ops<SHAPE, 0, LDSLOG>(A, xv, gt, k0, log_tab, s);
     } else {
@@ -1545,6 +1632,7 @@ __device__ __forceinline__ void rows_score_block(
 // what a lane keeps of its row between the passes
 struct RowsRow {
     uint32_t xv[kRowsXv];
+    uint32_t code;     // the tile's joint value (folding), wave-uniform
     size_t out;        // batch-relative index (results, entropy)
     int g;             // own slot, -1 for a lane without a live row
     float s_own;
@@ -1587,9 +1675,22 @@ __global__ __launch_bounds__(kScratchMaxBlock) void k_rows_scratch(RowsArgs A) {
     const int K8 = (K + kRowsBlock - 1) & ~(kRowsBlock - 1);
     const int K16 = (K + kRowsScan - 1) & ~(kRowsScan - 1);
 
-    auto load_row = [&](size_t item, RowsRow & r) {
-        const bool in = item < A.n_items;
-        r.out = in ? item : 0;
+    // work item w: 64 consecutive rows, or (folding) a tile of the
+    // code-sorted row list
+    auto load_row = [&](size_t w, RowsRow & r) {
+        bool in;
+        r.code = 0;
+        if (A.fold) {
+            const uint4 tile = A.tiles[w];
+            r.code = (uint32_t)__builtin_amdgcn_readfirstlane((int)tile.x);
+            const uint32_t pos = tile.y, rows = tile.z;
+            in = (uint32_t)lane < rows && r.code < A.fold_codes;
+            r.out = in ? A.sorted_rows[pos + lane] : 0;
+        } else {
+            const size_t item = w * 64 + lane;
+            in = item < A.n_items;
+            r.out = in ? item : 0;
+        }
         const size_t row = A.row_begin + r.out;
         const uint32_t slot = A.slot[r.out];   // k_row_prepass
         // (a handed-over row idles along on value 0: its own values may lie
@@ -1610,11 +1711,19 @@ __global__ __launch_bounds__(kScratchMaxBlock) void k_rows_scratch(RowsArgs A) {
             }
         }
     };
+    // where a row's score starts: the driver's scores, or (folding) the
+    // folded ops' scores of the wave's joint value
+    auto base_of = [&](const RowsRow & r) -> uniform_fp {
+        if (!A.fold) return as_uniform(A.gtab);
+        const uint32_t code = r.code < A.fold_codes ? r.code : 0u;
+        return as_uniform(A.fold) + (size_t)code * A.Kpad;
+    };
     // one block of the max pass (vector_max, vector_math.cc:74-83; max is
     // order-free); groups beyond the last score -inf
     auto max_block = [&](const RowsRow & r, int k0, float & m) {
         float s[kRowsBlock];
-        rows_score_block<SHAPE, LDSLOG>(A, r.xv, k0, r.g, r.s_own, s_log, s);
+        rows_score_block<SHAPE, LDSLOG>(A, base_of(r), r.xv, k0, r.g, r.s_own,
+                                        s_log, s);
         if (k0 + kRowsBlock > K) {
 #pragma unroll
             for (int j = 0; j < kRowsBlock; ++j)
@@ -1638,8 +1747,8 @@ __global__ __launch_bounds__(kScratchMaxBlock) void k_rows_scratch(RowsArgs A) {
             s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w;
             s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w;
         } else {
-            rows_score_block<SHAPE, LDSLOG>(A, r.xv, k0, r.g, r.s_own, s_log,
-                                            s);
+            rows_score_block<SHAPE, LDSLOG>(A, base_of(r), r.xv, k0, r.g,
+                                            r.s_own, s_log, s);
         }
 #pragma unroll
         for (int j = 0; j < kRowsBlock; ++j)
@@ -1676,11 +1785,12 @@ __global__ __launch_bounds__(kScratchMaxBlock) void k_rows_scratch(RowsArgs A) {
         return lcg_unif01(xs);
     };
 
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    size_t tile = wave_slot * 64;   // first row of the wave's 64 (uniform)
-    if (tile >= A.n_items) return;
+    const size_t stride = (size_t)gridDim.x * (blockDim.x >> 6);
+    const size_t n_work = A.fold ? (size_t)A.n_tiles : (A.n_items + 63) / 64;
+    size_t tile = wave_slot;   // the wave's work item (uniform)
+    if (tile >= n_work) return;
     RowsRow cur;
-    load_row(tile + lane, cur);
+    load_row(tile, cur);
     float m = -INFINITY;
     for (int k0 = 0; k0 < K8; k0 += kRowsBlock) max_block(cur, k0, m);
     for (;;) {
@@ -1705,7 +1815,7 @@ __global__ __launch_bounds__(kScratchMaxBlock) void k_rows_scratch(RowsArgs A) {
         float t = total * draw(cur);
         int steps = 0;
         const size_t next_tile = tile + stride;
-        const bool more = next_tile < A.n_items;
+        const bool more = next_tile < n_work;
         RowsRow nxt;
         float m_next = -INFINITY;
         if (MODE == 2) {
@@ -1723,7 +1833,7 @@ __global__ __launch_bounds__(kScratchMaxBlock) void k_rows_scratch(RowsArgs A) {
             // the scan of this tile inside the max pass of the next one: a
             // run's loads are requested, two blocks are scored, then the run
             // is consumed
-            load_row(next_tile + lane, nxt);
+            load_row(next_tile, nxt);
             for (int k0 = 0; k0 < K16; k0 += kRowsScan) {
                 float l[kRowsScan];
                 load_run(k0, l);
@@ -1759,7 +1869,7 @@ __global__ __launch_bounds__(kScratchMaxBlock) void k_rows_scratch(RowsArgs A) {
             cur = nxt;
             m = m_next;
         } else {
-            load_row(tile + lane, cur);
+            load_row(tile, cur);
             m = -INFINITY;
             for (int k0 = 0; k0 < K8; k0 += kRowsBlock) max_block(cur, k0, m);
         }

@@ -100,19 +100,21 @@ def test_batch_sweeps_bit_exact(config, batch, mode):
 
 
 @pytest.mark.parametrize("config", CONFIGS + ["nich2"])
-@pytest.mark.parametrize("scratch,lds_log,block", [(0, 1, 512), (1, 1, 512),
-                                                   (1, 0, 256), (2, 1, 1024),
-                                                   (2, 0, 64), (3, 1, 512),
-                                                   (1, 1, 64)])
+@pytest.mark.parametrize("scratch,lds_log,block,fold",
+                         [(0, 1, 512, 0), (1, 1, 512, 0), (1, 0, 256, 2),
+                          (2, 1, 1024, 0), (2, 0, 64, 2), (3, 1, 512, 0),
+                          (3, 1, 256, 2), (1, 1, 64, 2)])
 @pytest.mark.parametrize("k", [31, 40])
 def test_general_rows_scratch_kernel_bit_exact(config, scratch, lds_log, block,
-                                               k):
-    """k_rows_scratch (the likelihoods of the total's pass kept for the scan;
-    mode 2: the scores of the max pass kept as well; mode 3: its loops without
-    the scratch; small workgroups give every wave several row tiles, i.e. the
-    scan of one tile inside the max pass of the next) against the oracle, on
-    every feature list, with group counts on either side of its blocks of 8
-    and 16 groups; rows_scratch = 0 is round 2's k_sweep_program."""
+                                               fold, k):
+    """k_rows_scratch against the oracle on every feature list, with group
+    counts on either side of its blocks of 8 and 16 groups.  scratch 1: the
+    likelihoods of the total's pass kept for the scan; 2: the scores of the
+    max pass kept as well; 3: its loops without the scratch; 0: round 2's
+    kernels.  Small workgroups give every wave several row tiles (mode 1: the
+    scan of one tile inside the max pass of the next).  fold 2: the leading
+    discrete features' scores from the per-(joint value, group) table, rows
+    sorted by joint value, whenever the joint domain fits the batch."""
     n = 6000
     from distributions_amd import engine
     osh, gsh, vals, assign = workloads.make(config, n, k)
@@ -123,6 +125,7 @@ def test_general_rows_scratch_kernel_bit_exact(config, scratch, lds_log, block,
     gpu.set_option("rows_scratch", scratch)
     gpu.set_option("rows_scratch_lds_log", lds_log)
     gpu.set_option("rows_scratch_block", block)
+    gpu.set_option("rows_fold", fold)
     gpu.load_rows(vals, assign, k, 1)
     seed = 4242
     st = ol.oracle().orc_rng_seed(seed)
@@ -133,6 +136,9 @@ def test_general_rows_scratch_kernel_bit_exact(config, scratch, lds_log, block,
         assert_same_state(orc, gpu, "%s sweep %d" % (config, sweep))
     counts = gpu.core.debug_counts()
     assert counts["scratch_batches"] == (4 if scratch else 0)
+    discrete_first = config not in ("nich", "nich2")
+    assert counts["fold_batches"] == (
+        4 if scratch and fold and discrete_first else 0)
 
 
 @pytest.mark.parametrize("config,dim,k", [("dd", 256, 64), ("dd_skew", 64, 16),
