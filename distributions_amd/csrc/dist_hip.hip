@@ -887,6 +887,12 @@ struct Gibbs {
     int program_all = 1;
     DeviceBuf<float> rows_scratch;          // [resident waves][Kpad][64]
     DeviceBuf<float> rows_gtab;             // [W][Kpad], see k_rows_gtab
+    DeviceBuf<float2> rows_snap;            // k_rows_scratch MODE 3
+    // 0 exact (the reference's float operations in the reference's order:
+    // bit-identical assignments; the default and the line of record);
+    // 1 scan: tolerance-level sampling (same scores, same draw per row, the
+    // softmax and its inverse CDF by parallel-friendly float arithmetic)
+    int sampling_mode = 0;
     // folding (kernels.h, FoldSpec): 0 off, 1 where the joint domain of the
     // leading discrete features leaves >= kFoldRowsPerCode rows per value
     int rows_fold_mode = 1;
@@ -1468,8 +1474,10 @@ struct Gibbs {
         const int W = next;
         if (W > kRowsMaxW) return false;
         const bool lds_log = nich && rows_scratch_lds_log != 0;
-        // 0 likelihoods in the scratch, 1 scores as well, 2 no scratch
-        const int mode = rows_scratch_mode == 2 ? 1
+        // 0 likelihoods in the scratch, 1 scores as well, 2 no scratch,
+        // 3 scan sampling (tolerance-level, option "sampling")
+        const int mode = sampling_mode == 1 ? 3
+                         : rows_scratch_mode == 2 ? 1
                          : rows_scratch_mode == 3 ? 2 : 0;
         const int block = rows_scratch_block;
         // the program's shape at compile time where an instance exists
@@ -1488,7 +1496,8 @@ struct Gibbs {
             shape_id = ID;                                                   \
             if (mode == 0) ROWS_SCRATCH_M(0, SHAPE);                         \
             else if (mode == 1) ROWS_SCRATCH_M(1, SHAPE);                    \
-            else ROWS_SCRATCH_M(2, SHAPE);                                   \
+            else if (mode == 2) ROWS_SCRATCH_M(2, SHAPE);                    \
+            else ROWS_SCRATCH_M(3, SHAPE);                                   \
         } while (0)
         if (shape == kShapeGN) ROWS_SCRATCH(1, kShapeGN);
         else if (shape == kShapeN) ROWS_SCRATCH(2, kShapeN);
@@ -1501,7 +1510,7 @@ struct Gibbs {
         int dev = 0;
         HIP_CHECK(hipGetDevice(&dev));
         // workgroups of `block` threads resident per CU, per instance
-        static std::atomic<int> per_cu[3][2][6][64];
+        static std::atomic<int> per_cu[4][2][6][64];
         std::atomic<int> & cached =
             per_cu[mode][lds_log ? 1 : 0][shape_id][dev & 63];
         int resident = cached.load(std::memory_order_relaxed);
@@ -1521,7 +1530,10 @@ struct Gibbs {
         if (limit < 1) return false;
         blocks = std::max<size_t>(1, std::min(blocks, limit));
         const size_t blocks_cap = blocks;
-        if (mode != 2) rows_scratch.reserve(blocks * per_block, 0);
+        if (mode < 2) rows_scratch.reserve(blocks * per_block, 0);
+        if (mode == 3)
+            rows_snap.reserve(blocks * (size_t)(block / 64)
+                                  * (Kpad / kRowsSuper) * 64, 0);
         rows_gtab.reserve(grow_capacity((size_t)Kpad * W), 0);
         LAUNCH(k_rows_gtab, (size_t)Kpad, P.base, src, rows_gtab.p, Kpad, K(),
                P.dev);
@@ -1554,6 +1566,7 @@ struct Gibbs {
         A.pow_lo = P.pow_lo;
         A.pow_hi = P.pow_hi;
         A.scratch = rows_scratch.p;
+        A.snap = rows_snap.p;
         blocks = std::max<size_t>(
             1, std::min(blocks_cap,
                         (n_work + block / 64 - 1) / (size_t)(block / 64)));
@@ -1604,7 +1617,8 @@ struct Gibbs {
         mark(ev0);
         LAUNCH(k_row_prepass, n, P, prog, own_score.p, deferred.p,
                deferred_count.p);
-        if (rows_scratch_mode == 0 || !launch_rows_scratch(P, prog, n)) {
+        if ((rows_scratch_mode == 0 && sampling_mode == 0)
+            || !launch_rows_scratch(P, prog, n)) {
             const unsigned blocks = (unsigned)std::min<size_t>(
                 (n + kBlock - 1) / kBlock, 256 * 16);
             hipLaunchKernelGGL(k_sweep_program, dim3(blocks), dim3(kBlock), 0,
@@ -3916,6 +3930,9 @@ int dist_gibbs_set_option(dist_gibbs_t * g, const char * name, int value) {
                              && value % 64 == 0,
                          "rows_scratch_block: a multiple of 64 up to 1024");
             g->impl->rows_scratch_block = value;
+        } else if (key == "sampling") {
+            DIST_REQUIRE(value == 0 || value == 1, "sampling: 0 exact, 1 scan");
+            g->impl->sampling_mode = value;
         } else if (key == "rows_fold") {
             // general rows: the leading discrete features' scores from a
             // per-(joint value, group) table, rows sorted by joint value

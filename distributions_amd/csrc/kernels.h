@@ -1338,6 +1338,8 @@ constexpr int kRowsMaxOps = 8;      // = kMaxF: one op per feature
 // rows of scratch a wave block is padded to (the scan reads two runs of
 // kRowsScan rows ahead)
 constexpr int kRowsScan = 16;
+// MODE 3 (scan sampling): groups per snapshot of the running (sum, max)
+constexpr int kRowsSuper = 32;
 
 enum { ROP_GATHER = 0,   // s += tab[k][x]           BB, GP, BNB
        ROP_CAT = 1,      // s = (s + tab[k][x]) - shift[k]   DD, DPD
@@ -1367,6 +1369,7 @@ struct RowsArgs {
     const uint32_t * pow_lo;
     const uint32_t * pow_hi;
     float * scratch;
+    float2 * snap;                 // MODE 3: [waves][Kpad / kRowsSuper][64]
     // folded leading ops (see FoldSpec): the wave's rows share one joint
     // value `code`, their score before the first remaining op is
     // fold[code][k]; work items are tiles of the code-sorted row list
@@ -1629,6 +1632,37 @@ __device__ __forceinline__ void rows_score_block(
     }
 }
 
+// the score of ONE group with a per-lane group index (vector loads; the same
+// float operations as rows_score_block): MODE 3's second look at the
+// kRowsSuper groups around a row's draw
+template <bool LDSLOG>
+__device__ __forceinline__ float rows_score_lane(
+        const RowsArgs & A, const float * basep, const uint32_t (&xv)[kRowsXv],
+        int k, int g, float s_own, const uint32_t * log_tab) {
+    float s = basep[k];
+#pragma unroll
+    for (int o = 0; o < kRowsMaxOps; ++o) {
+        if (o >= A.n_ops) break;
+        const RowsOp & op = A.op[o];
+        if (op.type == ROP_NICH) {
+            const float * p = A.gtab + (size_t)op.slot * A.Kpad + k;
+            const float x = u2f(xv[o]);
+            const float d = x - p[3 * (size_t)A.Kpad];
+            const float temp = 1.f + p[2 * (size_t)A.Kpad] * (d * d);
+            const float lg = LDSLOG ? fast_log_t(temp, log_tab)
+                                    : fast_log(temp);
+            s = s + (p[0] + p[(size_t)A.Kpad] * lg);
+        } else {
+            s = s + *reinterpret_cast<const float *>(
+                        reinterpret_cast<const char *>(op.tab)
+                        + (size_t)k * op.row_bytes + xv[o]);
+            if (op.type == ROP_CAT)
+                s = s - A.gtab[(size_t)op.slot * A.Kpad + k];
+        }
+    }
+    return k == g ? s_own : s;
+}
+
 // what a lane keeps of its row between the passes
 struct RowsRow {
     uint32_t xv[kRowsXv];
@@ -1646,6 +1680,18 @@ struct RowsRow {
 // MODE 1: scores kept for the total's pass as well (one evaluation, 16 B);
 // MODE 2: no scratch: the scan evaluates score and exponential again (rows
 //         whose score is cheap -- one feature -- are faster this way).
+// MODE 3: SCAN SAMPLING, tolerance-level and opt-in (option "sampling" = 1;
+//         never the default).  One pass: every score is evaluated once (the
+//         same float operations: the scores are the exact modes' bit for bit)
+//         into a running log-sum-exp -- running maximum m, running sum S of
+//         exp(s - m) rescaled whenever m grows, hardware exp2 -- with a
+//         snapshot of (S, m) every kRowsSuper groups; the row's draw u (the
+//         very engine step the exact modes use) is then located among the
+//         snapshots and only the kRowsSuper groups around it are scored
+//         again.  Same distribution as random.hpp:316-333 (first k with
+//         cumulative likelihood >= u * total), different float summation
+//         order: the index can differ from the exact modes' where u * total
+//         falls within rounding of a boundary.
 template <int MODE, bool LDSLOG, int SHAPE>
 __global__ __launch_bounds__(kScratchMaxBlock) void k_rows_scratch(RowsArgs A) {
     __shared__ uint32_t s_exp[1024];                  // biased, see above
@@ -1667,7 +1713,7 @@ __global__ __launch_bounds__(kScratchMaxBlock) void k_rows_scratch(RowsArgs A) {
         + (size_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     // this wave's block of the scratch; groups 4q .. 4q + 3 of the lane's row
     // at col[q * 64]
-    float4 * col = MODE == 2
+    float4 * col = MODE >= 2
                        ? nullptr
                        : reinterpret_cast<float4 *>(
                              A.scratch + wave_slot * (size_t)A.Kpad * 64)
@@ -1790,6 +1836,82 @@ __global__ __launch_bounds__(kScratchMaxBlock) void k_rows_scratch(RowsArgs A) {
     size_t tile = wave_slot;   // the wave's work item (uniform)
     if (tile >= n_work) return;
     RowsRow cur;
+    if constexpr (MODE == 3) {
+        constexpr float kLog2e = 1.44269504088896341f;
+        const int n_super = (K + kRowsSuper - 1) / kRowsSuper;
+        float2 * snap =
+            A.snap + wave_slot * (size_t)(A.Kpad / kRowsSuper) * 64 + lane;
+        for (; tile < n_work; tile += stride) {
+            load_row(tile, cur);
+            float m = -INFINITY, S = 0.f;
+            for (int k0 = 0; k0 < K8; k0 += kRowsBlock) {
+                float s[kRowsBlock];
+                rows_score_block<SHAPE, LDSLOG>(A, base_of(cur), cur.xv, k0,
+                                                cur.g, cur.s_own, s_log, s);
+                if (k0 + kRowsBlock > K) {
+#pragma unroll
+                    for (int j = 0; j < kRowsBlock; ++j)
+                        s[j] = k0 + j < K ? s[j] : -INFINITY;
+                }
+                float bm = s[0];
+#pragma unroll
+                for (int j = 1; j < kRowsBlock; ++j) bm = fmaxf(bm, s[j]);
+                const float m_new = fmaxf(m, bm);
+                // (the first block: m = -inf, S = 0: exp2(-inf) = 0)
+                S = S * __builtin_amdgcn_exp2f((m - m_new) * kLog2e);
+                m = m_new;
+                const float mc = -m * kLog2e;
+#pragma unroll
+                for (int j = 0; j < kRowsBlock; ++j)
+                    S += __builtin_amdgcn_exp2f(
+                        __builtin_fmaf(s[j], kLog2e, mc));
+                if (((k0 + kRowsBlock) & (kRowsSuper - 1)) == 0
+                    || k0 + kRowsBlock >= K8)
+                    snap[(size_t)(k0 / kRowsSuper) * 64] = make_float2(S, m);
+            }
+            // locate the draw among the snapshots
+            const float target = S * draw(cur);
+            int b_sel = n_super - 1;
+            float cum_before = 0.f, prev = 0.f;
+            bool found = false;
+            for (int b = 0; b < n_super; ++b) {
+                const float2 v = snap[(size_t)b * 64];
+                const float cum =
+                    v.x * __builtin_amdgcn_exp2f((v.y - m) * kLog2e);
+                if (!found && (cum >= target || b == n_super - 1)) {
+                    found = true;
+                    b_sel = b;
+                    cum_before = prev;
+                }
+                prev = cum;
+            }
+            // ... and score its kRowsSuper groups again, lane by lane
+            const float * basep = A.gtab;
+            if (A.fold)
+                basep = A.fold
+                        + (size_t)(cur.code < A.fold_codes ? cur.code : 0u)
+                              * A.Kpad;
+            const float mc = -m * kLog2e;
+            float cum = cum_before;
+            int k_sel = -1;
+            for (int j = 0; j < kRowsSuper; ++j) {
+                const int k = b_sel * kRowsSuper + j;
+                const int kc = k < K ? k : K - 1;
+                const float sc = rows_score_lane<LDSLOG>(
+                    A, basep, cur.xv, kc, cur.g, cur.s_own, s_log);
+                if (k < K)
+                    cum += __builtin_amdgcn_exp2f(
+                        __builtin_fmaf(sc, kLog2e, mc));
+                if (k_sel < 0 && k < K && cum >= target) k_sel = k;
+            }
+            if (k_sel < 0) {   // rounding left the block just short
+                const int last = b_sel * kRowsSuper + kRowsSuper - 1;
+                k_sel = last < K - 1 ? last : K - 1;
+            }
+            if (cur.live) A.new_packed[cur.out] = (uint32_t)k_sel;
+        }
+        return;
+    }
     load_row(tile, cur);
     float m = -INFINITY;
     for (int k0 = 0; k0 < K8; k0 += kRowsBlock) max_block(cur, k0, m);

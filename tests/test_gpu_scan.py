@@ -1,0 +1,89 @@
+"""Scan sampling (option "sampling" = 1): the tolerance-level, opt-in mode of
+the batched row update -- one score evaluation per (row, group), a running
+log-sum-exp, the draw located by cumulative sums.  Same scores (bit for bit)
+and the same draw per row as the exact mode; the sampled index follows the
+same distribution (random.hpp:316-333, random.cc:94-106) but is computed with
+a different float summation order, so it may differ from the exact mode's
+where u * total falls within rounding of a boundary between two groups.
+
+(i)   samples against the softmax of the scores, Pearson chi-squared as the
+      reference's own check (distributions/tests/test_random.py:183-210,
+      tests/util.py:182-203: goodness of fit > 1e-3);
+(ii)  agreement with the exact mode on the same batch (> 99.5 % asserted;
+      the measured rate is printed);
+(iii) the scores are the exact mode's, bit for bit."""
+import numpy as np
+import pytest
+from scipy import stats
+
+import workloads
+
+pytestmark = pytest.mark.gpu
+
+CONFIGS = ["gp_nich", "nich", "nich2", "dd_bb_gp", "gp", "dd", "bnb"]
+
+
+def engine_for(config, n, k, sampling, fold=1, seed=workloads.SEED,
+               extra_rows=None):
+    from distributions_amd import engine
+    osh, gsh, vals, assign = workloads.make(config, n, k, seed=seed)
+    if extra_rows is not None:
+        count, values, group = extra_rows
+        vals = [np.concatenate([v, np.full(count, x, v.dtype)])
+                for v, x in zip(vals, values)]
+        assign = np.concatenate([assign, np.full(count, group, np.uint32)])
+    gpu = engine.Gibbs(1.0, 0.2, gsh)
+    gpu.set_option("value_sorted", 0)
+    gpu.set_option("sampling", sampling)
+    gpu.set_option("rows_fold", fold)
+    gpu.load_rows(vals, assign, k, 1)
+    return gpu, vals, assign
+
+
+@pytest.mark.parametrize("config", CONFIGS)
+@pytest.mark.parametrize("k", [24, 101])
+def test_scan_agrees_with_exact_on_one_batch(config, k):
+    n = 50000
+    out = []
+    for sampling in (0, 1):
+        gpu, _, _ = engine_for(config, n, k, sampling)
+        scores = gpu.row_scores(123)
+        gpu.sweep(0, n, n, 777)          # ONE batch: one common snapshot
+        out.append((gpu.assignments().copy(), scores))
+        assert gpu.core.debug_counts()["scratch_batches"] == 1
+    (exact, s0), (scan, s1) = out
+    assert np.array_equal(s0.view(np.uint32), s1.view(np.uint32))
+    agree = float((exact == scan).mean())
+    first = np.nonzero(exact != scan)[0]
+    print("%s K=%d: scan == exact on %.4f %% of %d rows; first divergence %s"
+          % (config, k, 100 * agree, n, first[:1]))
+    assert agree > 0.995
+
+
+@pytest.mark.parametrize("config,probe", [("gp_nich", (3, 0.25)),
+                                          ("dd_bb_gp", (2, 1, 4)),
+                                          ("nich", (-0.5,))])
+@pytest.mark.parametrize("fold", [0, 2])
+def test_scan_samples_match_scores(config, probe, fold):
+    """20 000 identical probe rows in one group: in batch semantics they all
+    see the same score vector, so their new groups are draws from its
+    softmax."""
+    n, k, m = 30000, 12, 20000
+    gpu, vals, _ = engine_for(config, n, k, 1, fold=fold,
+                              extra_rows=(m, probe, 3))
+    scores = gpu.row_scores(n)           # the first probe row
+    gpu.sweep(0, n + m, n + m, 4321)
+    new = gpu.assignments()[n:]
+    # (global ids == packed ids here: one batch, no group created before it)
+    counts = np.bincount(new, minlength=len(scores))[:len(scores)]
+    assert counts.sum() == m
+    p = np.exp(scores.astype(np.float64) - scores.max())
+    p /= p.sum()
+    keep = p * m >= 5                    # chi-squared needs expected counts
+    obs = np.append(counts[keep], counts[~keep].sum())
+    exp = np.append(p[keep] * m, p[~keep].sum() * m)
+    if exp[-1] == 0:
+        obs, exp = obs[:-1], exp[:-1]
+    gof = stats.chisquare(obs, exp * obs.sum() / exp.sum()).pvalue
+    print("goodness of fit", gof)
+    assert gof > 1e-3
