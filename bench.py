@@ -49,7 +49,7 @@ METRIC = ("row-Gibbs-updates/sec (score+sample+suffstat) at N=10M, K=1024; "
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--rows", type=int, default=10_000_000,
                     help="rows per GPU")
@@ -97,6 +97,10 @@ def parse():
                     help="comma-separated sub-sweep sizes timed besides "
                          "--batch (a few steps each, reported in "
                          "`batch_variants`; empty = none)")
+    ap.add_argument("--other-configs", default="gp_nich,mixed",
+                    help="N = 1: general-row configurations timed besides "
+                         "the headline one (a few steps each, exact and scan "
+                         "sampling, reported in `other_configs`; empty = none)")
     ap.add_argument("--opt", action="append", default=[],
                     metavar="NAME=VALUE",
                     help="any other engine option (dist_gibbs_set_option), "
@@ -285,6 +289,7 @@ def cpu_baseline(args, column_host):
                                 % (cores, n_par, dt_par)},
     }
     out["c1"] = cpu_c1(args, ol)
+    out["reference_kernels"] = cpu_reference_kernels()
     # the same file built for this host's own instruction set
     try:
         subprocess.check_call(["make", "-s", "-C",
@@ -305,6 +310,57 @@ def cpu_baseline(args, column_host):
                       % (n_nat, dt2)}
     except (subprocess.CalledProcessError, OSError, AttributeError) as e:
         out["march_native"] = {"value": None, "error": str(e)[:200]}
+    return out
+
+
+def cpu_reference_kernels():
+    """The REAL reference where it compiles (oracle/_ref/libref.so: its
+    src/vector_math.cc and src/special.cc built with its release flags, see
+    oracle/Makefile): the three streaming loops a row update spends its time
+    in -- vector_add_subtract (vector_math.cc:160-168, the DirichletDiscrete
+    score), vector_max (:74-83) and vector_exp (:190-221, fmath's table exp)
+    -- at K = 1024 and K = 64, one thread.  None when the library is absent."""
+    import ctypes
+    import numpy as np
+    path = os.path.join(ROOT, "oracle", "_ref", "libref.so")
+    try:
+        L = ctypes.CDLL(path)
+    except OSError:
+        return None
+    fp = ctypes.POINTER(ctypes.c_float)
+    L.ref_vector_add_subtract.argtypes = [ctypes.c_size_t, fp, fp, fp]
+    L.ref_vector_max.argtypes = [ctypes.c_size_t, fp]
+    L.ref_vector_max.restype = ctypes.c_float
+    L.ref_vector_exp.argtypes = [ctypes.c_size_t, fp]
+    out = {}
+    rng = np.random.default_rng(1)
+    for k in (1024, 64):
+        a = rng.normal(size=k).astype(np.float32)
+        b = rng.normal(size=k).astype(np.float32)
+        io = np.zeros(k, np.float32)
+        pa, pb, pio = (x.ctypes.data_as(fp) for x in (a, b, io))
+        reps = 20000 if k == 1024 else 200000
+
+        def rate(fn):
+            fn()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            return k * reps / (time.perf_counter() - t0) / 1e6
+
+        def exp_once():
+            io[:] = a            # (keeps the argument in fmath's range)
+            L.ref_vector_exp(k, pio)
+        out["K=%d" % k] = {
+            "vector_add_subtract_elements_per_us":
+                rate(lambda: L.ref_vector_add_subtract(k, pio, pa, pb)),
+            "vector_max_elements_per_us":
+                rate(lambda: L.ref_vector_max(k, pa)),
+            "vector_exp_elements_per_us": rate(exp_once),
+        }
+    out["note"] = ("the reference's own vector_math.cc / special.cc "
+                   "(-O3 -msse4.1 -ffast-math), called through ctypes: the "
+                   "call overhead (about 1 us) is inside the K = 64 figures")
     return out
 
 
@@ -338,6 +394,11 @@ def cpu_c1(args, ol):
     return {"full_row_update_dd16_k64_rows_per_s": full,
             "reference_probe_rows_per_s": 1.83e6,
             "mixture_cc_loop_dd4_k1000_cells_per_us": loop,
+            "mixture_cc_loop_label": "UNVECTORISED port (oracle.c is built "
+                                     "-fno-fast-math, its loop stays "
+                                     "scalar); the compiled reference's "
+                                     "probe below is the figure to compare "
+                                     "a GPU number with",
             "reference_probe_cells_per_us": 9.43,
             "note": "oracle/oracle.c on one host core; the probes are the "
                     "compiled reference in the survey container (another "
@@ -441,7 +502,7 @@ def run_rank(args):
     k = args.groups
     seed_state = _core.rng_seed(args.seed)
 
-    def build_job(n, row_offset):
+    def build_job(n, row_offset, args=args):
         gen = torch.Generator(device=dev)
         gen.manual_seed(args.seed + rank)
         assign = (torch.arange(n, device=dev, dtype=torch.int64)
@@ -536,6 +597,46 @@ def run_rank(args):
             "ms_per_step": 1e3 * dt_b / steps_b, "steps": steps_b,
             "kernel": took[0] if took else "k_sweep_sample",
             "kernel_avg_launch_ms": ms_b / max(launches_b, 1)})
+
+    comm_ms, comm_count = (g.core.comm_stats() if native_comm else (0.0, 0))
+
+    # the general-row configurations (any feature list the value-sorted
+    # kernels do not take), exact and with scan sampling
+    others = []
+    if world == 1 and not args.force_collective:
+        for cfg in [c.strip() for c in args.other_configs.split(",")
+                    if c.strip()]:
+            if cfg == args.config:
+                continue
+            for sampling in (0, 1):
+                sub = argparse.Namespace(**vars(args))
+                sub.config = cfg
+                sub.opt = list(args.opt) + ["sampling=%d" % sampling]
+                if len(others) == 0:
+                    del sharded, g, columns
+                    g = sharded = columns = None
+                torch.cuda.empty_cache()
+                g2, sh2, _, _, name2 = build_job(n, 0, sub)
+                steps_o = max(1, min(args.steps, 3))
+                dt_o = timed(sh2, g2, n, args.batch, steps_o, 1, 0)
+                ms_o, launches_o, _ = g2.kernel_stats()
+                counts_o = g2.core.debug_counts()
+                others.append({
+                    "config": cfg, "workload": name2,
+                    "sampling": "scan (tolerance-level, opt-in)" if sampling
+                                else "exact",
+                    "value": float(n) * steps_o / dt_o,
+                    "unit": "row-updates/s", "steps": steps_o,
+                    "ms_per_step": 1e3 * dt_o / steps_o,
+                    "batch_rows": args.batch,
+                    "kernel": "k_rows_scratch" if counts_o["scratch_batches"]
+                              else "k_sweep_sample",
+                    "folded": bool(counts_o["fold_batches"]),
+                    "kernel_avg_launch_ms": ms_o / max(launches_o, 1)})
+                del g2, sh2
+        if others:
+            torch.cuda.empty_cache()
+            g, sharded, columns, _, _ = build_job(n, rank * n)
 
     strong = None
     if world > 1 and not args.no_strong:
@@ -666,7 +767,18 @@ def run_rank(args):
             },
             "roofline": roof,
             "batch_variants": variants,
+            "other_configs": others,
         }
+        if sharded_collective(world, args):
+            out["comm"] = {
+                "ranks": world,
+                "all_reduce_avg_us": (1e3 * comm_ms / comm_count
+                                      if comm_count else None),
+                "timed": comm_count,
+                "words_per_all_reduce": g.core.stat_words(),
+                "note": "HIP events around the library's in-place all-reduce "
+                        "of the int32 delta image, every `timed_every`-th "
+                        "sub-sweep of the timed region and the variants"}
         if strong is not None:
             out["strong_scaling"] = strong
         if column_host is not None:

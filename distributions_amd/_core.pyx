@@ -194,6 +194,7 @@ cdef extern from "distributions_hip.h" nogil:
     int dist_gibbs_global_to_packed(const dist_gibbs_t *, uint32_t, uint32_t *)
     size_t dist_gibbs_global_size(const dist_gibbs_t *)
     int dist_gibbs_debug_counts(dist_gibbs_t *, uint64_t *, size_t)
+    int dist_gibbs_comm_stats(dist_gibbs_t *, double *, uint64_t *, int)
     int dist_gibbs_sharded_device_normalise_ok(const dist_gibbs_t *, size_t,
                                                size_t, int *)
     int dist_gibbs_kernel_stats(dist_gibbs_t *, double *, uint64_t *,
@@ -215,6 +216,13 @@ cdef inline int check(int rc) except -1:
     if rc != 0:
         raise RuntimeError(dist_last_error().decode("utf-8", "replace"))
     return 0
+
+
+cdef inline object checked_size(size_t n):
+    # the size_t getters report a failure as (size_t)-1
+    if n == <size_t> -1:
+        raise RuntimeError(dist_last_error().decode("utf-8", "replace"))
+    return n
 
 
 def abi_version():
@@ -917,7 +925,7 @@ cdef class GibbsEngine:
         check(rc)
 
     def stat_words(self):
-        return dist_gibbs_stat_words(self.ptr)
+        return checked_size(dist_gibbs_stat_words(self.ptr))
 
     def export_stats_dev(self, size_t ptr):
         check(dist_gibbs_export_stats_dev(self.ptr, <int32_t *> ptr))
@@ -1013,7 +1021,7 @@ cdef class GibbsEngine:
                                         <float *> ptr, ld))
 
     def group_count(self):
-        return dist_gibbs_group_count(self.ptr)
+        return checked_size(dist_gibbs_group_count(self.ptr))
 
     def row_count(self):
         return dist_gibbs_row_count(self.ptr)
@@ -1049,7 +1057,7 @@ cdef class GibbsEngine:
         return out
 
     def global_size(self):
-        return dist_gibbs_global_size(self.ptr)
+        return checked_size(dist_gibbs_global_size(self.ptr))
 
     def sharded_device_normalise_ok(self, size_t n_batches, size_t batch_rows):
         cdef int ok = 0
@@ -1076,6 +1084,14 @@ cdef class GibbsEngine:
         cdef uint64_t a = 0, b = 0
         check(dist_gibbs_path_counts(self.ptr, &a, &b))
         return a, b
+
+    def comm_stats(self, reset=False):
+        """-> (ms, count) of the timed all-reduces of sweep_sharded"""
+        cdef double ms = 0
+        cdef uint64_t launches = 0
+        check(dist_gibbs_comm_stats(self.ptr, &ms, &launches,
+                                    1 if reset else 0))
+        return ms, launches
 
     def kernel_stats(self, reset=False):
         """-> (ms, launches, rows) of the score+sample kernel (HIP events)"""

@@ -12,6 +12,7 @@
 #include <cstring>
 #include <memory>
 #include <atomic>
+#include <chrono>
 #include <map>
 #include <mutex>
 #include <set>
@@ -984,7 +985,9 @@ struct Gibbs {
     bool async_active = false;
     // 0 never, 1 where it applies (2: the same; default)
     int device_normalise_mode = 2;
-    bool sharded_device_normalise = false;   // the ranks agreed on it
+    // dist_gibbs_sweep_sharded may normalise on the device (the ranks agree
+    // on it among themselves when a run is opened)
+    bool sharded_device_normalise = true;
     uint64_t async_batches = 0;
     std::vector<hipEvent_t> ev_pool;
 
@@ -1003,6 +1006,35 @@ struct Gibbs {
     }
     double kernel_ms = 0.0;
     uint64_t kernel_launches = 0, kernel_rows = 0;
+    // the all-reduce of dist_gibbs_sweep_sharded between two events, every
+    // kernel_timing-th sub-sweep (dist_gibbs_comm_stats)
+    double comm_ms = 0.0;
+    uint64_t comm_launches = 0, comm_tick = 0;
+    std::vector<hipEvent_t> comm_ev_free;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> comm_ev_pending;
+    hipEvent_t comm_event() {
+        if (comm_ev_free.empty()) {
+            hipEvent_t e = nullptr;
+            HIP_CHECK(hipEventCreate(&e));
+            return e;
+        }
+        hipEvent_t e = comm_ev_free.back();
+        comm_ev_free.pop_back();
+        return e;
+    }
+    // (call with the stream drained)
+    void collect_comm_timing() {
+        for (auto & pr : comm_ev_pending) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+                comm_ms += ms;
+                comm_launches += 1;
+            }
+            comm_ev_free.push_back(pr.first);
+            comm_ev_free.push_back(pr.second);
+        }
+        comm_ev_pending.clear();
+    }
 
     Gibbs(float alpha_, float d_, int F, const dist_shared_t * shareds)
         : alpha(alpha_), d(d_) {
@@ -1019,6 +1051,11 @@ struct Gibbs {
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
         for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
+        for (hipEvent_t e : comm_ev_free) (void)hipEventDestroy(e);
+        for (auto & pr : comm_ev_pending) {
+            (void)hipEventDestroy(pr.first);
+            (void)hipEventDestroy(pr.second);
+        }
         if (pinned_counts) (void)hipHostFree(pinned_counts);
         if (pinned_seq) (void)hipHostFree(pinned_seq);
         if (pinned_pairs) (void)hipHostFree(pinned_pairs);
@@ -1171,8 +1208,17 @@ struct Gibbs {
                 while (k < n && (pairs[k] >> 32) == want) ++k;
                 return k == n;
             };
-            for (long spin = 0; spin < 200000000L && !seen; ++spin)
-                seen = scan();
+            // a short poll of the pinned pairs (the publishing kernel is a
+            // few microseconds away in the usual case), then the stream: a
+            // kernel queued behind a long one or behind a collective that
+            // waits for a late peer must not cost this rank a busy core
+            const auto t_poll = std::chrono::steady_clock::now();
+            while (!seen) {
+                for (int spin = 0; spin < 256 && !seen; ++spin) seen = scan();
+                if (std::chrono::steady_clock::now() - t_poll
+                    > std::chrono::microseconds(200))
+                    break;
+            }
             if (!seen) {
                 // Not there after the bounded spin: the publishing kernel may
                 // simply be queued behind a long kernel or a collective that
@@ -1202,10 +1248,16 @@ struct Gibbs {
                            (volatile unsigned *)pinned_seq, ticket);
         HIP_CHECK(hipGetLastError());
         bool seen = false;
-        for (long spin = 0; spin < 200000000L; ++spin) {
-            if (*(volatile unsigned *)pinned_seq == ticket) { seen = true; break; }
+        const auto t_poll = std::chrono::steady_clock::now();
+        while (!seen) {
+            for (int spin = 0; spin < 256 && !seen; ++spin)
+                seen = *(volatile unsigned *)pinned_seq == ticket;
+            if (std::chrono::steady_clock::now() - t_poll
+                > std::chrono::microseconds(200))
+                break;
         }
-        // (a failed kernel never writes the ticket: surface its error)
+        // (not yet: drain the stream, which also surfaces the error of a
+        // failed kernel -- that one never writes the ticket)
         if (!seen) HIP_CHECK(hipStreamSynchronize(stream()));
         std::atomic_thread_fence(std::memory_order_acquire);
         std::copy(pinned_counts, pinned_counts + n, py.counts.begin());
@@ -1864,7 +1916,10 @@ struct Gibbs {
         // ... and where the tables are large: small ones are built in a few
         // microseconds and serve every wave from the scalar cache or LDS,
         // while a streaming tile evaluates K scores and exponentials per pass
-        if ((size_t)vs_nvals() * (size_t)K() < ((size_t)1 << 21)) return false;
+        // (the group count the run began with: K() is an inflated bound while
+        // a device-normalised run is open)
+        const size_t groups = async_active ? (size_t)async_K0 : (size_t)K();
+        if ((size_t)vs_nvals() * groups < ((size_t)1 << 21)) return false;
         return (size_t)c.n_tiles * 2 <= (size_t)c.n_values_present * 3;
     }
     struct VsStreamLaunch {
@@ -2611,6 +2666,10 @@ struct Gibbs {
     }
     // the host mirrors (group sizes, group count, id maps) from the device
     void pull_host_state() {
+        // the run is queued on the stream of the thread that swept; another
+        // thread closing it must drain THAT stream, not its own
+        if (async_stream && async_stream != stream())
+            HIP_CHECK(hipStreamSynchronize(async_stream));
         sync();
         DevState st;
         dev_state.download(&st, 1);
@@ -2645,6 +2704,12 @@ struct Gibbs {
     // allows, and async_left counts the batches still covered.
     static constexpr size_t kAsyncSweeps = 8;
     size_t async_left = 0;
+    int async_K0 = 0;                    // the group count the run began with
+    hipStream_t async_stream = nullptr;  // the stream the run is queued on
+    // a sharded run (dist_gibbs_sweep_sharded) goes on only with the tiling
+    // all ranks agreed on when it was opened
+    size_t sharded_batches = 0, sharded_batch_rows = 0;
+    DeviceBuf<int> agree_flag;
     void async_begin(size_t n_first) {
         const int K0 = K();
         size_t n_batches = kAsyncSweeps * n_first;
@@ -2688,6 +2753,8 @@ struct Gibbs {
         async_rows.clear();
         async_timed.clear();
         py.counts.resize((size_t)bound, 0);   // from here on K() is the bound
+        async_K0 = K0;
+        async_stream = stream();
         async_active = true;
         pairs_ticket = 0;
     }
@@ -2715,8 +2782,16 @@ struct Gibbs {
             try { pull_host_state(); } catch (...) {}
             return;
         }
+        try {
+            pull_host_state();   // (reads dev_state: K() is still the bound)
+        } catch (...) {
+            // the mirrors are unknown: every later call on this engine fails
+            poisoned = true;
+            async_active = false;
+            throw;
+        }
         async_active = false;
-        pull_host_state();
+        collect_comm_timing();
         for (size_t i = 0; i < async_rows.size(); ++i) {
             if (!async_rows[i] || !async_timed[i]) continue;
             float ms = 0.f;
@@ -2754,14 +2829,16 @@ struct Gibbs {
     }
     // the host's mirrors are current again (every entry point but sweep()
     // comes through here: dist_gibbs::impl)
+    bool poisoned = false;   // a run could not be closed: state unknown
     void settle() {
+        DIST_REQUIRE(!poisoned, "engine state lost: an open device-normalised "
+                                "run failed to close (see the earlier error)");
         if (async_active && !batch_open) async_end(false);
     }
     // the sharded loop (dist_gibbs_sweep_sharded): rank-local conditions; the
     // ranks must agree before they rely on it (engine.ShardedGibbs)
     bool async_eligible_sharded(size_t n_batches, size_t batch) const {
-        // (only on request: never measured on more than one GPU)
-        if (device_normalise_mode != 1 || cluster != 0 || F() != 1) return false;
+        if (device_normalise_mode == 0 || cluster != 0 || F() != 1) return false;
         if (!n_batches || any_float_stats() || py.n_empty < 1) return false;
         for (size_t b = 0; b < n_batches; ++b) {
             const size_t r0 = std::min(n_rows, b * batch);
@@ -2910,12 +2987,14 @@ struct GibbsRef {
     std::unique_ptr<Gibbs> p;
     // (a failure while pulling is recorded like any entry point's, and the
     // call that follows meets the same broken device)
+    // (every entry point dereferences inside its own guarded(): a failure
+    // while closing an open run is that call's failure, not a later one's)
     Gibbs * operator->() const {
-        (void)guarded([&] { p->settle(); });
+        p->settle();
         return p.get();
     }
     Gibbs & operator*() const {
-        (void)guarded([&] { p->settle(); });
+        p->settle();
         return *p;
     }
     Gibbs * open() const { return p.get(); }
@@ -3594,8 +3673,12 @@ int dist_gibbs_load_rows_dev(dist_gibbs_t * g, size_t n_rows,
                       nonempty, empty, row_offset);
     });
 }
+// (the size_t getters have no status channel: (size_t)-1 reports a failure,
+// with its message in dist_last_error)
 size_t dist_gibbs_stat_words(const dist_gibbs_t * g) {
-    return g->impl->stat_words();
+    size_t n = (size_t)-1;
+    (void)guarded([&] { n = g->impl->stat_words(); });
+    return n;
 }
 int dist_gibbs_export_stats_dev(const dist_gibbs_t * g, int32_t * stats_dev) {
     return guarded([&] { g->impl->copy_stats(stats_dev, true); sync(); });
@@ -3706,19 +3789,44 @@ int dist_gibbs_sweep_sharded(dist_gibbs_t * g, dist_comm_t * c,
                              size_t n_batches, size_t batch_rows,
                              uint32_t seed_state, uint64_t draw_base) {
     return guarded([&] {
-        Gibbs & e = *g->impl;
         DIST_REQUIRE(c && c->comm, "no communicator");
         DIST_REQUIRE(batch_rows > 0, "batch_rows must be positive");
-        DIST_REQUIRE(!e.any_float_stats(),
+        DIST_REQUIRE(!g->impl.open()->any_float_stats(),
                      "order-dependent statistics are exchanged as rows "
                      "(dist_gibbs_batch_moves_dev / replay_ordered_dev)");
-        // the ranks agreed that every one of them can run this pass with the
-        // group set normalised on the device (engine.ShardedGibbs): no host
-        // round trip per batch on any of them
-        const bool on_device = e.sharded_device_normalise
-                               && e.async_eligible_sharded(n_batches,
-                                                           batch_rows);
-        if (on_device) e.async_begin(n_batches);
+        // The group set is normalised on the device -- no host round trip per
+        // sub-sweep on any rank -- when EVERY rank can (one all-reduce of a
+        // flag when a run is opened: the layout of the delta image depends
+        // on it).  Like the single-engine sweep, the run then stays open
+        // across passes of the same tiling; any other call settles it.
+        Gibbs * open = g->impl.open();
+        bool on_device = false;
+        if (open->async_active && !open->batch_open
+            && open->sharded_batches == n_batches
+            && open->sharded_batch_rows == batch_rows
+            && n_batches <= open->async_left) {
+            on_device = true;   // the open run goes on
+        } else {
+            Gibbs & s = *g->impl;   // (settles an open run)
+            int mine = s.sharded_device_normalise
+                       && s.async_eligible_sharded(n_batches, batch_rows)
+                           ? 1 : 0;
+            s.agree_flag.reserve(1, 0);
+            HIP_CHECK(hipMemcpyAsync(s.agree_flag.p, &mine, sizeof(int),
+                                     hipMemcpyHostToDevice, stream()));
+            RCCL_CHECK(rccl().all_reduce(s.agree_flag.p, s.agree_flag.p, 1,
+                                         ncclInt32, ncclMin, c->comm,
+                                         stream()));
+            s.agree_flag.download(&mine, 1);
+            on_device = mine != 0;
+            if (on_device) {
+                s.async_begin(n_batches);
+                s.sharded_batches = n_batches;
+                s.sharded_batch_rows = batch_rows;
+            }
+        }
+        Gibbs & e = *open;
+        if (on_device) e.async_left -= std::min(e.async_left, n_batches);
         try {
             for (size_t b = 0; b < n_batches; ++b) {
                 const size_t r0 = std::min(e.n_rows, b * batch_rows);
@@ -3735,9 +3843,22 @@ int dist_gibbs_sweep_sharded(dist_gibbs_t * g, dist_comm_t * c,
                 }
                 e.batch_delta(e.delta_image.p, true);
                 // in place, on the engine's stream: no hop to another stream
+                const bool timed = e.kernel_timing > 0
+                                   && e.comm_tick++ % (uint64_t)e.kernel_timing
+                                          == 0;
+                hipEvent_t t0 = nullptr, t1 = nullptr;
+                if (timed) {
+                    t0 = e.comm_event();
+                    t1 = e.comm_event();
+                    HIP_CHECK(hipEventRecord(t0, stream()));
+                }
                 RCCL_CHECK(rccl().all_reduce(e.delta_image.p, e.delta_image.p,
                                              words, ncclInt32, ncclSum,
                                              c->comm, stream()));
+                if (timed) {
+                    HIP_CHECK(hipEventRecord(t1, stream()));
+                    e.comm_ev_pending.emplace_back(t0, t1);
+                }
                 e.batch_apply_delta(e.delta_image.p, true);
                 if (on_device) e.batch_finish_device();
                 else e.batch_finish();
@@ -3746,8 +3867,11 @@ int dist_gibbs_sweep_sharded(dist_gibbs_t * g, dist_comm_t * c,
             if (on_device) e.async_end(true);
             throw;
         }
-        if (on_device) e.async_end(false);
-        sync();
+        if (!on_device) {
+            sync();
+            e.collect_comm_timing();
+        }
+        // (an on-device run stays open: Gibbs::settle)
     });
 }
 
@@ -3814,7 +3938,9 @@ int dist_gibbs_score_rows_dev(dist_gibbs_t * g, size_t row_begin,
     });
 }
 size_t dist_gibbs_group_count(const dist_gibbs_t * g) {
-    return (size_t)g->impl->K();
+    size_t n = (size_t)-1;
+    (void)guarded([&] { n = (size_t)g->impl->K(); });
+    return n;
 }
 size_t dist_gibbs_row_count(const dist_gibbs_t * g) {
     return g->impl.open()->n_rows;
@@ -3855,7 +3981,9 @@ int dist_gibbs_global_to_packed(const dist_gibbs_t * g, uint32_t global,
     return guarded([&] { *out = g->impl->tracker.global_to_packed(global); });
 }
 size_t dist_gibbs_global_size(const dist_gibbs_t * g) {
-    return g->impl->tracker.g2p.size();
+    size_t n = (size_t)-1;
+    (void)guarded([&] { n = g->impl->tracker.g2p.size(); });
+    return n;
 }
 int dist_gibbs_sharded_device_normalise_ok(const dist_gibbs_t * g,
                                            size_t n_batches,
@@ -3874,6 +4002,8 @@ int dist_gibbs_set_option(dist_gibbs_t * g, const char * name, int value) {
             // the table-free value-sorted kernel: 0 never, 1 auto, 2 always
             DIST_REQUIRE(value >= 0 && value <= 2, "value_stream: 0, 1 or 2");
             g->impl->value_stream_mode = value;
+            // (cached ranges chose their apply chunks by it)
+            g->impl->drop_overlapping_caches(0, g->impl->n_rows, false);
         } else if (key == "narrow_tiles") {
             // k_vs_narrow for launches that cannot fill the chip: 0 never,
             // 1 auto, 2 whenever the vectors fit its LDS
@@ -3981,6 +4111,19 @@ int dist_gibbs_debug_counts(dist_gibbs_t * g, uint64_t * out, size_t n) {
             v[5] = d;
         }
         for (size_t i = 0; i < n && i < 11; ++i) out[i] = v[i];
+    });
+}
+int dist_gibbs_comm_stats(dist_gibbs_t * g, double * ms_out,
+                          uint64_t * launches_out, int reset) {
+    return guarded([&] {
+        Gibbs & e = *g->impl;   // (settles an open run: its events are read)
+        e.collect_comm_timing();
+        if (ms_out) *ms_out = e.comm_ms;
+        if (launches_out) *launches_out = e.comm_launches;
+        if (reset) {
+            e.comm_ms = 0.0;
+            e.comm_launches = 0;
+        }
     });
 }
 int dist_gibbs_kernel_stats(dist_gibbs_t * g, double * ms_out,

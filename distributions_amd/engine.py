@@ -160,7 +160,6 @@ class ShardedGibbs(object):
         self._delta = None
         self._comm = None
         self._n_batches = {}    # batch_rows -> sub-sweeps per pass (all ranks)
-        self._device_normalise = {}   # batch_rows -> all ranks can (0 / 1)
         self.ordered = self.collective and backend.ordered_features() > 0
         self.columns = columns
         self.assign_packed = assign_packed
@@ -310,16 +309,8 @@ class ShardedGibbs(object):
                 self._n_batches[batch_rows] = int(nb.item())
             n_batches = self._n_batches[batch_rows]
         if self._comm is not None:
-            if batch_rows not in self._device_normalise:
-                # every rank or none: the delta image's layout depends on it
-                ok = torch.tensor(
-                    [1 if self.backend.sharded_device_normalise_ok(
-                        n_batches, batch_rows) else 0],
-                    dtype=torch.int32, device=self.device)
-                self._all_reduce(ok, op=self.dist.ReduceOp.MIN)
-                self._device_normalise[batch_rows] = int(ok.item())
-            self.backend.set_option("sharded_device_normalise",
-                                    self._device_normalise[batch_rows])
+            # (the library's loop; whether the group set is normalised on the
+            # device is agreed among the ranks inside it, when a run opens)
             self.backend.sweep_sharded(self._comm, n_batches, batch_rows,
                                        seed_state, draw_base)
             return

@@ -12,7 +12,7 @@ using namespace distributions_hip;
 
 int main() {
     typedef DirichletDiscrete<> Model;
-    rng_t rng = dist_rng_seed(1);
+    rng_t rng(1);
 
     Model::Shared shared;
     shared.dim = 4;

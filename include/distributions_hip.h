@@ -299,7 +299,7 @@ int dist_gibbs_load_rows_dev(dist_gibbs_t * g, size_t n_rows,
                              int empty_groups, uint64_t row_offset);
 /* multi-GPU: the statistics were built from local rows only; add the other
  * shards' (dist_gibbs_stat_words() int32 words, all-reduced by the caller) */
-size_t dist_gibbs_stat_words(const dist_gibbs_t * g);
+size_t dist_gibbs_stat_words(const dist_gibbs_t * g);   /* (size_t)-1: failed, see dist_last_error */
 int dist_gibbs_export_stats_dev(const dist_gibbs_t * g, int32_t * stats_dev);
 int dist_gibbs_import_stats_dev(dist_gibbs_t * g, const int32_t * stats_dev);
 
@@ -410,14 +410,39 @@ int dist_gibbs_sharded_device_normalise_ok(const dist_gibbs_t * g,
  * "kernel_timing" = n: HIP events around the score+sample kernel of every
  * n-th batch feed dist_gibbs_kernel_stats (1, the default: every batch; 0:
  * none; two events cost a batch some 8 us);
- * "device_normalise" = 1 (default): sweeps that stay on the value-sorted
- * path with integer statistics normalise the group set on the device and run
- * without a host round trip per batch; such a run stays open when
- * dist_gibbs_sweep returns (the next sweep goes on with it, any other call
- * pulls the host's mirrors first), so dist_gibbs_sweep returns before the
- * device has finished; 0: never; "sharded_device_normalise" = the same for
- * dist_gibbs_sweep_sharded, to be set on every rank or on none.
- * None changes a result. */
+ * "device_normalise" = 1 or 2 (the same; 2 is the default): sweeps that stay
+ * on the value-sorted path with integer statistics normalise the group set on
+ * the device and run without a host round trip per batch; such a run stays
+ * open when dist_gibbs_sweep / dist_gibbs_sweep_sharded return (the next
+ * sweep of the same tiling goes on with it, any other call pulls the host's
+ * mirrors first), so they return before the device has finished.  An open run
+ * is queued on the stream of the thread that swept; a call from another
+ * thread drains that stream before it reads the state.  0: never.
+ * "sharded_device_normalise" = 1 (default) lets dist_gibbs_sweep_sharded do
+ * the same: the ranks agree among themselves (one all-reduce of a flag when a
+ * run is opened) whether every one of them can; 0 keeps this rank, and so
+ * all of them, on the host-normalised loop;
+ * "rows_scratch" (general rows: any feature list the value-sorted kernels do
+ * not take) = 3 (default: k_rows_scratch's loops, every pass scores again),
+ * 1 (the likelihoods of the total's pass stay in an HBM scratch column for
+ * the scan), 2 (the scores of the max pass as well), 0 (round 2's kernels);
+ * "rows_scratch_lds_log" = 1 (default: FastLog's table in LDS) or 0;
+ * "rows_scratch_block" = threads per workgroup of that kernel (512);
+ * "rows_fold" = 1 (default: the discrete features before the first
+ * real-valued one are folded into a per-(joint value, group) table and the
+ * rows sorted by joint value, where at least 128 rows share a value),
+ * 2 (whenever the joint domain is no larger than the batch), 0 (never);
+ * "program_all" = 1 (default: every batch outside the value-sorted path is
+ * scored through the per-batch score program) or 0.
+ * None of the above changes a result.
+ * "sampling" = 0 (default, the line of record: the reference's float
+ * operations in the reference's order, bit-identical assignments) or 1: SCAN
+ * SAMPLING, tolerance-level -- the same scores bit for bit and the same engine
+ * step per row, but the softmax and its inverse CDF by a running log-sum-exp
+ * and cumulative sums (random.hpp:316-333 in distribution; the index can
+ * differ from the exact mode's where u * total falls within float rounding of
+ * a boundary between two groups).
+ */
 int dist_gibbs_set_option(dist_gibbs_t * g, const char * name, int value);
 /* how many batches each score+sample kernel has served */
 int dist_gibbs_path_counts(const dist_gibbs_t * g, uint64_t * value_sorted,
@@ -428,8 +453,13 @@ int dist_gibbs_path_counts(const dist_gibbs_t * g, uint64_t * value_sorted,
  * last value-sorted launch, rows that launch handed to the wave-per-row
  * kernel, value-sorted batches that took the table-free kernel, batches
  * whose group set the device normalised itself, value-sorted batches that
- * took the small-launch kernel (first min(n, 9) entries are written) */
+ * took the small-launch kernel, batches through k_rows_scratch, batches with
+ * folded leading features (first min(n, 11) entries are written) */
 int dist_gibbs_debug_counts(dist_gibbs_t * g, uint64_t * out, size_t n);
+/* HIP-event time (ms) and count of the all-reduces dist_gibbs_sweep_sharded
+ * timed (every "kernel_timing"-th sub-sweep) since the last reset */
+int dist_gibbs_comm_stats(dist_gibbs_t * g, double * ms_out,
+                          uint64_t * launches_out, int reset);
 /* HIP-event time (ms) and launch count of the score+sample kernel since the
  * last reset, measured on the engine's stream */
 int dist_gibbs_kernel_stats(dist_gibbs_t * g, double * ms_out,

@@ -32,16 +32,23 @@ namespace distributions_hip {
 // default-constructed engine is seeded with 1 like the reference's; it also
 // satisfies UniformRandomBitGenerator, so <random> distributions drawing from
 // it give what they give over std::minstd_rand0.
+// `rng_t rng(seed)` SEEDS the engine, as std::default_random_engine(seed) does
+// (the seed reduced mod 2^31 - 1, 0 mapped to 1); a raw engine state -- what
+// dist_rng_seed / dist_rng_jump return -- goes through rng_t::from_state().
 struct rng_t {
     typedef uint32_t result_type;
     uint32_t state;
     rng_t() : state(1u) {}
-    rng_t(uint32_t engine_state) : state(engine_state) {}   // dist_rng_seed
+    explicit rng_t(uint32_t seed_value) : state(dist_rng_seed(seed_value)) {}
+    static rng_t from_state(uint32_t engine_state) {
+        rng_t r;
+        r.state = engine_state;
+        return r;
+    }
     void seed(uint32_t value) { state = dist_rng_seed(value); }
     static constexpr result_type min() { return 1u; }
     static constexpr result_type max() { return 2147483646u; }
     result_type operator()() { return dist_rng_next(&state); }
-    operator uint32_t() const { return state; }
 };
 
 inline void check(int rc) {

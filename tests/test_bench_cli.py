@@ -57,6 +57,29 @@ def test_small_single_gpu_run_prints_one_json_line():
     assert roof["bound"] in ("valu", "hbm") and roof["avg_launch_ms"] > 0
     if roof["frac"] is not None:
         assert 0.0 < roof["frac"] <= 1.0
+    # the general-row configurations, exact and with scan sampling
+    got = [(o["config"], o["sampling"].split()[0]) for o in out["other_configs"]]
+    assert got == [("gp_nich", "exact"), ("gp_nich", "scan"),
+                   ("mixed", "exact"), ("mixed", "scan")]
+    assert all(o["value"] > 0 and o["kernel"] == "k_rows_scratch"
+               for o in out["other_configs"])
+    assert out["cpu_baseline"]["reference_kernels"] is None or (
+        out["cpu_baseline"]["reference_kernels"]["K=1024"]
+        ["vector_exp_elements_per_us"] > 0)
+
+
+@pytest.mark.gpu
+def test_one_rank_collective_path_reports_its_all_reduce():
+    r = run(["--rows", "400000", "--batch", "100000", "--steps", "3",
+             "--warmup", "1", "--cpu-rows", "0", "--other-batches", "",
+             "--force-collective", "--kernel-timing", "2"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([x for x in r.stdout.splitlines()
+                      if x.startswith("{")][-1])
+    assert out["config"]["comm_ranks"] == 1
+    assert out["config"]["collectives"] == "library RCCL communicator"
+    assert out["comm"]["timed"] >= 1 and out["comm"]["all_reduce_avg_us"] > 0
+    assert "normalised on the device" in out["config"]["group_set"]
 
 
 @pytest.mark.gpu

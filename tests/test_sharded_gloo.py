@@ -19,28 +19,45 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 N, K, BATCH, SWEEPS, SEED = 2400, 12, 300, 2, 4242
+# BASELINE config 4's shape (SURVEY 8d "C4"): PitmanYor(alpha=1, d=0.2), one
+# DirichletDiscrete(256) feature, 8 ranks, sub-sweeps of 65 536 rows per rank
+# -- at a reduced N (two sub-sweeps per rank and pass)
+C4 = dict(N=8 * 131072, K=48, BATCH=8 * 65536, SWEEPS=1, world=8)
+
+
+def shape(config):
+    if config == "c4":
+        return C4["N"], C4["K"], C4["BATCH"], C4["SWEEPS"]
+    return N, K, BATCH, SWEEPS
 
 
 def make_rows(config):
     """-> (list of value columns, packed assignment)"""
+    n, k, _, _ = shape(config)
     rng = np.random.default_rng(7)
-    assign = (np.arange(N) % K).astype(np.uint32)
+    assign = (np.arange(n) % k).astype(np.uint32)
     if config == "dd":
-        return [rng.integers(0, 8, N).astype(np.uint32)], assign
+        return [rng.integers(0, 8, n).astype(np.uint32)], assign
+    if config == "c4":
+        return [rng.integers(0, 256, n).astype(np.uint32)], assign
     # order-dependent statistics: GammaPoisson (log_prod) + NormalInverseChiSq
-    return [rng.poisson(5.0, N).astype(np.uint32),
-            rng.normal(0.0, 1.0, N).astype(np.float32)], assign
+    return [rng.poisson(5.0, n).astype(np.uint32),
+            rng.normal(0.0, 1.0, n).astype(np.float32)], assign
 
 
 def make_mix(config, values, assign, lo, hi):
     import oracle_lib as ol
+    k = shape(config)[1]
     if config == "dd":
         sh = [ol.make_shared(ol.DD, alphas=[0.5] * 8)]
+    elif config == "c4":
+        sh = [ol.make_shared(ol.DD, alphas=[0.5] * 256)]
     else:
         sh = [ol.make_shared(ol.GP, alpha=1.0, inv_beta=1.0),
               ol.make_shared(ol.NICH, mu=0.0, kappa=1.0, sigmasq=1.0, nu=1.0)]
-    m = ol.OracleMixture(3.0, 0.3, sh)
-    m.init_from_assignments([v[lo:hi] for v in values], assign[lo:hi], K, 2)
+    m = (ol.OracleMixture(1.0, 0.2, sh) if config == "c4"
+         else ol.OracleMixture(3.0, 0.3, sh))
+    m.init_from_assignments([v[lo:hi] for v in values], assign[lo:hi], k, 2)
     return m
 
 
@@ -56,6 +73,7 @@ def worker(rank, world, port, out, config):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import oracle_lib as ol
     from distributions_amd import engine
+    N, K, BATCH, SWEEPS = shape(config)
     values, assign = make_rows(config)
     lo, hi = rank * N // world, (rank + 1) * N // world
     m = make_mix(config, values, assign, lo, hi)
@@ -83,18 +101,22 @@ def free_port():
     return port
 
 
-@pytest.mark.parametrize("config", ["dd", "gp_nich"])
-def test_two_ranks_equal_one_rank_with_the_same_batches(tmp_path, config):
+@pytest.mark.parametrize("config,world", [("dd", 2), ("gp_nich", 2),
+                                          ("c4", C4["world"])])
+def test_ranks_equal_one_rank_with_the_same_batches(tmp_path, config, world):
+    """world_size 2 (both exchanges: integer deltas, ordered rows) and
+    world_size 8 in BASELINE config 4's shape."""
     import oracle_lib as ol
-    world = 2
+    N, K, BATCH, SWEEPS = shape(config)
     mp.spawn(worker, args=(world, free_port(), str(tmp_path), config),
              nprocs=world, join=True)
     got = np.concatenate([np.load(tmp_path / ("assign_%d.npy" % r))
                           for r in range(world)])
     counts = [np.load(tmp_path / ("counts_%d.npy" % r)) for r in range(world)]
     groups = [np.load(tmp_path / ("groups_%d.npy" % r)) for r in range(world)]
-    assert np.array_equal(counts[0], counts[1])   # replicas agree
-    assert np.array_equal(groups[0], groups[1])   # ... bit for bit
+    for r in range(1, world):
+        assert np.array_equal(counts[0], counts[r])   # replicas agree
+        assert np.array_equal(groups[0], groups[r])   # ... bit for bit
 
     # single process, same batch composition: batch b = the union over ranks
     # of local rows [b*B/2, (b+1)*B/2) of each shard
