@@ -1992,8 +1992,65 @@ struct Gibbs {
         }
     }
 
+    // scan sampling on the value-sorted path (kernels.h, k_vs_scan_*)
+    struct VsScanLaunch {
+        Gibbs * self;
+        SweepParams * P;
+        VsCache * c;
+        VsScanTables T;
+        template <int KIND>
+        void go() {
+            const size_t n = P->row_end - P->row_begin;
+            self->mark(self->ev0);
+            hipLaunchKernelGGL((k_vs_scan_prepare<KIND>), dim3(T.n_values),
+                               dim3(kVsScanBlock),
+                               T.lds_scores ? (size_t)T.Kpad * 4 : 0,
+                               stream(), *P, T, self->deferred_count.p,
+                               c->n_other);
+            hipLaunchKernelGGL((k_vs_scan_rows<KIND>), grid_for(n),
+                               dim3(kBlock), 0, stream(), *P, T,
+                               c->sorted_rows.p, n, self->deferred.p,
+                               self->deferred_count.p);
+            HIP_CHECK(hipGetLastError());
+            self->mark(self->ev1);
+        }
+    };
+    uint64_t scan_batches = 0;
+    void sample_value_scan(SweepParams & P, VsCache & c) {
+        const size_t n = P.row_end - P.row_begin;
+        const uint32_t nv = (uint32_t)vs_nvals();
+        const int Kpad = (K() + kVsScanCoarse - 1) / kVsScanCoarse
+                         * kVsScanCoarse;
+        vsLA.reserve(grow_capacity((size_t)nv * Kpad), 0);
+        vsPA.reserve(grow_capacity((size_t)nv * (Kpad / kVsScanCoarse)), 0);
+        vsM.reserve(nv, 0);
+        vsmB.reserve(nv, 0);
+        deferred.reserve(std::max<size_t>(n, 1), 0);
+        deferred_count.reserve(1, 0);
+        prepare(P, false);
+        if (c.n_other)
+            HIP_CHECK(hipMemcpyAsync(deferred.p, c.other_pos.p,
+                                     4 * (size_t)c.n_other,
+                                     hipMemcpyDeviceToDevice, stream()));
+        P.sorted_rows = c.sorted_rows.p;
+        P.assign_pos = c.assign_pos.p;
+        VsScanLaunch L{this, &P, &c,
+                       VsScanTables{vsLA.p, vsPA.p, vsM.p, vsmB.p, Kpad, nv,
+                                    (size_t)Kpad * 4 <= 48 * 1024 ? 1 : 0}};
+        switch (feats[0]->sh.kind) {
+        case DIST_DD: L.go<DIST_DD>(); break;
+        case DIST_DPD: L.go<DIST_DPD>(); break;
+        case DIST_GP: L.go<DIST_GP>(); break;
+        case DIST_BNB: L.go<DIST_BNB>(); break;
+        default: L.go<DIST_BB>(); break;
+        }
+        scan_batches += 1;
+        launch_deferred(P);
+    }
+
     void sample_value_sorted(SweepParams & P) {
         VsCache & c = vs_get(P.row_begin, P.row_end);
+        if (sampling_mode == 1) return sample_value_scan(P, c);
         if (use_stream(c)) return sample_value_stream(P, c);
         const size_t n = P.row_end - P.row_begin;
         const uint32_t nv = (uint32_t)vs_nvals();
@@ -4094,10 +4151,10 @@ int dist_gibbs_path_counts(const dist_gibbs_t * g, uint64_t * value_sorted,
 int dist_gibbs_debug_counts(dist_gibbs_t * g, uint64_t * out, size_t n) {
     return guarded([&] {
         Gibbs & e = *g->impl;
-        uint64_t v[11] = {e.vs_batches, e.generic_batches, e.band_batches,
+        uint64_t v[12] = {e.vs_batches, e.generic_batches, e.band_batches,
                           e.prefix_batches, 0, 0, e.stream_batches,
                           e.async_batches, e.narrow_batches,
-                          e.scratch_batches, e.fold_batches};
+                          e.scratch_batches, e.fold_batches, e.scan_batches};
         if (e.last_bands && !e.batch_open && e.vsBandMode.p) {
             // values whose arg-max group's rows had a tile of their own in
             // the last value-sorted launch
@@ -4110,7 +4167,7 @@ int dist_gibbs_debug_counts(dist_gibbs_t * g, uint64_t * out, size_t n) {
             e.deferred_count.download(&d, 1);
             v[5] = d;
         }
-        for (size_t i = 0; i < n && i < 11; ++i) out[i] = v[i];
+        for (size_t i = 0; i < n && i < 12; ++i) out[i] = v[i];
     });
 }
 int dist_gibbs_comm_stats(dist_gibbs_t * g, double * ms_out,

@@ -2902,6 +2902,187 @@ void k_vs_sample(
 }
 
 // ---------------------------------------------------------------------------
+// Scan sampling on the value-sorted path (option "sampling" = 1: opt-in,
+// tolerance-level; the exact kernels above stay the line of record).
+//
+// Rows with the same value x share their score vector except in their own
+// slot, so the softmax and its cumulative sums are a property of the VALUE:
+// k_vs_scan_prepare computes, per value, the scores (the exact kernels' float
+// operations: bit-identical scores), their maximum M[x], the likelihoods
+// exp2((s - M) log2 e) and their inclusive prefix sums C[x][k] by a parallel
+// scan.  A row then needs its own slot's two likelihoods -- with the row
+// removed (l_own) and as tabulated (l_g) -- and a binary search for the first
+// k with  C[x][k] + (k >= g ? l_own - l_g : 0)  >=  u * (C[x][K-1] + l_own -
+// l_g): about log2 K dependent loads per row instead of 2 K dependent adds
+// (random.hpp:316-333 in distribution; the same engine step per row).
+// What a sub-sweep then costs is the table pass -- V x K entries read and
+// written once, the HBM stream SURVEY 8d prices for C5 -- and the launches
+// around it.  Rows alone in their group are handed to the wave-per-row kernel
+// as on the exact path.
+struct VsScanTables {
+    float * C;        // [nvals][Kpad] inclusive prefix sums of the likelihoods
+    float * coarse;   // [nvals][Kpad / kVsScanCoarse]: C[x][64 j + 63]
+    float * M;        // [nvals] maxima
+    float * total;    // [nvals] C[x][K - 1]
+    int Kpad;         // a multiple of kVsScanCoarse
+    uint32_t n_values;
+    int lds_scores;
+};
+constexpr int kVsScanBlock = 256;
+constexpr int kVsScanCoarse = 64;
+
+template <int KIND>
+__global__ __launch_bounds__(kVsScanBlock) void k_vs_scan_prepare(
+        SweepParams P, VsScanTables T, uint32_t * deferred_count,
+        uint32_t deferred_initial) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *deferred_count = deferred_initial;
+    __shared__ float r_m[kVsScanBlock / 64];
+    __shared__ float r_sum[kVsScanBlock / 64];
+    __shared__ float sh_M, sh_carry;
+    extern __shared__ float s_scores[];   // [Kpad] when T.lds_scores
+    constexpr float kLog2e = 1.44269504088896341f;
+    const uint32_t x = blockIdx.x;
+    SlaveView v = P.feat[0];
+    v.kind = KIND;
+    const int K = sweep_K(P);
+    const float lf = KIND == DIST_GP ? fast_log_factorial(x) : 0.f;
+    float * c = T.C + (size_t)x * T.Kpad;
+    // the scores wait for pass 2 in LDS (or, too many for it, in the prefix
+    // row itself: one more trip of the row through memory)
+    float * sc = T.lds_scores ? s_scores : c;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // pass 1: scores and their maximum
+    float m = -INFINITY;
+    {   // (four groups per thread in flight: the pass is a stream of loads)
+        int k = threadIdx.x;
+        for (; k + 3 * kVsScanBlock < K; k += 4 * kVsScanBlock) {
+            Entry e[4];
+            float b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                e[i] = load_entry(v, k + i * kVsScanBlock, x);
+                b[i] = P.base[k + i * kVsScanBlock];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float s = accumulate(KIND, b[i], e[i], x, lf, v.p);
+                sc[k + i * kVsScanBlock] = s;
+                m = fmaxf(m, s);
+            }
+        }
+        for (; k < K; k += kVsScanBlock) {
+            const float s =
+                accumulate(KIND, P.base[k], load_entry(v, k, x), x, lf, v.p);
+            sc[k] = s;
+            m = fmaxf(m, s);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if (lane == 0) r_m[wave] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float mm = r_m[0];
+        for (int w = 1; w < kVsScanBlock / 64; ++w) mm = fmaxf(mm, r_m[w]);
+        sh_M = mm;
+        sh_carry = 0.f;
+        T.M[x] = mm;
+    }
+    __syncthreads();
+    const float mc = -sh_M * kLog2e;
+    // pass 2: likelihoods and their inclusive prefix sums, kVsScanBlock x 4
+    // entries a round (each thread four consecutive ones), the rounds chained
+    // through sh_carry
+    for (int k0 = 0; k0 < T.Kpad; k0 += 4 * kVsScanBlock) {
+        const int k = k0 + 4 * threadIdx.x;
+        float l[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            l[i] = k + i < K ? __builtin_amdgcn_exp2f(
+                                   __builtin_fmaf(sc[k + i], kLog2e, mc))
+                             : 0.f;
+        l[1] += l[0]; l[2] += l[1]; l[3] += l[2];
+        // inclusive scan of the threads' sums over the wave, then the waves
+        float run = l[3];
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const float up = __shfl_up(run, off);
+            if (lane >= off) run += up;
+        }
+        if (lane == 63) r_sum[wave] = run;
+        __syncthreads();
+        float before = sh_carry;
+        for (int w = 0; w < wave; ++w) before += r_sum[w];
+        before += run - l[3];   // the wave's threads before this one
+        if (k < T.Kpad) {   // (Kpad is a multiple of four: whole float4s)
+            *reinterpret_cast<float4 *>(c + k) = make_float4(
+                before + l[0], before + l[1], before + l[2], before + l[3]);
+            // every kVsScanCoarse-th prefix again, close together: the rows'
+            // search starts there
+            if ((k & (kVsScanCoarse - 1)) == kVsScanCoarse - 4)
+                T.coarse[(size_t)x * (T.Kpad / kVsScanCoarse)
+                         + k / kVsScanCoarse] = before + l[3];
+        }
+        __syncthreads();
+        if (threadIdx.x == kVsScanBlock - 1) sh_carry = before + l[3];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) T.total[x] = sh_carry;
+}
+
+// one thread per position of the value-sorted row list
+template <int KIND>
+__global__ __launch_bounds__(kBlock) void k_vs_scan_rows(
+        SweepParams P, VsScanTables T,
+        const uint32_t * __restrict__ sorted_rows, size_t n,
+        uint32_t * __restrict__ deferred, uint32_t * deferred_count) {
+    const size_t at = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (at >= n) return;
+    constexpr float kLog2e = 1.44269504088896341f;
+    const size_t row = P.row_begin + sorted_rows[at];
+    const uint32_t x = P.values[0][row];
+    if (x >= T.n_values) return;   // (beyond the table: listed by the host)
+    SlaveView v = P.feat[0];
+    v.kind = KIND;
+    const int K = sweep_K(P);
+    const int g = P.g2p[P.assign_pos[at]];
+    const int n_g = P.counts[g];
+    if (n_g == 1) {   // the group would vanish: the wave-per-row kernel
+        deferred[atomicAdd(deferred_count, 1u)] = (uint32_t)at;
+        return;
+    }
+    const float lf = KIND == DIST_GP ? fast_log_factorial(x) : 0.f;
+    const float s_own = vs_own_score(P, v, g, n_g, x, lf, P.scalars->shift);
+    const float s_g =
+        accumulate(KIND, P.base[g], load_entry(v, g, x), x, lf, v.p);
+    const float mc = -T.M[x] * kLog2e;
+    const float delta =
+        __builtin_amdgcn_exp2f(__builtin_fmaf(s_own, kLog2e, mc))
+        - __builtin_amdgcn_exp2f(__builtin_fmaf(s_g, kLog2e, mc));
+    const float target = (T.total[x] + delta) * batch_row_unif01(P, row);
+    // first among the block ends C[x][64 j + 63] (a few cache lines per
+    // value, shared by its rows), then inside the block found
+    const float * coarse = T.coarse + (size_t)x * (T.Kpad / kVsScanCoarse);
+    int lo = 0, hi = (K - 1) / kVsScanCoarse;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        const int k = mid * kVsScanCoarse + kVsScanCoarse - 1;
+        const float cum = coarse[mid] + (k >= g ? delta : 0.f);
+        if (cum >= target) hi = mid; else lo = mid + 1;
+    }
+    const float * c = T.C + (size_t)x * T.Kpad;
+    hi = min(K - 1, lo * kVsScanCoarse + kVsScanCoarse - 1);
+    lo = lo * kVsScanCoarse;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        const float cum = c[mid] + (mid >= g ? delta : 0.f);
+        if (cum >= target) hi = mid; else lo = mid + 1;
+    }
+    P.old_packed[at] = (uint32_t)g;
+    P.new_packed[at] = (uint32_t)lo;
+}
+
+// ---------------------------------------------------------------------------
 // k_vs_narrow: the value-sorted row update for launches that cannot fill the
 // chip (sub-sweeps of some 10^4..10^5 rows).  There a tile's wave is alone on
 // its SIMD, and what the launch takes is ONE wave's latency: every scalar load

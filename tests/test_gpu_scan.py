@@ -24,7 +24,7 @@ CONFIGS = ["gp_nich", "nich", "nich2", "dd_bb_gp", "gp", "dd", "bnb"]
 
 
 def engine_for(config, n, k, sampling, fold=1, seed=workloads.SEED,
-               extra_rows=None):
+               extra_rows=None, value_sorted=0):
     from distributions_amd import engine
     osh, gsh, vals, assign = workloads.make(config, n, k, seed=seed)
     if extra_rows is not None:
@@ -33,7 +33,7 @@ def engine_for(config, n, k, sampling, fold=1, seed=workloads.SEED,
                 for v, x in zip(vals, values)]
         assign = np.concatenate([assign, np.full(count, group, np.uint32)])
     gpu = engine.Gibbs(1.0, 0.2, gsh)
-    gpu.set_option("value_sorted", 0)
+    gpu.set_option("value_sorted", value_sorted)
     gpu.set_option("sampling", sampling)
     gpu.set_option("rows_fold", fold)
     gpu.load_rows(vals, assign, k, 1)
@@ -87,3 +87,75 @@ def test_scan_samples_match_scores(config, probe, fold):
     gof = stats.chisquare(obs, exp * obs.sum() / exp.sum()).pvalue
     print("goodness of fit", gof)
     assert gof > 1e-3
+
+
+VS_CONFIGS = ["dd", "dd_skew", "bb", "gp", "dpd", "dpd_other", "bnb"]
+
+
+@pytest.mark.parametrize("config", VS_CONFIGS)
+@pytest.mark.parametrize("k", [24, 101, 1000])
+def test_value_sorted_scan_agrees_with_exact_on_one_batch(config, k):
+    """the value-sorted path's scan sampling (per-value prefix sums, a binary
+    search per row) against its exact kernels"""
+    n = 60000
+    out = []
+    for sampling in (0, 1):
+        gpu, _, _ = engine_for(config, n, k, sampling, value_sorted=2)
+        gpu.sweep(0, n, n, 777)
+        out.append(gpu.assignments().copy())
+        assert gpu.core.debug_counts()["scan_batches"] == sampling
+    exact, scan = out
+    agree = float((exact == scan).mean())
+    first = np.nonzero(exact != scan)[0]
+    print("%s K=%d: value-sorted scan == exact on %.4f %% of %d rows; first "
+          "divergence %s" % (config, k, 100 * agree, n, first[:1]))
+    assert agree > 0.995
+
+
+@pytest.mark.parametrize("config,probe", [("dd", (5,)), ("gp", (7,)),
+                                          ("bb", (1,))])
+def test_value_sorted_scan_samples_match_scores(config, probe):
+    n, k, m = 30000, 12, 20000
+    gpu, _, _ = engine_for(config, n, k, 1, extra_rows=(m, probe, 3),
+                           value_sorted=2)
+    scores = gpu.row_scores(n)
+    gpu.sweep(0, n + m, n + m, 4321)
+    assert gpu.core.debug_counts()["scan_batches"] == 1
+    new = gpu.assignments()[n:]
+    counts = np.bincount(new, minlength=len(scores))[:len(scores)]
+    assert counts.sum() == m
+    p = np.exp(scores.astype(np.float64) - scores.max())
+    p /= p.sum()
+    keep = p * m >= 5
+    obs = np.append(counts[keep], counts[~keep].sum())
+    exp = np.append(p[keep] * m, p[~keep].sum() * m)
+    if exp[-1] == 0:
+        obs, exp = obs[:-1], exp[:-1]
+    gof = stats.chisquare(obs, exp * obs.sum() / exp.sum()).pvalue
+    print("goodness of fit", gof)
+    assert gof > 1e-3
+
+
+def test_value_sorted_scan_many_sweeps_keep_the_state_consistent():
+    """statistics stay those of the assignments (the apply kernels are the
+    exact path's), groups are created and removed, through device-normalised
+    runs"""
+    n, k = 40000, 200
+    gpu, vals, _ = engine_for("dd", n, k, 1, value_sorted=2)
+    for sweep in range(6):
+        gpu.sweep(0, n, 8000, 99, draw_base=sweep * n)
+    assign = gpu.assignments()
+    counts = gpu.counts()
+    packed = np.array([gpu.core.global_to_packed(int(a)) for a in
+                       np.unique(assign)])
+    sizes = np.bincount([gpu.core.global_to_packed(int(a)) for a in assign],
+                        minlength=len(counts))
+    assert np.array_equal(sizes, counts)
+    assert packed.max() < len(counts)
+    # the categorical counts of a group are those of its rows
+    g0 = gpu.core.global_to_packed(int(assign[0]))
+    members = np.array([gpu.core.global_to_packed(int(a)) for a in assign]) == g0
+    words = gpu.get_group(0, g0)
+    assert words[0] == members.sum()
+    assert np.array_equal(words[1:17],
+                          np.bincount(vals[0][members], minlength=16))
