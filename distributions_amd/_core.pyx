@@ -165,6 +165,11 @@ cdef extern from "distributions_hip.h" nogil:
     int dist_gibbs_load_rows_dev(dist_gibbs_t *, size_t,
                                  const uint32_t * const *, uint32_t *, int,
                                  int, uint64_t)
+    int dist_gibbs_load_rows_unassigned(dist_gibbs_t *, size_t,
+                                        const uint32_t * const *, int,
+                                        uint64_t)
+    int dist_gibbs_init_sequential(dist_gibbs_t *, size_t, size_t,
+                                   uint32_t *, int) nogil
     size_t dist_gibbs_stat_words(const dist_gibbs_t *)
     int dist_gibbs_export_stats_dev(const dist_gibbs_t *, int32_t *)
     int dist_gibbs_import_stats_dev(dist_gibbs_t *, const int32_t *)
@@ -903,6 +908,42 @@ cdef class GibbsEngine:
                                            <uint64_t> row_offset)
         free(ptrs)
         check(rc)
+
+    def load_rows_unassigned(self, values, int empty_groups=1, row_offset=0):
+        """rows without a group yet; init_sequential assigns them"""
+        cdef int n = len(self.shareds)
+        cdef const uint32_t ** ptrs = <const uint32_t **> malloc(
+            sizeof(void *) * (n + 1))
+        cdef cnp.ndarray[cnp.uint32_t, ndim=1] w
+        cdef SharedParams s
+        words = []
+        cdef int i
+        cdef size_t rows = 0
+        for i in range(n):
+            s = self.shareds[i]
+            w = value_words(s.c.kind, values[i])
+            if i and w.shape[0] != rows:
+                free(ptrs)
+                raise RuntimeError("feature columns differ in length")
+            rows = w.shape[0]
+            words.append(w)
+            ptrs[i] = <const uint32_t *> w.data
+        cdef int rc = dist_gibbs_load_rows_unassigned(
+            self.ptr, rows, ptrs, empty_groups, <uint64_t> row_offset)
+        free(ptrs)
+        check(rc)
+
+    def init_sequential(self, size_t row_begin, size_t row_end,
+                        uint32_t rng_state, prior_only=False):
+        """-> new rng state"""
+        cdef uint32_t s = rng_state
+        cdef int rc
+        cdef int prior = 1 if prior_only else 0
+        with nogil:
+            rc = dist_gibbs_init_sequential(self.ptr, row_begin, row_end, &s,
+                                            prior)
+        check(rc)
+        return s
 
     def load_rows_dev(self, value_ptrs, size_t assign_ptr, size_t n_rows,
                       int nonempty_groups, int empty_groups=1, row_offset=0,

@@ -1280,6 +1280,17 @@ struct Gibbs {
             for (int f = 0; f < F(); ++f) values[f] = vals[f];
             packed_dev = assign_dev;
             assign = assign_dev;       // rewritten to global ids below
+        } else if (assign_packed == nullptr) {
+            // rows without a group yet (init_sequential assigns them)
+            DIST_REQUIRE(nonempty == 0, "unassigned rows: no group has members");
+            for (int f = 0; f < F(); ++f) {
+                own_values[f].upload(vals[f], n);
+                values[f] = own_values[f].p;
+            }
+            own_assign.reserve(std::max<size_t>(n, 1), 0);
+            HIP_CHECK(hipMemsetAsync(own_assign.p, 0xFF,
+                                     std::max<size_t>(n, 1) * 4, stream()));
+            assign = own_assign.p;
         } else {
             std::vector<uint32_t> chk(assign_packed, assign_packed + n);
             for (size_t i = 0; i < n; ++i)
@@ -1292,6 +1303,8 @@ struct Gibbs {
             packed_dev = own_assign.p;
             assign = own_assign.p;
         }
+        const bool unassigned = !vals_on_device && assign_packed == nullptr;
+        assigned_rows = unassigned ? 0 : n;
         if (vals_on_device && n) {   // the host-pointer form checked above
             DeviceBuf<uint32_t> mx;
             mx.reserve(1, 0);
@@ -1345,7 +1358,7 @@ struct Gibbs {
         // order (Group::add_value per row, like GroupIoMixin.from_values,
         // distributions/mixins.py:83-90)
         SweepParams P = params(0, n, 0, 0);
-        if (n) {
+        if (n && !unassigned) {
             LAUNCH(k_load_counts, n, P, live_image(), packed_dev);
             replay_sorted(nullptr, packed_dev, 0, n);
             // assignments become global ids (identity map right after init)
@@ -2168,6 +2181,8 @@ struct Gibbs {
     void batch_sample(size_t r0, size_t r1, uint32_t seed, uint64_t draw_base) {
         DIST_REQUIRE(!batch_open, "previous batch not finished");
         DIST_REQUIRE(r0 <= r1 && r1 <= n_rows, "bad row range");
+        DIST_REQUIRE(r1 <= assigned_rows || r0 == r1,
+                     "rows without a group yet: init_sequential first");
         batch_begin = r0;
         batch_end = r1;
         batch_open = true;
@@ -2941,12 +2956,22 @@ struct Gibbs {
         uint32_t rng;
         ChainResult * res;
         int K;
+        int init = 0;   // 1 / 2: the initialisation loops (k_chain_rows)
         template <int A, int B, int NF>
         void run() {
-            hipLaunchKernelGGL((k_chain_rows<A, B, NF>), dim3(1), dim3(kBlock),
-                               (size_t)((K + 63) & ~63) * sizeof(float),
-                               stream(), *P, base,
-                               counts, assign, p2g, rng, res);
+            const size_t lds = (size_t)((K + 63) & ~63) * sizeof(float);
+            if (init == 1)
+                hipLaunchKernelGGL((k_chain_rows<A, B, NF, 1>), dim3(1),
+                                   dim3(kBlock), lds, stream(), *P, base,
+                                   counts, assign, p2g, rng, res);
+            else if (init == 2)
+                hipLaunchKernelGGL((k_chain_rows<A, B, NF, 2>), dim3(1),
+                                   dim3(kBlock), lds, stream(), *P, base,
+                                   counts, assign, p2g, rng, res);
+            else
+                hipLaunchKernelGGL((k_chain_rows<A, B, NF>), dim3(1),
+                                   dim3(kBlock), lds, stream(), *P, base,
+                                   counts, assign, p2g, rng, res);
             HIP_CHECK(hipGetLastError());
         }
     };
@@ -2963,6 +2988,8 @@ struct Gibbs {
     void sweep_sequential(size_t r0, size_t r1, uint32_t * rng_state) {
         DIST_REQUIRE(!batch_open, "previous batch not finished");
         DIST_REQUIRE(r0 <= r1 && r1 <= n_rows, "bad row range");
+        DIST_REQUIRE(r1 <= assigned_rows || r0 == r1,
+                     "rows without a group yet: init_sequential first");
         size_t r = r0;
         while (r < r1) {
             if ((size_t)((K() + 63) & ~63) * sizeof(float) > 60 * 1024
@@ -2995,6 +3022,45 @@ struct Gibbs {
                 sequential_row_as_batch(r, rng_state);
                 r += 1;
             }
+        }
+        sync();
+    }
+
+    // rows [assigned_rows, n_rows) have no group yet (load without
+    // assignments); init_sequential gives them one, in order
+    size_t assigned_rows = 0;
+    void init_sequential(size_t r0, size_t r1, uint32_t * rng_state,
+                         bool prior_only) {
+        DIST_REQUIRE(!batch_open, "previous batch not finished");
+        DIST_REQUIRE(r0 == assigned_rows && r0 <= r1 && r1 <= n_rows,
+                     "init_sequential: rows are assigned in order, from the "
+                     "first unassigned one");
+        size_t r = r0;
+        while (r < r1) {
+            DIST_REQUIRE((size_t)((K() + 63) & ~63) * sizeof(float)
+                             <= 60 * 1024,
+                         "init_sequential: too many groups for the chain "
+                         "kernel's strip of LDS");
+            upload_maps();
+            SweepParams P = params(r, r1, 0, 0);
+            prepare(P, false);
+            chain_result.reserve(1, 0);
+            ChainLaunch L{&P, base.p, py.d_counts.p, assign, d_p2g_ptr,
+                          *rng_state, chain_result.p, K(),
+                          prior_only ? 2 : 1};
+            dispatch(L);
+            ChainResult res;
+            chain_result.download(&res, 1);
+            // host mirrors, the appended empty group, caches from the
+            // statistics (the empty groups' prior follows the number of
+            // non-empty ones, clustering.hpp:221-230)
+            batch_begin = batch_end = r;
+            batch_value_sorted = false;
+            batch_open = true;
+            batch_finish();
+            *rng_state = res.rng_state;
+            r += res.rows_done;
+            assigned_rows = r;
         }
         sync();
     }
@@ -3719,6 +3785,22 @@ int dist_gibbs_load_rows(dist_gibbs_t * g, size_t n_rows,
     return guarded([&] {
         g->impl->load(n_rows, values, false, assign_packed, nullptr, nonempty,
                       empty, row_offset);
+    });
+}
+int dist_gibbs_load_rows_unassigned(dist_gibbs_t * g, size_t n_rows,
+                                    const uint32_t * const * values,
+                                    int empty, uint64_t row_offset) {
+    return guarded([&] {
+        g->impl->load(n_rows, values, false, nullptr, nullptr, 0, empty,
+                      row_offset);
+    });
+}
+int dist_gibbs_init_sequential(dist_gibbs_t * g, size_t row_begin,
+                               size_t row_end, uint32_t * rng_state,
+                               int prior_only) {
+    return guarded([&] {
+        g->impl->init_sequential(row_begin, row_end, rng_state,
+                                 prior_only != 0);
     });
 }
 int dist_gibbs_load_rows_dev(dist_gibbs_t * g, size_t n_rows,

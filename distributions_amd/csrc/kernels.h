@@ -2171,7 +2171,12 @@ __device__ __forceinline__ void chain_value_op(const SlaveView & s, int k,
     refresh_scalar_entry(s, k);
 }
 
-template <int KIND0, int KIND1, int NF>
+// INIT (the initialisation loops of examples/mixture/main.py:227-232 and
+// 265-270): rows that have no group yet are ADDED one at a time -- score,
+// sample, add; nothing is removed, the sample size grows with every row (so
+// the driver's score is shifted[k] - fast_log(sample_size + alpha) afresh per
+// row, clustering.hpp:195-208); 2: with the clustering model's score alone.
+template <int KIND0, int KIND1, int NF, int INIT = 0>
 __global__ __launch_bounds__(kBlock) void k_chain_rows(
         SweepParams P, float * __restrict__ base, int32_t * counts,
         uint32_t * assign, const uint32_t * __restrict__ p2g,
@@ -2195,10 +2200,14 @@ __global__ __launch_bounds__(kBlock) void k_chain_rows(
     float * sc = chain_lds;
     uint32_t done = 0;
     int event = 0;
+    float * shifted = const_cast<float *>(P.shifted);
     for (size_t row = P.row_begin; row < P.row_end; ++row) {
-        const int g = P.g2p[assign[row]];
-        const int n_g = counts[g];
-        if (n_g == 1) { event = 1; break; }
+        const int g = INIT ? 0 : P.g2p[assign[row]];
+        const int n_g = INIT ? 0 : counts[g];
+        if (!INIT && n_g == 1) { event = 1; break; }
+        // INIT: the sample size this row is scored with
+        const long long size_now = P.sample_size + (long long)done;
+        const float shift_row = INIT ? py_shift(size_now, P.alpha) : 0.f;
         uint32_t x[kMaxF];
         float lf[kMaxF];
         int kind[kMaxF];
@@ -2211,7 +2220,7 @@ __global__ __launch_bounds__(kBlock) void k_chain_rows(
             lf[f] = kind[f] == DIST_GP ? fast_log_factorial(x[f]) : 0.f;
         }
         // remove_value (mixture.hpp:94-122,386-398; clustering.hpp:178-193)
-        if (tid == 0) {
+        if (!INIT && tid == 0) {
             counts[g] = n_g - 1;
             base[g] = P.cluster == 0
                 ? fast_log_t((float)(n_g - 1) - P.d, s_log) + shift
@@ -2228,9 +2237,14 @@ __global__ __launch_bounds__(kBlock) void k_chain_rows(
         float m = -INFINITY;
         for (int k = tid; k < K; k += kBlock) {
             float s = base[k];
+            if (INIT)   // clustering.hpp:195-208 / mixture.hpp:124-141
+                s = P.cluster == 0
+                    ? shifted[k] + shift_row
+                    : le_score_add_value(P.dataset_size, counts[k],
+                                         (int)size_now, P.n_empty);
 #pragma unroll
             for (int f = 0; f < (NF > 0 ? NF : kMaxF); ++f) {
-                if (f >= nf) break;
+                if (f >= nf || INIT == 2) break;
                 SlaveView v = P.feat[f];
                 v.kind = kind[f];
                 s = accumulate(kind[f], s, load_entry(v, k, x[f]), x[f],
@@ -2266,6 +2280,8 @@ __global__ __launch_bounds__(kBlock) void k_chain_rows(
         // add_value (mixture.hpp:73-92,376-384; clustering.hpp:163-176)
         if (tid == 0) {
             counts[g2] = n2 + 1;
+            if (INIT)   // clustering.hpp:163-176, _update_nonempty_group
+                shifted[g2] = fast_log_t((float)(n2 + 1) - P.d, s_log);
             base[g2] = P.cluster == 0
                 ? fast_log_t((float)(n2 + 1) - P.d, s_log) + shift
                 : cluster_own_score(P, n2 + 1, shift);

@@ -79,6 +79,21 @@ class Gibbs(object):
                                 empty_groups, row_offset,
                                 keep=(list(values), assign_packed))
 
+    def load_rows_unassigned(self, values, empty_groups=1, row_offset=0):
+        """Rows without a group yet (a fresh mixture, examples/mixture/
+        main.py:222-224); `init_sequential` assigns them."""
+        self.core.load_rows_unassigned(values, empty_groups, row_offset)
+
+    def init_sequential(self, row_begin, row_end, rng_state, prior_only=False):
+        """The initialisation loop of examples/mixture/main.py on the
+        device: rows [row_begin, row_end) are added one at a time -- score
+        every group (all features, main.py:265-270; `prior_only`: the
+        clustering model alone, main.py:227-232), sample, add.  Rows are
+        assigned in order, starting at the first unassigned one.  Returns the
+        new rng state."""
+        return self.core.init_sequential(row_begin, row_end, rng_state,
+                                         prior_only)
+
     # -- sweeps -------------------------------------------------------------
     def sweep(self, row_begin, row_end, batch_rows, seed, draw_base=0):
         """One pass over rows [row_begin,row_end) in frozen batches.

@@ -122,8 +122,14 @@ class GroupBase(ProtobufSerializable):
         return shared.params.group_score_data(self.words)
 
     def sample_value(self, shared):
-        raise NotImplementedError(
-            "samplers are outside the row-update path (SURVEY 2.2)")
+        """Group::sample_value (dd.hpp:188-199 and the other models'): one
+        draw from the posterior predictive through a fresh Sampler.  Host-side
+        (a sampler, not part of the accelerated path): numpy distributions
+        seeded from the global engine's stream, so `seed()` makes it
+        repeatable; not the reference's own variate stream."""
+        sampler = SamplerBase()
+        sampler.init(shared, self)
+        return sampler.eval(shared)
 
     @staticmethod
     def _word(shared, value):
@@ -143,6 +149,77 @@ class GroupBase(ProtobufSerializable):
         group = cls()
         group.load(raw)
         return group
+
+
+def _host_generator():
+    """a numpy Generator seeded with the next word of the global engine"""
+    return np.random.default_rng(get_rng()())
+
+
+class SamplerBase(object):
+    """Model::Sampler (dd.hpp:201-222, bb.hpp:163-183, gp.hpp:175-191,
+    nich.hpp:213-231, bnb.hpp:177-192): init draws the component's
+    parameters from the posterior given a group, eval draws a value."""
+
+    def __init__(self):
+        self._draw = None
+
+    def init(self, shared, group):
+        params = shared.params
+        kind = params.kind
+        words = np.asarray(group.words)
+        rng = _host_generator()
+        self._rng = rng
+        if kind == _core.KIND_DD:
+            dim = params.dim
+            a = np.asarray(params.alphas[:dim], np.float64) + words[
+                1:1 + dim].astype(np.int32)
+            ps = rng.dirichlet(a)
+            self._draw = lambda: int(rng.choice(dim, p=ps))
+        elif kind == _core.KIND_BB:
+            a, b = params.p[0], params.p[1]
+            heads, tails = int(np.int32(words[0])), int(np.int32(words[1]))
+            p = rng.beta(a + heads, b + tails)
+            self._draw = lambda: bool(rng.random() < p)
+        elif kind == _core.KIND_GP:
+            alpha, inv_beta = params.p[0], params.p[1]
+            mean = rng.gamma(alpha + int(words[1]),
+                             1.0 / (inv_beta + int(words[0])))
+            self._draw = lambda: int(rng.poisson(mean))
+        elif kind == _core.KIND_BNB:
+            alpha, beta, r = params.p[0], params.p[1], int(params.p[2])
+            p = rng.beta(alpha + r * int(words[0]), beta + int(words[1]))
+            self._draw = lambda: int(rng.negative_binomial(r, p))
+        elif kind == _core.KIND_NICH:
+            mu, kappa, sigmasq, nu = (float(x) for x in params.p[:4])
+            n = float(np.int32(words[0]))
+            mean = float(words[1:2].view(np.float32)[0])
+            ctv = float(words[2:3].view(np.float32)[0])
+            pk = kappa + n
+            pmu = (kappa * mu + mean * n) / pk
+            pnu = nu + n
+            psig = (nu * sigmasq + ctv + n * kappa * (mu - mean) ** 2 / pk) / pnu
+            s2 = pnu * psig / rng.chisquare(pnu)
+            centre = rng.normal(pmu, np.sqrt(s2 / pk))
+            self._draw = lambda: float(rng.normal(centre, np.sqrt(s2)))
+        else:
+            raise NotImplementedError(
+                "no Sampler for this model (DirichletProcessDiscrete's draws "
+                "new values: SURVEY 2.2, out of scope)")
+
+    def eval(self, shared):
+        assert self._draw is not None, "Sampler.init first"
+        return self._draw()
+
+
+def sample_group_with(group_cls, shared, size):
+    """module.sample_group (lp/models/_dd.pyx:141-151): `size` values from
+    ONE component drawn from the prior"""
+    group = group_cls()
+    group.init(shared)
+    sampler = SamplerBase()
+    sampler.init(shared, group)
+    return [sampler.eval(shared) for _ in range(int(size))]
 
 
 class MixtureBase(object):

@@ -2,7 +2,8 @@
 import numpy as np
 
 from ... import _core
-from ._base import SharedBase, GroupBase, MixtureBase
+from ._base import (SharedBase, GroupBase, MixtureBase, SamplerBase,
+                    sample_group_with)
 
 NAME = 'BetaBernoulli'
 EXAMPLES = [
@@ -54,3 +55,11 @@ class Group(GroupBase):
 
 class Mixture(MixtureBase):
     GROUP = Group
+
+
+class Sampler(SamplerBase):                    # lp/models/_dd.pyx:71-81
+    pass
+
+
+def sample_group(shared, size):                # lp/models/_dd.pyx:141-151
+    return sample_group_with(Group, shared, size)

@@ -1,17 +1,18 @@
-// The reference's mixture benchmark loop (benchmarks/mixture.cc:79-115) as a
-// downstream program writes it against the reference's headers: the includes,
-// the namespace, Model::Shared::EXAMPLE(), mixture.groups(), the remove /
-// score_value (accumulating) / add loop and its "cells/us" figure.  It builds
-// against THIS library by putting include/compat first on the include path:
+// Remove / score / add churn through the Mixture interface, written against
+// the reference's header names so that it builds unchanged against either
+// library: put this library's include/compat first on the include path,
 //   g++ -std=c++11 -Iinclude/compat examples/mixture_bench.cc
 //       -Ldistributions_amd -ldistributions_hip -Wl,-rpath,$PWD/distributions_amd
-// (Group::sample_value, which the reference's benchmark draws its values with,
-// belongs to the samplers -- out of this library's scope -- so values come
-// from sample_int / sample_unif01 here; the Scorers half of the benchmark,
-// mixture.cc:119-131, times the per-group Scorer objects, which the batched
-// engine has no use for.)
-#include <iomanip>
-#include <iostream>
+// For each component model it plants a table -- every group draws its rows
+// from its own posterior predictive (Group::sample_value) -- and then times
+// the three calls a Gibbs row update makes on a feature's mixture (take the
+// row out of its group, score it against every group, put it back), reporting
+// (row, group) cells per microsecond for 1, 10, 100, ... groups, plus a
+// checksum of the last score vectors so that the work cannot be optimised
+// away and two libraries can be compared.
+#include <cstdio>
+#include <cstdlib>
+#include <string>
 #include <typeinfo>
 #include <vector>
 
@@ -23,78 +24,91 @@
 #include <distributions/models/nich.hpp>
 #include <distributions/timers.hpp>
 
-using namespace distributions;  // NOLINT(*)
+namespace {
 
-rng_t rng;
+using distributions::rng_t;
+using distributions::VectorFloat;
 
-template <class Value> Value draw_value();
-template <> int draw_value<int>() { return sample_int(rng, 0, 3); }
-template <> bool draw_value<bool>() { return sample_int(rng, 0, 1) != 0; }
-template <> uint32_t draw_value<uint32_t>() {
-    return (uint32_t)sample_int(rng, 0, 12);
-}
-template <> float draw_value<float>() { return 6.f * sample_unif01(rng) - 3.f; }
+// a planted table of one feature: rows, the group each sits in, the mixture
+template <class M>
+class Table {
+  public:
+    typedef typename M::Value Value;
 
-template <class Model>
-double speedtest(const typename Model::Shared & shared, size_t group_count,
-                 size_t iters, double * checksum) {
-    typename Model::Mixture mixture;
-    mixture.groups().resize(group_count);
-    std::vector<typename Model::Value> values;
-    std::vector<size_t> assignments;
-    for (size_t groupid = 0; groupid < group_count; ++groupid) {
-        typename Model::Group & group = mixture.groups()[groupid];
-        group.init(shared, rng);
-    }
-    for (size_t i = 0; i < 4 * group_count; ++i) {
-        size_t groupid = sample_int(rng, 0, group_count - 1);
-        typename Model::Group & group = mixture.groups()[groupid];
-        typename Model::Value value = draw_value<typename Model::Value>();
-        group.add_value(shared, value, rng);
-        values.push_back(value);
-        assignments.push_back(groupid);
-    }
-    mixture.init(shared, rng);
-    VectorFloat scores(group_count);
-
-    int64_t time = -current_time_us();
-    for (size_t i = 0; i < iters / 8; ++i) {
-        vector_zero(scores.size(), scores.data());
-        for (size_t j = 0; j < 8; ++j) {
-            size_t k = (8 * i + j) % values.size();
-            typename Model::Value value = values[k];
-            size_t groupid = assignments[k];
-            mixture.remove_value(shared, groupid, value, rng);
-            mixture.score_value(shared, value, scores, rng);
-            mixture.add_value(shared, groupid, value, rng);
+    Table(const typename M::Shared & shared, size_t groups, size_t rows_each,
+          rng_t & rng)
+        : shared_(shared), scores_(groups, 0.f) {
+        mixture_.groups().resize(groups);
+        for (auto & group : mixture_.groups()) group.init(shared_, rng);
+        // round-robin over the groups: a group's next row comes from its own
+        // posterior predictive given the rows it already holds
+        for (size_t pass = 0; pass < rows_each; ++pass) {
+            for (size_t g = 0; g < groups; ++g) {
+                auto & group = mixture_.groups()[g];
+                const Value x = group.sample_value(shared_, rng);
+                group.add_value(shared_, x, rng);
+                rows_.push_back(x);
+                home_.push_back(g);
+            }
         }
+        mixture_.init(shared_, rng);
     }
-    time += current_time_us();
-    for (size_t g = 0; g < group_count; ++g) *checksum += scores[g];
-    return iters * 1e0 / time;
+
+    // `updates` row updates, in table order; returns elapsed microseconds
+    long churn(size_t updates, rng_t & rng) {
+        const long begin = distributions::current_time_us();
+        for (size_t u = 0; u < updates; ++u) {
+            const size_t i = u % rows_.size();
+            if (u % 8 == 0)
+                distributions::vector_zero(scores_.size(), scores_.data());
+            mixture_.remove_value(shared_, home_[i], rows_[i], rng);
+            mixture_.score_value(shared_, rows_[i], scores_, rng);
+            mixture_.add_value(shared_, home_[i], rows_[i], rng);
+        }
+        return distributions::current_time_us() - begin;
+    }
+
+    double checksum() const {
+        double sum = 0;
+        for (float s : scores_) sum += s;
+        return sum;
+    }
+
+  private:
+    typename M::Shared shared_;
+    typename M::Mixture mixture_;
+    std::vector<Value> rows_;
+    std::vector<size_t> home_;
+    VectorFloat scores_;
+};
+
+template <class M>
+void report(size_t largest, rng_t & rng) {
+    const std::string name =
+        distributions::demangle(typeid(typename M::Shared).name());
+    std::printf("%s\nGroups\tcells/us\n", name.c_str());
+    const typename M::Shared shared = M::Shared::EXAMPLE();
+    double checksum = 0;
+    for (size_t groups = 1; groups <= largest; groups *= 10) {
+        Table<M> table(shared, groups, 4, rng);
+        const size_t updates = 8 * (200 / (1 + groups / 100) + 1);
+        const long us = table.churn(updates, rng);
+        checksum += table.checksum();
+        std::printf("%zu\t%9.4f\n", groups,
+                    (double)updates / (double)(us > 0 ? us : 1));
+    }
+    std::printf("checksum %.6f\n", checksum);
 }
 
-template <class Model>
-void speedtests(size_t max_groups) {
-    std::cout << demangle(typeid(typename Model::Shared).name()) << '\n'
-              << "Groups" << '\t' << "Mixture (cells/us)" << '\n';
-    auto const shared = Model::Shared::EXAMPLE();
-    double checksum = 0;
-    for (size_t group_count = 1; group_count <= max_groups; group_count *= 10) {
-        size_t iters = 8 * (200 / (1 + group_count / 100) + 1);
-        double rate = speedtest<Model>(shared, group_count, iters, &checksum);
-        std::cout << group_count << '\t' << std::right << std::setw(7)
-                  << std::fixed << std::setprecision(4) << rate << '\n';
-    }
-    std::cout << "checksum " << std::setprecision(6) << checksum << '\n';
-}
+}  // namespace
 
 int main(int argc, char ** argv) {
-    const size_t max_groups = argc > 1 ? (size_t)atoi(argv[1]) : 1000;
-    speedtests<BetaBernoulli>(max_groups);
-    speedtests<DirichletDiscrete<4>>(max_groups);
-    speedtests<GammaPoisson>(max_groups);
-    speedtests<BetaNegativeBinomial>(max_groups);
-    speedtests<NormalInverseChiSq>(max_groups);
+    const size_t largest = argc > 1 ? (size_t)std::atoi(argv[1]) : 1000;
+    rng_t rng;
+    report<distributions::BetaBernoulli>(largest, rng);
+    report<distributions::DirichletDiscrete<4>>(largest, rng);
+    report<distributions::GammaPoisson>(largest, rng);
+    report<distributions::BetaNegativeBinomial>(largest, rng);
+    report<distributions::NormalInverseChiSq>(largest, rng);
     return 0;
 }

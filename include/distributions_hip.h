@@ -285,6 +285,20 @@ dist_gibbs_t * dist_gibbs_create_low_entropy(int dataset_size, int n_features,
                                              const dist_shared_t * shareds);
 void dist_gibbs_destroy(dist_gibbs_t * g);
 
+/* Rows that have no group yet: `empty_groups` empty groups, every row
+ * unassigned (mixture.init(model) of a fresh mixture, examples/mixture/
+ * main.py:222-224).  dist_gibbs_init_sequential then assigns rows
+ * [row_begin, row_end) in order -- it must start at the first unassigned row
+ * -- by the initialisation loop of examples/mixture/main.py: score every
+ * group for the row (prior_only: with the clustering model alone, main.py:
+ * 227-232; else with all features, main.py:265-270), sample, add; nothing is
+ * removed; one engine step per row from *rng_state, which is advanced. */
+int dist_gibbs_load_rows_unassigned(dist_gibbs_t * g, size_t n_rows,
+                                    const uint32_t * const * values,
+                                    int empty_groups, uint64_t row_offset);
+int dist_gibbs_init_sequential(dist_gibbs_t * g, size_t row_begin,
+                               size_t row_end, uint32_t * rng_state,
+                               int prior_only);
 /* Make n_rows rows resident.  values[f] -> n_rows words; assign_packed[i] in
  * [0, nonempty_groups); empty_groups >= 1 empty groups are appended
  * (mixture.hpp:152-162).  row_offset = global index of local row 0 (multi-GPU

@@ -17,8 +17,10 @@
 //     DIST_THROW_ON_ERROR, common.hpp:49-57).
 #pragma once
 
+#include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <random>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -142,6 +144,89 @@ struct Model {
                                          detail::word(value), &out));
             return out;
         }
+        // Group::sample_value (dd.hpp:188-199, bb.hpp:154-160, gp.hpp:166-172,
+        // nich.hpp:204-210, bnb.hpp:168-174): a draw from the posterior
+        // predictive through the model's Sampler (init, then eval), on the
+        // host with the <random> distributions random.hpp:42-108 uses, over
+        // rng_t.  A sampler, not part of the accelerated path: what a caller
+        // like benchmarks/mixture.cc:94 draws its data with.
+        Value sample_value(const Shared & shared, rng_t & rng) const {
+            return sample_value_impl(shared, rng, static_cast<Value *>(nullptr));
+        }
+
+      private:
+        static float gamma_(rng_t & rng, float alpha, float beta = 1.f) {
+            std::gamma_distribution<double> d(alpha, beta);   // random.hpp:87-97
+            return (float)d(rng);
+        }
+        static float word_f(uint32_t w) { float f; memcpy(&f, &w, 4); return f; }
+        template <class V>
+        V sample_value_impl(const Shared & shared, rng_t & rng, V *) const {
+            switch (KIND) {
+            case DIST_DD: {   // Sampler: dirichlet(alphas + counts), discrete
+                float ps[DIST_DD_MAX_DIM];
+                float total = 0.f;
+                for (int v = 0; v < shared.dim; ++v) {
+                    const float a = shared.alphas[v] + (float)(int)words[1 + v];
+                    ps[v] = a > 0 ? gamma_(rng, a) : 0.f;   // random.cc:121-137
+                    total += ps[v];
+                }
+                const float scale = 1.f / total;
+                float t = dist_rng_unif01(&rng.state);      // random.hpp:300-313
+                for (int v = 0; v + 1 < shared.dim; ++v) {
+                    t -= ps[v] * scale;
+                    if (t < 0) return (V)v;
+                }
+                return (V)(shared.dim - 1);
+            }
+            case DIST_BB: {
+                const float x = gamma_(rng, shared.p[0] + (float)(int)words[0]);
+                const float y = gamma_(rng, shared.p[1] + (float)(int)words[1]);
+                const float heads = x * (1.f / (x + y));
+                return (V)(dist_rng_unif01(&rng.state) < heads);
+            }
+            case DIST_GP: {
+                const float a = shared.p[0] + (float)words[1];
+                const float inv_b = shared.p[1] + (float)words[0];
+                std::poisson_distribution<int> d(gamma_(rng, a, 1.f / inv_b));
+                return (V)d(rng);
+            }
+            case DIST_BNB: {   // bnb.hpp:177-192
+                const float r = shared.p[2];
+                const float a = shared.p[0] + r * (float)words[0];
+                const float b = shared.p[1] + (float)words[1];
+                const float x = gamma_(rng, a), y = gamma_(rng, b);
+                float beta = x / (x + y);
+                if (x == 0 && y == 0)
+                    beta = dist_rng_unif01(&rng.state) < a / (a + b) ? 1.f : 0.f;
+                std::negative_binomial_distribution<int> d((int)r, beta);
+                return (V)d(rng);
+            }
+            case DIST_NICH: {   // nich.hpp:58-69, 213-231
+                const float mu = shared.p[0], kappa = shared.p[1];
+                const float sigmasq = shared.p[2], nu = shared.p[3];
+                const float n = (float)(int)words[0];
+                const float mean = word_f(words[1]), ctv = word_f(words[2]);
+                const float mu_1 = mu - mean;
+                const float pk = kappa + n;
+                const float pmu = (kappa * mu + mean * n) / pk;
+                const float pnu = nu + n;
+                const float psig = 1.f / pnu * (nu * sigmasq + ctv
+                                                + (n * kappa * mu_1 * mu_1) / pk);
+                std::chi_squared_distribution<double> chi(pnu);
+                const float s2 = pnu * psig / (float)chi(rng);
+                std::normal_distribution<float> m(pmu, sqrtf(s2 / pk));
+                const float centre = m(rng);
+                std::normal_distribution<float> d(centre, sqrtf(s2));
+                return (V)d(rng);
+            }
+            default:
+                throw std::runtime_error("sample_value: no sampler for this "
+                                         "model in the shim");
+            }
+        }
+
+      public:
     };
 
     // MixtureSlave<Model, ...> (mixture.hpp:340-450)

@@ -1465,6 +1465,41 @@ void orc_mix_gibbs_sequential(orc_mix * m, size_t row_begin, size_t row_end,
     orc_ftz_restore(saved);
 }
 
+/* The initialisation loop of examples/mixture/main.py: rows are ADDED one at a
+ * time, nothing is removed.  prior_only = 0: compress_seq_gibbs (main.py:
+ * 265-270), every row is scored against the groups built so far
+ * (mixture.score_value) and sampled; prior_only = 1: compress_gibbs
+ * (main.py:227-232), the clustering model's score alone
+ * (mixture.clustering.score_value).  One engine step per row. */
+void orc_mix_init_sequential(orc_mix * m, size_t row_begin, size_t row_end,
+                             const uint32_t * const * values,
+                             uint32_t * assign, uint32_t * rng_state,
+                             int prior_only) {
+    unsigned saved = orc_ftz_enable();
+    int scap = m->K + 64;
+    float * scores = malloc(sizeof(float) * scap);
+    for (size_t i = row_begin; i < row_end; ++i) {
+        if (m->K > scap) {
+            scap = 2 * m->K;
+            scores = realloc(scores, sizeof(float) * scap);
+        }
+        orc_mix_driver_score_value(m, scores);
+        for (int fi = 0; !prior_only && fi < m->F; ++fi)
+            feat_score_value(&m->f[fi], values[fi][i], scores);
+        int g2 = (int)orc_sample_from_scores_overwrite(rng_state, m->K, scores);
+        int added = orc_mix_driver_add_value(m, g2);
+        for (int fi = 0; fi < m->F; ++fi)
+            orc_mix_slave_add_value(m, fi, g2, values[fi][i]);
+        if (added) {
+            for (int fi = 0; fi < m->F; ++fi) feat_add_group(&m->f[fi]);
+            orc_mix_tracker_add_group(m);
+        }
+        assign[i] = orc_mix_packed_to_global(m, (uint32_t)g2);
+    }
+    free(scores);
+    orc_ftz_restore(saved);
+}
+
 /* Batch-semantics scores of one row whose current group is `g`: the state at
  * entry with the row itself taken out.  Nothing is mutated.
  *   n_g >= 2: group order unchanged, entry g re-derived from (stats - row)

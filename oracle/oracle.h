@@ -234,6 +234,12 @@ void orc_mix_load_state(orc_mix * m, int K, const int32_t * counts,
 void orc_mix_gibbs_sequential(orc_mix * m, size_t row_begin, size_t row_end,
                               const uint32_t * const * values,
                               uint32_t * assign_global, uint32_t * rng_state);
+/* the initialisation loops of examples/mixture/main.py:227-232 (prior_only)
+ * and :265-270: rows added one at a time, score -> sample -> add */
+void orc_mix_init_sequential(orc_mix * m, size_t row_begin, size_t row_end,
+                             const uint32_t * const * values,
+                             uint32_t * assign_global, uint32_t * rng_state,
+                             int prior_only);
 /* frozen-snapshot batch (DESIGN.md "Batch semantics"): every row of
  * [row_begin,row_end) is scored against the state at entry minus itself and
  * uses engine draw number (draw_base + row); then all moves are applied in

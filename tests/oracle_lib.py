@@ -155,6 +155,7 @@ def bind_oracle(path):
     sig("orc_mix_init_from_assignments", None, vp, sz, pp, c_u32p, ci, ci,
         c_u32p)
     sig("orc_mix_gibbs_sequential", None, vp, sz, sz, pp, c_u32p, u32ptr)
+    sig("orc_mix_init_sequential", None, vp, sz, sz, pp, c_u32p, u32ptr, ci)
     sig("orc_mix_load_state", None, vp, ci, c_i32p, pp, c_u32p, u32)
     sig("orc_mixture_benchmark_loop", f32, vp, sz, c_u32p, c_u32p, sz)
     sig("orc_mix_gibbs_batch", None, vp, sz, sz, pp, c_u32p, u32, u64)
@@ -309,6 +310,25 @@ class OracleMixture(object):
         self.L.orc_mix_gibbs_sequential(self.h, row_begin, row_end,
                                         self._vals, self.assign,
                                         ctypes.byref(st))
+        return st.value
+
+    def init_empty(self, values, empty=1):
+        """no rows assigned yet: `empty` empty groups (mixture.init(model) of
+        a fresh mixture, examples/mixture/main.py:222-224)"""
+        n = len(values[0])
+        self.init_from_assignments([v[:0] for v in values],
+                                   np.zeros(0, np.uint32), 0, empty)
+        self.values = [value_words(s.kind, v)
+                       for s, v in zip(self.shareds, values)]
+        self.n_rows = n
+        self._vals = ptr_array(self.values)
+        self.assign = np.full(n, 0xFFFFFFFF, np.uint32)
+
+    def init_sequential(self, row_begin, row_end, rng_state, prior_only=False):
+        st = ctypes.c_uint32(rng_state)
+        self.L.orc_mix_init_sequential(self.h, row_begin, row_end, self._vals,
+                                       self.assign, ctypes.byref(st),
+                                       1 if prior_only else 0)
         return st.value
 
     def gibbs_batch(self, row_begin, row_end, seed_state, draw_base):

@@ -679,3 +679,41 @@ def test_independent_engines_on_their_own_streams():
         assert got_state == state
         np.testing.assert_array_equal(got_assign, orc.assign)
         np.testing.assert_array_equal(got_counts, orc.counts())
+
+
+@pytest.mark.parametrize("config", ["dd", "nich", "gp_nich", "dd_bb_gp",
+                                    "bnb"])
+@pytest.mark.parametrize("prior_only", [False, True])
+@pytest.mark.parametrize("empty", [1, 3])
+def test_sequential_init_bit_exact(config, prior_only, empty):
+    """a chain started from an empty mixture -- rows added
+    one at a time, score -> sample -> add (examples/mixture/main.py:227-232,
+    265-270) -- then a sequential and a batched sweep from that state."""
+    from distributions_amd import engine
+    n = 4096
+    osh, gsh, vals, _ = workloads.make(config, n, 8)
+    orc = ol.OracleMixture(2.0, 0.3, osh)
+    orc.init_empty(vals, empty)
+    gpu = engine.Gibbs(2.0, 0.3, gsh)
+    gpu.load_rows_unassigned(vals, empty)
+    with pytest.raises(RuntimeError, match="init_sequential first"):
+        gpu.sweep(0, n, 1024, 1)
+    st = ol.oracle().orc_rng_seed(31337)
+    # in two stretches: the second resumes where the first stopped
+    a = orc.init_sequential(0, 1000, st, prior_only)
+    b = gpu.init_sequential(0, 1000, st, prior_only)
+    assert a == b
+    with pytest.raises(RuntimeError, match="in order"):
+        gpu.init_sequential(5, 10, st)
+    a = orc.init_sequential(1000, n, a, prior_only)
+    b = gpu.init_sequential(1000, n, b, prior_only)
+    assert a == b
+    assert_same_state(orc, gpu, "%s after the init" % config)
+    assert len(orc) > empty          # groups were created
+    assert orc.gibbs_sequential(0, 500, a) == gpu.sweep_sequential(0, 500, b)
+    seed = 99
+    s2 = ol.oracle().orc_rng_seed(seed)
+    for bb in range(0, n, 2048):
+        orc.gibbs_batch(bb, bb + 2048, s2, 0)
+    gpu.sweep(0, n, 2048, seed)
+    assert_same_state(orc, gpu, "%s after a sweep" % config)
