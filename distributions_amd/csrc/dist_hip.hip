@@ -2461,8 +2461,71 @@ struct Gibbs {
     }
     // the general rows' integer statistics: per-group totals through LDS
     // where (1 + 2 F) K integers fit a workgroup's, else direct atomics
+    uint64_t staged_applies = 0;
+    int apply_stage_mode = 1;   // 0: never the all-in-LDS form
     void apply_moves(size_t n, const SweepParams & P, const StatImage & img,
                      const uint32_t * p2g, uint32_t * assign_out) {
+        // the whole integer image in LDS (small categoricals): no global
+        // atomics, the workgroups' images meet in a staging matrix
+        const size_t all_words = stat_words();
+        if (apply_stage_mode && all_words * sizeof(int) <= 144 * 1024
+            && n >= (size_t)4 * K()) {
+            bool cat = false;
+            for (auto & f : feats) cat = cat || is_cat(f->sh.kind);
+            if (cat) {
+                StageLayout L;
+                memset(&L, 0, sizeof(L));
+                L.K = K();
+                int off = K();
+                for (int f = 0; f < F(); ++f) {
+                    L.off_i0[f] = off; off += K();
+                    L.off_i1[f] = off; off += K();
+                    L.off_cnt[f] = off; off += K() * feats[f]->dim();
+                    L.dim[f] = feats[f]->dim();
+                }
+                L.words = off;
+                const unsigned blocks =
+                    (unsigned)((n + kApplyLdsRows - 1) / kApplyLdsRows);
+                vs_stage.reserve(grow_capacity((size_t)blocks * L.words), 0);
+                const size_t lds_all = (size_t)L.words * sizeof(int);
+                int device = 0;
+                HIP_CHECK(hipGetDevice(&device));
+                static std::atomic<size_t> opted_in[64];
+                std::atomic<size_t> & have = opted_in[device & 63];
+                if (lds_all > 64 * 1024
+                    && lds_all > have.load(std::memory_order_relaxed)) {
+                    HIP_CHECK(hipFuncSetAttribute(
+                        reinterpret_cast<const void *>(&k_apply_moves_stage),
+                        hipFuncAttributeMaxDynamicSharedMemorySize,
+                        (int)lds_all));
+                    have.store(lds_all, std::memory_order_relaxed);
+                }
+                hipLaunchKernelGGL(k_apply_moves_stage, dim3(blocks),
+                                   dim3(kApplyLdsBlock), lds_all, stream(), P,
+                                   L, vs_stage.p, p2g, assign_out);
+                HIP_CHECK(hipGetLastError());
+                WordSegments seg;
+                memset(&seg, 0, sizeof(seg));
+                size_t end = 0;
+                auto push = [&](int32_t * dst, size_t words) {
+                    end += words;
+                    seg.dst[seg.n] = dst;
+                    seg.end[seg.n] = end;
+                    seg.n += 1;
+                };
+                push(img.counts, (size_t)K());
+                for (int f = 0; f < F(); ++f) {
+                    push(img.i0[f], (size_t)K());
+                    push(img.i1[f], (size_t)K());
+                    // (a zero-length segment never matches a word)
+                    push(img.cnt[f], (size_t)K() * feats[f]->dim());
+                }
+                LAUNCH(k_stage_reduce, (size_t)L.words, seg, vs_stage.p,
+                       (int)blocks, L.words);
+                staged_applies += 1;
+                return;
+            }
+        }
         const size_t lds = (size_t)(1 + 2 * F()) * K() * sizeof(int);
         if (lds > 64 * 1024 || n < (size_t)4 * K()) {   // (too few to pay)
             LAUNCH(k_apply_moves, n, P, img, p2g, assign_out);
@@ -4202,6 +4265,12 @@ int dist_gibbs_set_option(dist_gibbs_t * g, const char * name, int value) {
         } else if (key == "sampling") {
             DIST_REQUIRE(value == 0 || value == 1, "sampling: 0 exact, 1 scan");
             g->impl->sampling_mode = value;
+        } else if (key == "apply_stage") {
+            // general rows' integer statistics: 1 (default) the whole image
+            // in LDS and a staging matrix where it fits, 0 global atomics on
+            // the categorical cells
+            DIST_REQUIRE(value == 0 || value == 1, "apply_stage: 0 or 1");
+            g->impl->apply_stage_mode = value;
         } else if (key == "rows_fold") {
             // general rows: the leading discrete features' scores from a
             // per-(joint value, group) table, rows sorted by joint value
