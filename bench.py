@@ -608,10 +608,16 @@ def run_rank(args):
                     if c.strip()]:
             if cfg == args.config:
                 continue
-            for sampling in (0, 1):
+            for label, opts in (
+                    ("exact", []),
+                    ("scan sampling (tolerance-level, opt-in)",
+                     ["sampling=1"]),
+                    ("scan sampling + merged float statistics "
+                     "(tolerance-level, opt-in)",
+                     ["sampling=1", "float_stats=1"])):
                 sub = argparse.Namespace(**vars(args))
                 sub.config = cfg
-                sub.opt = list(args.opt) + ["sampling=%d" % sampling]
+                sub.opt = list(args.opt) + opts
                 if len(others) == 0:
                     del sharded, g, columns
                     g = sharded = columns = None
@@ -623,8 +629,7 @@ def run_rank(args):
                 counts_o = g2.core.debug_counts()
                 others.append({
                     "config": cfg, "workload": name2,
-                    "sampling": "scan (tolerance-level, opt-in)" if sampling
-                                else "exact",
+                    "sampling": label,
                     "value": float(n) * steps_o / dt_o,
                     "unit": "row-updates/s", "steps": steps_o,
                     "ms_per_step": 1e3 * dt_o / steps_o,

@@ -200,6 +200,11 @@ cdef extern from "distributions_hip.h" nogil:
     size_t dist_gibbs_global_size(const dist_gibbs_t *)
     int dist_gibbs_debug_counts(dist_gibbs_t *, uint64_t *, size_t)
     int dist_gibbs_comm_stats(dist_gibbs_t *, double *, uint64_t *, int)
+    size_t dist_gibbs_float_delta_words(const dist_gibbs_t *)
+    int dist_gibbs_batch_float_delta_dev(dist_gibbs_t *, double *)
+    int dist_gibbs_batch_apply_float_delta_dev(dist_gibbs_t *, const double *)
+    int dist_gibbs_export_float_moments_dev(dist_gibbs_t *, double *)
+    int dist_gibbs_import_float_moments_dev(dist_gibbs_t *, const double *)
     int dist_gibbs_sharded_device_normalise_ok(const dist_gibbs_t *, size_t,
                                                size_t, int *)
     int dist_gibbs_kernel_stats(dist_gibbs_t *, double *, uint64_t *,
@@ -1108,14 +1113,15 @@ cdef class GibbsEngine:
 
     def debug_counts(self):
         """dict of the engine's path diagnostics (dist_gibbs_debug_counts)"""
-        cdef uint64_t out[12]
-        check(dist_gibbs_debug_counts(self.ptr, out, 12))
+        cdef uint64_t out[13]
+        check(dist_gibbs_debug_counts(self.ptr, out, 13))
         return {"value_sorted_batches": out[0], "other_batches": out[1],
                 "band_launches": out[2], "running_sum_launches": out[3],
                 "band_values_last": out[4], "handed_over_last": out[5],
                 "stream_batches": out[6], "device_normalised": out[7],
                 "narrow_batches": out[8], "scratch_batches": out[9],
-                "fold_batches": out[10], "scan_batches": out[11]}
+                "fold_batches": out[10], "scan_batches": out[11],
+                "merged_batches": out[12]}
 
     def set_option(self, name, int value):
         check(dist_gibbs_set_option(self.ptr, name.encode(), value))
@@ -1125,6 +1131,25 @@ cdef class GibbsEngine:
         cdef uint64_t a = 0, b = 0
         check(dist_gibbs_path_counts(self.ptr, &a, &b))
         return a, b
+
+    def float_delta_words(self):
+        """doubles per image of the merged float statistics (0: the ordered
+        replay is in use)"""
+        return checked_size(dist_gibbs_float_delta_words(self.ptr))
+
+    def batch_float_delta_dev(self, size_t ptr):
+        check(dist_gibbs_batch_float_delta_dev(self.ptr, <double *> ptr))
+
+    def batch_apply_float_delta_dev(self, size_t ptr):
+        check(dist_gibbs_batch_apply_float_delta_dev(self.ptr,
+                                                     <const double *> ptr))
+
+    def export_float_moments_dev(self, size_t ptr):
+        check(dist_gibbs_export_float_moments_dev(self.ptr, <double *> ptr))
+
+    def import_float_moments_dev(self, size_t ptr):
+        check(dist_gibbs_import_float_moments_dev(self.ptr,
+                                                  <const double *> ptr))
 
     def comm_stats(self, reset=False):
         """-> (ms, count) of the timed all-reduces of sweep_sharded"""

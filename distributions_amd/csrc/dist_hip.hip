@@ -2315,7 +2315,78 @@ struct Gibbs {
         replay_sorted(old_dev, new_dev, 0, n, vals);
         if (reset && !batch_open) rebuild_caches();
     }
+    // "float_stats": 0 the ordered replay (bit-identical to the sequential
+    // chain's running updates; default), 1 merged: binary64 sums per group
+    // (kernels.h, k_merge_float_*; tolerance-level)
+    int float_stats_mode = 0;
+    DeviceBuf<double> merge_stage, merge_image;
+    uint64_t merged_batches = 0;
+    MergeLayout merge_layout() const {
+        MergeLayout L;
+        memset(&L, 0, sizeof(L));
+        L.F = F();
+        L.K = K();
+        int off = 0;
+        for (int f = 0; f < F(); ++f) {
+            const int kind = feats[f]->sh.kind;
+            L.kind[f] = has_float_stats(kind) ? kind : -1;
+            L.off[f] = off;
+            if (kind == DIST_NICH) off += 3 * K();
+            if (kind == DIST_GP) off += K();
+        }
+        L.words = off;
+        return L;
+    }
+    bool merged_floats() const {
+        return float_stats_mode == 1 && any_float_stats()
+               && (size_t)merge_layout().words * 8 <= 144 * 1024;
+    }
+    // the open batch's float-statistic sums into merge_image (not applied)
+    void merge_float_delta() {
+        const size_t n = batch_end - batch_begin;
+        const MergeLayout L = merge_layout();
+        merge_image.reserve(grow_capacity((size_t)L.words), 0);
+        if (!n) {
+            HIP_CHECK(hipMemsetAsync(merge_image.p, 0, (size_t)L.words * 8,
+                                     stream()));
+            return;
+        }
+        const bool by_pos = batch_value_sorted;
+        SweepParams P = params(batch_begin, batch_end, 0, 0);
+        const unsigned blocks =
+            (unsigned)((n + kApplyLdsRows - 1) / kApplyLdsRows);
+        merge_stage.reserve(grow_capacity((size_t)blocks * L.words), 0);
+        const size_t lds = (size_t)L.words * 8;
+        int device = 0;
+        HIP_CHECK(hipGetDevice(&device));
+        static std::atomic<size_t> opted_in[64];
+        std::atomic<size_t> & have = opted_in[device & 63];
+        if (lds > 64 * 1024 && lds > have.load(std::memory_order_relaxed)) {
+            HIP_CHECK(hipFuncSetAttribute(
+                reinterpret_cast<const void *>(&k_merge_float_moves),
+                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            have.store(lds, std::memory_order_relaxed);
+        }
+        hipLaunchKernelGGL(k_merge_float_moves, dim3(blocks),
+                           dim3(kApplyLdsBlock), lds, stream(), P, L,
+                           by_pos ? old_row.p : old_packed.p,
+                           by_pos ? new_row.p : new_packed.p, merge_stage.p);
+        HIP_CHECK(hipGetLastError());
+        LAUNCH(k_merge_float_reduce, (size_t)L.words, merge_stage.p,
+               (int)blocks, L.words, merge_image.p);
+    }
+    void merge_float_apply(const double * image, bool reset = false) {
+        const MergeLayout L = merge_layout();
+        SweepParams P = params(batch_begin, batch_end, 0, 0);
+        LAUNCH(k_merge_float_apply, (size_t)K(), P, L, image, reset ? 1 : 0);
+        merged_batches += reset ? 0 : 1;
+    }
     void replay_floats() {
+        if (merged_floats()) {
+            merge_float_delta();
+            merge_float_apply(merge_image.p);
+            return;
+        }
         // value-sorted batches hold the moves by position; apply_ints left a
         // row-ordered copy for the replay
         const bool by_pos = batch_value_sorted;
@@ -3993,9 +4064,11 @@ int dist_gibbs_sweep_sharded(dist_gibbs_t * g, dist_comm_t * c,
     return guarded([&] {
         DIST_REQUIRE(c && c->comm, "no communicator");
         DIST_REQUIRE(batch_rows > 0, "batch_rows must be positive");
-        DIST_REQUIRE(!g->impl.open()->any_float_stats(),
+        DIST_REQUIRE(!g->impl.open()->any_float_stats()
+                         || g->impl.open()->merged_floats(),
                      "order-dependent statistics are exchanged as rows "
-                     "(dist_gibbs_batch_moves_dev / replay_ordered_dev)");
+                     "(dist_gibbs_batch_moves_dev / replay_ordered_dev), or "
+                     "as sums with float_stats = 1");
         // The group set is normalised on the device -- no host round trip per
         // sub-sweep on any rank -- when EVERY rank can (one all-reduce of a
         // flag when a run is opened: the layout of the delta image depends
@@ -4062,6 +4135,14 @@ int dist_gibbs_sweep_sharded(dist_gibbs_t * g, dist_comm_t * c,
                     e.comm_ev_pending.emplace_back(t0, t1);
                 }
                 e.batch_apply_delta(e.delta_image.p, true);
+                if (e.merged_floats()) {   // the float statistics as sums
+                    e.merge_float_delta();
+                    RCCL_CHECK(rccl().all_reduce(
+                        e.merge_image.p, e.merge_image.p,
+                        (size_t)e.merge_layout().words, ncclDouble, ncclSum,
+                        c->comm, stream()));
+                    e.merge_float_apply(e.merge_image.p);
+                }
                 if (on_device) e.batch_finish_device();
                 else e.batch_finish();
             }
@@ -4123,6 +4204,55 @@ int dist_gibbs_replay_ordered_dev(dist_gibbs_t * g,
     return guarded([&] {
         g->impl->replay_ordered(old_slot_dev, new_slot_dev, values_dev,
                                 n_rows, reset != 0);
+    });
+}
+size_t dist_gibbs_float_delta_words(const dist_gibbs_t * g) {
+    size_t n = (size_t)-1;
+    (void)guarded([&] {
+        Gibbs * e = g->impl.open();
+        n = e->merged_floats() ? (size_t)e->merge_layout().words : 0;
+    });
+    return n;
+}
+int dist_gibbs_export_float_moments_dev(dist_gibbs_t * g, double * out_dev) {
+    return guarded([&] {
+        Gibbs & e = *g->impl;
+        DIST_REQUIRE(!e.batch_open, "a batch is open");
+        DIST_REQUIRE(e.merged_floats(), "float_stats is not 1 (merged)");
+        const MergeLayout L = e.merge_layout();
+        SweepParams P = e.params(0, 0, 0, 0);
+        LAUNCH(k_merge_float_export, (size_t)e.K(), P, L, out_dev);
+    });
+}
+int dist_gibbs_import_float_moments_dev(dist_gibbs_t * g,
+                                        const double * image_dev) {
+    return guarded([&] {
+        Gibbs & e = *g->impl;
+        DIST_REQUIRE(!e.batch_open, "a batch is open");
+        DIST_REQUIRE(e.merged_floats(), "float_stats is not 1 (merged)");
+        e.merge_float_apply(image_dev, true);
+        e.rebuild_caches();
+        sync();
+    });
+}
+int dist_gibbs_batch_float_delta_dev(dist_gibbs_t * g, double * delta_dev) {
+    return guarded([&] {
+        Gibbs & e = *g->impl;
+        DIST_REQUIRE(e.batch_open, "no open batch");
+        DIST_REQUIRE(e.merged_floats(), "float_stats is not 1 (merged)");
+        e.merge_float_delta();
+        HIP_CHECK(hipMemcpyAsync(delta_dev, e.merge_image.p,
+                                 (size_t)e.merge_layout().words * 8,
+                                 hipMemcpyDeviceToDevice, stream()));
+    });
+}
+int dist_gibbs_batch_apply_float_delta_dev(dist_gibbs_t * g,
+                                           const double * delta_dev) {
+    return guarded([&] {
+        Gibbs & e = *g->impl;
+        DIST_REQUIRE(e.batch_open, "no open batch");
+        DIST_REQUIRE(e.merged_floats(), "float_stats is not 1 (merged)");
+        e.merge_float_apply(delta_dev);
     });
 }
 int dist_gibbs_batch_finish(dist_gibbs_t * g) {
@@ -4265,6 +4395,10 @@ int dist_gibbs_set_option(dist_gibbs_t * g, const char * name, int value) {
         } else if (key == "sampling") {
             DIST_REQUIRE(value == 0 || value == 1, "sampling: 0 exact, 1 scan");
             g->impl->sampling_mode = value;
+        } else if (key == "float_stats") {
+            DIST_REQUIRE(value == 0 || value == 1,
+                         "float_stats: 0 ordered, 1 merged");
+            g->impl->float_stats_mode = value;
         } else if (key == "apply_stage") {
             // general rows' integer statistics: 1 (default) the whole image
             // in LDS and a staging matrix where it fits, 0 global atomics on
@@ -4302,10 +4436,11 @@ int dist_gibbs_path_counts(const dist_gibbs_t * g, uint64_t * value_sorted,
 int dist_gibbs_debug_counts(dist_gibbs_t * g, uint64_t * out, size_t n) {
     return guarded([&] {
         Gibbs & e = *g->impl;
-        uint64_t v[12] = {e.vs_batches, e.generic_batches, e.band_batches,
+        uint64_t v[13] = {e.vs_batches, e.generic_batches, e.band_batches,
                           e.prefix_batches, 0, 0, e.stream_batches,
                           e.async_batches, e.narrow_batches,
-                          e.scratch_batches, e.fold_batches, e.scan_batches};
+                          e.scratch_batches, e.fold_batches, e.scan_batches,
+                          e.merged_batches};
         if (e.last_bands && !e.batch_open && e.vsBandMode.p) {
             // values whose arg-max group's rows had a tile of their own in
             // the last value-sorted launch
@@ -4318,7 +4453,7 @@ int dist_gibbs_debug_counts(dist_gibbs_t * g, uint64_t * out, size_t n) {
             e.deferred_count.download(&d, 1);
             v[5] = d;
         }
-        for (size_t i = 0; i < n && i < 12; ++i) out[i] = v[i];
+        for (size_t i = 0; i < n && i < 13; ++i) out[i] = v[i];
     });
 }
 int dist_gibbs_comm_stats(dist_gibbs_t * g, double * ms_out,

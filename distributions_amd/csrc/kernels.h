@@ -4240,6 +4240,127 @@ __global__ void k_stage_reduce(WordSegments seg,
     seg.dst[j][i - begin] += d;
 }
 
+// ---- merged float statistics (option "float_stats" = 1: opt-in,
+// tolerance-level; the ordered replay below stays the default) --------------
+// The order-dependent statistics of a batch as SUMS in binary64 -- per group
+// NICH: the change of the count, of sum x and of sum x^2; GP: of log_prod --
+// which do add over rows, workgroups and ranks.  The group's new (count,
+// mean, count_times_variance) follows from its old ones and the sums by the
+// textbook identities; it equals what nich.hpp:125-165's running updates give
+// to binary32 rounding (the tests bound the difference), not bit for bit.
+// Worth it where the ordered replay costs too much: a chain of ~2 B / K
+// dependent Welford steps per group and batch, and in a multi-rank run every
+// rank replaying every rank's rows.
+struct MergeLayout {
+    int F;
+    int kind[kMaxF];          // DIST_NICH, DIST_GP or -1
+    int off[kMaxF];           // first double of the feature's block
+    int words;                // doubles per image
+    int K;
+};
+__global__ __launch_bounds__(kApplyLdsBlock) void k_merge_float_moves(
+        SweepParams P, MergeLayout L, const uint32_t * __restrict__ old_slot,
+        const uint32_t * __restrict__ new_slot, double * __restrict__ stage) {
+    extern __shared__ double mf_lds[];   // [L.words]
+    for (int i = threadIdx.x; i < L.words; i += kApplyLdsBlock) mf_lds[i] = 0.0;
+    __syncthreads();
+    const size_t n = P.row_end - P.row_begin;
+    const size_t begin = (size_t)blockIdx.x * kApplyLdsRows;
+    const size_t end = begin + kApplyLdsRows < n ? begin + kApplyLdsRows : n;
+    for (size_t b = begin + threadIdx.x; b < end; b += kApplyLdsBlock) {
+        const uint32_t go = old_slot[b], gn = new_slot[b];
+        if (go == gn || go == 0xFFFFFFFFu) continue;   // (or padding)
+        const size_t row = P.row_begin + b;
+        for (int f = 0; f < L.F; ++f) {
+            if (L.kind[f] < 0) continue;
+            double * d = mf_lds + L.off[f];
+            const uint32_t w = P.values[f][row];
+            if (L.kind[f] == DIST_NICH) {
+                const double x = (double)u2f(w);
+                atomicAdd(&d[go], -1.0);
+                atomicAdd(&d[gn], 1.0);
+                atomicAdd(&d[L.K + go], -x);
+                atomicAdd(&d[L.K + gn], x);
+                atomicAdd(&d[2 * L.K + go], -x * x);
+                atomicAdd(&d[2 * L.K + gn], x * x);
+            } else {   // GammaPoisson's log_prod (gp.hpp:115,134)
+                const double lf = (double)fast_log_factorial(w);
+                atomicAdd(&d[go], -lf);
+                atomicAdd(&d[gn], lf);
+            }
+        }
+    }
+    __syncthreads();
+    double * out = stage + (size_t)blockIdx.x * L.words;
+    for (int i = threadIdx.x; i < L.words; i += kApplyLdsBlock)
+        out[i] = mf_lds[i];
+}
+// the staged rows summed per word, in row order (a fixed order: the same
+// partial sums give the same image)
+__global__ void k_merge_float_reduce(const double * __restrict__ stage,
+                                     int rows, int words,
+                                     double * __restrict__ image) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= words) return;
+    double d = 0.0;
+    for (int r = 0; r < rows; ++r) d += stage[(size_t)r * words + i];
+    image[i] = d;
+}
+// a replica's float statistics AS such an image (count, sum x, sum x^2;
+// log_prod): the all-reduce of the ranks' images, applied with `reset` (the
+// old statistics taken as zero), is the statistics of all rows
+__global__ void k_merge_float_export(SweepParams P, MergeLayout L,
+                                     double * __restrict__ image) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= L.K) return;
+    for (int f = 0; f < L.F; ++f) {
+        if (L.kind[f] < 0) continue;
+        const SlaveView & v = P.feat[f];
+        double * d = image + L.off[f];
+        if (L.kind[f] == DIST_NICH) {
+            const double n = (double)v.i0[k], mean = (double)v.f0[k];
+            d[k] = n;
+            d[L.K + k] = n * mean;
+            d[2 * L.K + k] = (double)v.f1[k] + n * mean * mean;
+        } else {
+            d[k] = (double)v.f0[k];
+        }
+    }
+}
+// the groups' statistics from their old ones and the (all-reduced) image
+__global__ void k_merge_float_apply(SweepParams P, MergeLayout L,
+                                    const double * __restrict__ image,
+                                    int reset) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= L.K) return;
+    for (int f = 0; f < L.F; ++f) {
+        if (L.kind[f] < 0) continue;
+        const SlaveView & v = P.feat[f];
+        const double * d = image + L.off[f];
+        if (L.kind[f] == DIST_NICH) {
+            const double dn = d[k], dx = d[L.K + k], dxx = d[2 * L.K + k];
+            if (!reset && dn == 0.0 && dx == 0.0 && dxx == 0.0) continue;
+            const double n0 = reset ? 0.0 : (double)v.i0[k];
+            const double mean0 = reset ? 0.0 : (double)v.f0[k];
+            const double ctv0 = reset ? 0.0 : (double)v.f1[k];
+            const double n1 = n0 + dn;
+            const double s1 = n0 * mean0 + dx;
+            const double s2 = ctv0 + n0 * mean0 * mean0 + dxx;
+            double mean1 = 0.0, ctv1 = 0.0;
+            if (n1 >= 1.0) mean1 = s1 / n1;
+            if (n1 >= 2.0) {   // nich.hpp:159-163: no variance below two
+                ctv1 = s2 - n1 * mean1 * mean1;
+                if (ctv1 < 0.0) ctv1 = 0.0;
+            }
+            v.i0[k] = (int32_t)n1;
+            v.f0[k] = (float)mean1;
+            v.f1[k] = (float)ctv1;
+        } else if (reset || d[k] != 0.0) {
+            v.f0[k] = (float)((reset ? 0.0 : (double)v.f0[k]) + d[k]);
+        }
+    }
+}
+
 // Float statistics (NICH count/mean/ctv, GP log_prod) depend on update order
 // (nich.hpp:125-165 is a running Welford update), so they are replayed per
 // group in row order -- the order the sequential chain would apply them in.

@@ -175,7 +175,14 @@ class ShardedGibbs(object):
         self._delta = None
         self._comm = None
         self._n_batches = {}    # batch_rows -> sub-sweeps per pass (all ranks)
-        self.ordered = self.collective and backend.ordered_features() > 0
+        # order-dependent statistics travel as rows (every replica replays
+        # all of them) unless the backend keeps them as sums
+        # (float_stats = 1: one more all-reduce of a few doubles per group)
+        self.merged = (self.collective and backend.ordered_features() > 0
+                       and getattr(backend, "float_delta_words",
+                                   lambda: 0)() > 0)
+        self.ordered = (self.collective and backend.ordered_features() > 0
+                        and not self.merged)
         self.columns = columns
         self.assign_packed = assign_packed
         if self.ordered and columns is None:
@@ -252,8 +259,15 @@ class ShardedGibbs(object):
         n = self.backend.stat_words()
         t = torch.zeros(n, dtype=torch.int32, device=self.device)
         self.backend.export_stats_dev(int(t.data_ptr()))
+        if self.merged:   # (from the rank's OWN statistics: before the import)
+            words = self.backend.float_delta_words()
+            image = torch.zeros(words, dtype=torch.float64, device=self.device)
+            self.backend.export_float_moments_dev(int(image.data_ptr()))
         self._all_reduce(t)
         self.backend.import_stats_dev(int(t.data_ptr()))
+        if self.merged:
+            self._all_reduce(image)
+            self.backend.import_float_moments_dev(int(image.data_ptr()))
         if self.ordered:
             # order-dependent statistics: every replica replays ALL rows in
             # global order (Group::add_value per row, in row order)
@@ -352,6 +366,14 @@ class ShardedGibbs(object):
                 self.backend.batch_delta_dev(int(delta.data_ptr()))
                 self._all_reduce(delta)
                 self.backend.batch_apply_delta_dev(int(delta.data_ptr()))
+                if self.merged:
+                    words = self.backend.float_delta_words()
+                    fd = torch.empty(words, dtype=torch.float64,
+                                     device=self.device)
+                    self.backend.batch_float_delta_dev(int(fd.data_ptr()))
+                    self._all_reduce(fd)
+                    self.backend.batch_apply_float_delta_dev(
+                        int(fd.data_ptr()))
                 if self.ordered:
                     nb_rows = r1 - r0
                     old = torch.empty(nb_rows, dtype=torch.int32,

@@ -338,6 +338,24 @@ int dist_gibbs_batch_delta_dev(dist_gibbs_t * g, int32_t * delta_dev);
 int dist_gibbs_batch_apply_delta_dev(dist_gibbs_t * g,
                                      const int32_t * delta_dev);
 int dist_gibbs_batch_apply_local(dist_gibbs_t * g);
+/* "float_stats" = 1 (merged; opt-in, tolerance-level): the order-dependent
+ * statistics -- NormalInverseChiSq's count / mean / count_times_variance
+ * (nich.hpp:125-165), GammaPoisson's log_prod (gp.hpp:115,134) -- are updated
+ * from binary64 SUMS per group (change of the count, of sum x, of sum x^2; of
+ * log_prod) instead of being replayed row by row: equal to the running
+ * updates to binary32 rounding, not bit for bit.  The sums add over ranks:
+ * dist_gibbs_float_delta_words() doubles per image (0: not in this mode);
+ * between dist_gibbs_batch_apply_delta_dev and dist_gibbs_batch_finish a
+ * multi-rank caller takes its open batch's image, all-reduces it and hands it
+ * back; dist_gibbs_sweep_sharded does so itself.  After every rank loaded
+ * ITS rows: export (which zeroes the rank's own), all-reduce, import. */
+size_t dist_gibbs_float_delta_words(const dist_gibbs_t * g);
+int dist_gibbs_batch_float_delta_dev(dist_gibbs_t * g, double * delta_dev);
+int dist_gibbs_batch_apply_float_delta_dev(dist_gibbs_t * g,
+                                           const double * delta_dev);
+int dist_gibbs_export_float_moments_dev(dist_gibbs_t * g, double * out_dev);
+int dist_gibbs_import_float_moments_dev(dist_gibbs_t * g,
+                                        const double * image_dev);
 int dist_gibbs_batch_finish(dist_gibbs_t * g);
 /* Order-dependent statistics -- all of NormalInverseChiSq's (Welford updates,
  * nich.hpp:125-165) and GammaPoisson's log_prod (gp.hpp:115,134) -- do not add
@@ -447,8 +465,12 @@ int dist_gibbs_sharded_device_normalise_ok(const dist_gibbs_t * g,
  * rows sorted by joint value, where at least 128 rows share a value),
  * 2 (whenever the joint domain is no larger than the batch), 0 (never);
  * "program_all" = 1 (default: every batch outside the value-sorted path is
- * scored through the per-batch score program) or 0.
+ * scored through the per-batch score program) or 0;
+ * "apply_stage" = 1 (default: general rows' integer statistics summed in LDS
+ * as one image per workgroup where the image fits) or 0.
  * None of the above changes a result.
+ * "float_stats" = 0 (default: the ordered replay) or 1 (merged sums, see
+ * dist_gibbs_float_delta_words): tolerance-level.
  * "sampling" = 0 (default, the line of record: the reference's float
  * operations in the reference's order, bit-identical assignments) or 1: SCAN
  * SAMPLING, tolerance-level -- the same scores bit for bit and the same engine

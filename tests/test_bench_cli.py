@@ -60,7 +60,8 @@ def test_small_single_gpu_run_prints_one_json_line():
     # the general-row configurations, exact and with scan sampling
     got = [(o["config"], o["sampling"].split()[0]) for o in out["other_configs"]]
     assert got == [("gp_nich", "exact"), ("gp_nich", "scan"),
-                   ("mixed", "exact"), ("mixed", "scan")]
+                   ("gp_nich", "scan"), ("mixed", "exact"), ("mixed", "scan"),
+                   ("mixed", "scan")]
     assert all(o["value"] > 0 and o["kernel"] == "k_rows_scratch"
                for o in out["other_configs"])
     assert out["cpu_baseline"]["reference_kernels"] is None or (

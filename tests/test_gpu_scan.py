@@ -159,3 +159,71 @@ def test_value_sorted_scan_many_sweeps_keep_the_state_consistent():
     assert words[0] == members.sum()
     assert np.array_equal(words[1:17],
                           np.bincount(vals[0][members], minlength=16))
+
+
+# ---------------------------------------------------------------------------
+# "float_stats" = 1: the order-dependent statistics as binary64 sums
+
+
+def group_stats(gpu, f, kind):
+    out = []
+    for g in range(len(gpu)):
+        w = gpu.get_group(f, g)
+        if kind == "nich":
+            out.append((int(np.int32(w[0])), float(w[1:2].view(np.float32)[0]),
+                        float(w[2:3].view(np.float32)[0])))
+        else:   # gp: count, sum, log_prod
+            out.append((int(w[0]), int(w[1]),
+                        float(w[2:3].view(np.float32)[0])))
+    return np.array(out, np.float64)
+
+
+@pytest.mark.parametrize("config,kinds", [("gp_nich", ("gp", "nich")),
+                                          ("nich", ("nich",)),
+                                          ("gp", ("gp",))])
+def test_merged_float_stats_match_the_ordered_replay_to_rounding(config, kinds):
+    """one batch from the same state: the same moves, statistics equal to the
+    sequential updates' up to binary32 rounding"""
+    n, k = 40000, 50
+    res = []
+    for merged in (0, 1):
+        gpu, _, _ = engine_for(config, n, k, 0)
+        gpu.set_option("float_stats", merged)
+        gpu.sweep(0, n, n, 2024)
+        res.append((gpu.assignments().copy(),
+                    [group_stats(gpu, f, kind) for f, kind in enumerate(kinds)],
+                    gpu.core.debug_counts()["merged_batches"]))
+    (a0, s0, m0), (a1, s1, m1) = res
+    assert (m0, m1) == (0, 1)
+    assert np.array_equal(a0, a1)
+    for x, y in zip(s0, s1):
+        assert np.array_equal(x[:, 0], y[:, 0])            # counts: exact
+        np.testing.assert_allclose(y[:, 1:], x[:, 1:], rtol=2e-5, atol=2e-5)
+
+
+def test_merged_float_stats_stay_those_of_the_rows_over_sweeps():
+    """ten sweeps of sub-sweeps (scan sampling + merged statistics: the
+    tolerance-level configuration): every group's count / mean /
+    count_times_variance are those of its rows, computed in binary64"""
+    n, k = 30000, 20
+    gpu, vals, _ = engine_for("gp_nich", n, k, 1)
+    gpu.set_option("float_stats", 1)
+    for sweep in range(10):
+        gpu.sweep(0, n, 5000, 11, draw_base=sweep * n)
+    assign = gpu.assignments()
+    packed = np.array([gpu.core.global_to_packed(int(a)) for a in assign])
+    got = group_stats(gpu, 1, "nich")
+    x = vals[1].astype(np.float64)
+    for g in range(len(gpu)):
+        rows = x[packed == g]
+        assert got[g, 0] == len(rows)
+        if len(rows):
+            assert abs(got[g, 1] - rows.mean()) < 1e-4 * max(1, abs(rows.mean()))
+        if len(rows) > 1:
+            ctv = ((rows - rows.mean()) ** 2).sum()
+            assert abs(got[g, 2] - ctv) < 1e-3 * max(1.0, ctv)
+    lf = np.array([float(np.sum([np.log(np.arange(1, v + 1)).sum()
+                                 for v in vals[0][packed == g]]))
+                   for g in range(len(gpu))])
+    got_gp = group_stats(gpu, 0, "gp")
+    np.testing.assert_allclose(got_gp[:, 2], lf, rtol=1e-3, atol=1e-2)

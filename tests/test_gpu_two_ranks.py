@@ -24,7 +24,7 @@ pytestmark = pytest.mark.gpu
 K, PER_RANK_BATCH, SWEEPS, SEED = 24, 750, 2, 777
 
 
-def worker(rank, world, port, out, config, mode, N):
+def worker(rank, world, port, out, config, mode, N, merged=0):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -40,6 +40,7 @@ def worker(rank, world, port, out, config, mode, N):
     packed = torch.from_numpy(assign[lo:hi].view(np.int32).copy()).to(dev)
     gpu = engine.Gibbs(1.0, 0.2, gsh)
     gpu.set_option("value_sorted", mode)
+    gpu.set_option("float_stats", merged)
     gpu.load_rows_torch(cols, packed.clone(), K, 2, row_offset=lo)
     sharded = engine.ShardedGibbs(gpu.core, hi - lo, lo, device=dev,
                                   columns=cols, assign_packed=packed)
@@ -111,3 +112,34 @@ def test_ranks_on_one_gpu_equal_one_process(tmp_path, config, mode, world, N):
                                      for f in range(len(osh))])
                      for g in range(len(m))])
     assert np.array_equal(want, groups[0])
+
+
+def test_merged_float_statistics_over_ranks(tmp_path):
+    """float_stats = 1: the ranks exchange binary64 sums instead of rows;
+    the replicas stay bit-identical and the statistics are those of the rows
+    (three ranks, ragged shards)"""
+    import workloads
+    world, N, config = 3, 5501, "gp_nich"
+    mp.spawn(worker, args=(world, free_port(), str(tmp_path), config, 1, N, 1),
+             nprocs=world, join=True)
+    assign = np.concatenate([np.load(tmp_path / ("assign_%d.npy" % r))
+                             for r in range(world)])
+    counts = [np.load(tmp_path / ("counts_%d.npy" % r)) for r in range(world)]
+    groups = [np.load(tmp_path / ("groups_%d.npy" % r)) for r in range(world)]
+    for r in range(1, world):
+        assert np.array_equal(counts[0], counts[r])
+        assert np.array_equal(groups[0], groups[r])
+    _, _, vals, _ = workloads.make(config, N, K)
+    # groups[0][g] = GP words (count, sum, log_prod) + NICH words (count,
+    # mean, ctv); global ids are dense here up to removed groups: match the
+    # groups by size and mean instead of by id
+    x = vals[1].astype(np.float64)
+    ids, sizes = np.unique(assign, return_counts=True)
+    nich = groups[0][:, 3:6]
+    got = sorted((int(np.int32(w[0])), float(w[1:2].view(np.float32)[0]))
+                 for w in nich if np.int32(w[0]) > 0)
+    want = sorted((int(c), float(x[assign == i].mean()))
+                  for i, c in zip(ids, sizes))
+    assert [g[0] for g in got] == [w[0] for w in want]
+    np.testing.assert_allclose([g[1] for g in got], [w[1] for w in want],
+                               rtol=1e-4, atol=1e-4)
