@@ -21,7 +21,7 @@ Prints ONE JSON line (rank 0).  `roofline` prices the score+sample kernel
 does not apply): its HIP-event duration on the launch stream is measured in
 this run; the counters behind `frac` (VALU busy cycles for the VALU-bound
 kernels, HBM bytes for the HBM-bound one) come from the rocprofv3 --pmc passes
-of this same command committed under profiles/ (profiles/r2_counters.json,
+of this same command committed under profiles/ (profiles/r3_counters.json,
 ignored when the kernel sources changed since).  `cpu_baseline` times the
 oracle's sequential chain (the reference loop restated, oracle/oracle.c) on the
 first --cpu-rows rows of the very column the GPU holds, one host thread.
@@ -201,10 +201,10 @@ def source_hash():
 
 def committed_counters(kernel):
     """Per-launch counter means of `kernel` from the committed rocprofv3
-    --pmc passes (profiles/r2_counters.json, written by tools/counters.py on
+    --pmc passes (profiles/r3_counters.json, written by tools/counters.py on
     the GPU box from separate passes of this command).  None when there is no
     record or the kernel sources changed since it was taken."""
-    path = os.path.join(ROOT, "profiles", "r2_counters.json")
+    path = os.path.join(ROOT, "profiles", "r3_counters.json")
     try:
         rec = json.load(open(path))
     except (OSError, ValueError):
@@ -600,6 +600,26 @@ def run_rank(args):
 
     comm_ms, comm_count = (g.core.comm_stats() if native_comm else (0.0, 0))
 
+    # where a sub-sweep's time goes: two more sweeps with events at the phase
+    # boundaries (a diagnostic pass of its own: the events cost some 20 us a
+    # sub-sweep, so the line's `value` is not measured with them)
+    breakdown = None
+    if rank == 0 and world == 1 and vs_batches and not args.force_collective:
+        g.set_option("phase_timing", 1)
+        g.core.phase_stats(reset=True)
+        timed(sharded, g, n, args.batch, 2, 0, draws)
+        draws += 2
+        ms5, timed_batches = g.core.phase_stats(reset=True)
+        g.set_option("phase_timing", 0)
+        if timed_batches:
+            names = ("tables_per_value", "score_and_sample",
+                     "handed_over_rows", "statistics",
+                     "group_set_and_caches")
+            breakdown = {name: 1e3 * ms / timed_batches
+                         for name, ms in zip(names, ms5)}
+            breakdown["unit"] = "us per sub-sweep (HIP events)"
+            breakdown["sub_sweeps_timed"] = timed_batches
+
     # the general-row configurations (any feature list the value-sorted
     # kernels do not take), exact and with scan sampling
     others = []
@@ -711,6 +731,16 @@ def run_rank(args):
                     "peak": SIMDS * CLOCK_GHZ,
                     "unit": "G SIMD-busy-cycles/s", "frac": valu_frac,
                     "hbm_frac": hbm_frac}
+        # essential / issued vector instructions of the value-sorted kernel:
+        # what the exact algorithm cannot do without is one packed add per
+        # entry, tile of 128 rows and pass, the total's pass starting at the
+        # tile's first own chunk (3/4 of K on average): 2 x K x 0.75
+        useful = None
+        if (usable and ctr.get("valu_instructions") and vs_batches
+                and not streamed and not narrow):
+            tiles = rows_per_launch / 128.0
+            useful = (1.5 * k * tiles) / (ctr["valu_instructions"] * scale)
+        roof["useful_frac"] = useful
         roof.update({
             "traffic": traffic,
             "algorithmic_bytes_per_row": bytes_per_row,
@@ -720,7 +750,7 @@ def run_rank(args):
             "avg_launch_ms": avg_ms if secs == secs else None,
             "launches": launches,
             "counters": (None if ctr is None else
-                         {"file": "profiles/r2_counters.json",
+                         {"file": "profiles/r3_counters.json",
                           "stale": ctr["stale"],
                           "rows_per_launch": ctr["rows_per_launch"]}),
             "timed_every": args.kernel_timing,
@@ -771,6 +801,7 @@ def run_rank(args):
                                    "sub-sweep"),
             },
             "roofline": roof,
+            "step_breakdown": breakdown,
             "batch_variants": variants,
             "other_configs": others,
         }

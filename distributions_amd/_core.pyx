@@ -200,6 +200,7 @@ cdef extern from "distributions_hip.h" nogil:
     size_t dist_gibbs_global_size(const dist_gibbs_t *)
     int dist_gibbs_debug_counts(dist_gibbs_t *, uint64_t *, size_t)
     int dist_gibbs_comm_stats(dist_gibbs_t *, double *, uint64_t *, int)
+    int dist_gibbs_phase_stats(dist_gibbs_t *, double *, uint64_t *, int)
     size_t dist_gibbs_float_delta_words(const dist_gibbs_t *)
     int dist_gibbs_batch_float_delta_dev(dist_gibbs_t *, double *)
     int dist_gibbs_batch_apply_float_delta_dev(dist_gibbs_t *, const double *)
@@ -1150,6 +1151,14 @@ cdef class GibbsEngine:
     def import_float_moments_dev(self, size_t ptr):
         check(dist_gibbs_import_float_moments_dev(self.ptr,
                                                   <const double *> ptr))
+
+    def phase_stats(self, reset=False):
+        """-> ([ms of tables, score+sample, handed-over rows, statistics,
+        group set + caches], sub-sweeps timed) with option phase_timing"""
+        cdef double ms[5]
+        cdef uint64_t n = 0
+        check(dist_gibbs_phase_stats(self.ptr, ms, &n, 1 if reset else 0))
+        return [ms[i] for i in range(5)], n
 
     def comm_stats(self, reset=False):
         """-> (ms, count) of the timed all-reduces of sweep_sharded"""

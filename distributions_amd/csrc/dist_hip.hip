@@ -1022,8 +1022,41 @@ struct Gibbs {
         comm_ev_free.pop_back();
         return e;
     }
+    // "phase_timing" = 1: HIP events at the phase boundaries of every
+    // device-normalised sub-sweep (tables | score+sample | handed-over rows |
+    // statistics | group set + caches): a diagnostic -- six events cost a
+    // sub-sweep some 20 us -- read by dist_gibbs_phase_stats
+    static constexpr int kPhases = 5;
+    int phase_timing = 0;
+    double phase_ms[kPhases] = {0, 0, 0, 0, 0};
+    uint64_t phase_batches = 0;
+    std::vector<std::vector<hipEvent_t>> phase_pending;
+    void phase_mark(int i) {
+        if (!phase_timing) return;
+        if (i == 0) phase_pending.emplace_back();
+        if (phase_pending.empty() || (int)phase_pending.back().size() != i)
+            return;   // (a path without all the marks: dropped below)
+        hipEvent_t e = comm_event();
+        HIP_CHECK(hipEventRecord(e, stream()));
+        phase_pending.back().push_back(e);
+    }
     // (call with the stream drained)
     void collect_comm_timing() {
+        for (auto & ev : phase_pending) {
+            if ((int)ev.size() == kPhases + 1) {
+                bool ok = true;
+                float ms[kPhases];
+                for (int i = 0; i < kPhases; ++i)
+                    ok = ok && hipEventElapsedTime(&ms[i], ev[i], ev[i + 1])
+                                   == hipSuccess;
+                if (ok) {
+                    for (int i = 0; i < kPhases; ++i) phase_ms[i] += ms[i];
+                    phase_batches += 1;
+                }
+            }
+            for (hipEvent_t e : ev) comm_ev_free.push_back(e);
+        }
+        phase_pending.clear();
         for (auto & pr : comm_ev_pending) {
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
@@ -1871,6 +1904,7 @@ struct Gibbs {
                                stream(), *P, T, self->deferred_count.p,
                                c->n_other);
             HIP_CHECK(hipGetLastError());
+            self->phase_mark(1);
             self->mark(self->ev0);
             // a launch that cannot fill the chip spreads out: a wave per
             // workgroup (no band tiles on such launches)
@@ -2020,6 +2054,7 @@ struct Gibbs {
                                T.lds_scores ? (size_t)T.Kpad * 4 : 0,
                                stream(), *P, T, self->deferred_count.p,
                                c->n_other);
+            self->phase_mark(1);
             hipLaunchKernelGGL((k_vs_scan_rows<KIND>), grid_for(n),
                                dim3(kBlock), 0, stream(), *P, T,
                                c->sorted_rows.p, n, self->deferred.p,
@@ -2058,11 +2093,14 @@ struct Gibbs {
         default: L.go<DIST_BB>(); break;
         }
         scan_batches += 1;
+        phase_mark(2);
         launch_deferred(P);
+        phase_mark(3);
     }
 
     void sample_value_sorted(SweepParams & P) {
         VsCache & c = vs_get(P.row_begin, P.row_end);
+        phase_mark(0);
         if (sampling_mode == 1) return sample_value_scan(P, c);
         if (use_stream(c)) return sample_value_stream(P, c);
         const size_t n = P.row_end - P.row_begin;
@@ -2146,7 +2184,9 @@ struct Gibbs {
                 fclose(f);
             }
         }
+        phase_mark(2);
         launch_deferred(P);
+        phase_mark(3);
     }
     struct DeferredLaunch {
         SweepParams * P;
@@ -3017,7 +3057,9 @@ struct Gibbs {
             for (size_t b = r0; b < r1; b += batch) {
                 async_sample(b, std::min(r1, b + batch), seed, draw_base);
                 apply_ints(live_image());
+                phase_mark(4);
                 batch_finish_device();
+                phase_mark(5);
             }
         } catch (...) {
             async_end(true);
@@ -4395,6 +4437,9 @@ int dist_gibbs_set_option(dist_gibbs_t * g, const char * name, int value) {
         } else if (key == "sampling") {
             DIST_REQUIRE(value == 0 || value == 1, "sampling: 0 exact, 1 scan");
             g->impl->sampling_mode = value;
+        } else if (key == "phase_timing") {
+            DIST_REQUIRE(value == 0 || value == 1, "phase_timing: 0 or 1");
+            g->impl->phase_timing = value;
         } else if (key == "float_stats") {
             DIST_REQUIRE(value == 0 || value == 1,
                          "float_stats: 0 ordered, 1 merged");
@@ -4454,6 +4499,19 @@ int dist_gibbs_debug_counts(dist_gibbs_t * g, uint64_t * out, size_t n) {
             v[5] = d;
         }
         for (size_t i = 0; i < n && i < 13; ++i) out[i] = v[i];
+    });
+}
+int dist_gibbs_phase_stats(dist_gibbs_t * g, double ms_out[5],
+                           uint64_t * batches_out, int reset) {
+    return guarded([&] {
+        Gibbs & e = *g->impl;   // (settles an open run: its events are read)
+        e.collect_comm_timing();
+        for (int i = 0; i < Gibbs::kPhases; ++i) ms_out[i] = e.phase_ms[i];
+        *batches_out = e.phase_batches;
+        if (reset) {
+            for (int i = 0; i < Gibbs::kPhases; ++i) e.phase_ms[i] = 0.0;
+            e.phase_batches = 0;
+        }
     });
 }
 int dist_gibbs_comm_stats(dist_gibbs_t * g, double * ms_out,

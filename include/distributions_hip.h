@@ -492,6 +492,13 @@ int dist_gibbs_path_counts(const dist_gibbs_t * g, uint64_t * value_sorted,
  * took the small-launch kernel, batches through k_rows_scratch, batches with
  * folded leading features (first min(n, 11) entries are written) */
 int dist_gibbs_debug_counts(dist_gibbs_t * g, uint64_t * out, size_t n);
+/* "phase_timing" = 1 (a diagnostic: six events per sub-sweep): HIP-event time
+ * (ms, summed) of the five phases of the device-normalised value-sorted
+ * sub-sweeps since the last reset -- the per-value tables, the score+sample
+ * kernel, the handed-over rows, the statistics, the group set and caches --
+ * and how many sub-sweeps were timed */
+int dist_gibbs_phase_stats(dist_gibbs_t * g, double ms_out[5],
+                           uint64_t * batches_out, int reset);
 /* HIP-event time (ms) and count of the all-reduces dist_gibbs_sweep_sharded
  * timed (every "kernel_timing"-th sub-sweep) since the last reset */
 int dist_gibbs_comm_stats(dist_gibbs_t * g, double * ms_out,
