@@ -105,6 +105,9 @@ def parse():
                     metavar="NAME=VALUE",
                     help="any other engine option (dist_gibbs_set_option), "
                          "e.g. rows_scratch=0; repeatable")
+    ap.add_argument("--no-breakdown", action="store_true",
+                    help="skip the diagnostic pass behind `step_breakdown` "
+                         "(two sweeps with events at the phase boundaries)")
     ap.add_argument("--torch-collectives", action="store_true",
                     help="keep the per-batch all-reduce on torch.distributed "
                          "instead of the library's own RCCL communicator")
@@ -574,6 +577,30 @@ def run_rank(args):
     narrow = g.core.debug_counts()["narrow_batches"]
     scratched = g.core.debug_counts()["scratch_batches"]
     draws = args.warmup + args.steps
+    groups_at_end = len(g)
+    comm_ms, comm_count = (g.core.comm_stats() if native_comm else (0.0, 0))
+
+    # where a sub-sweep's time goes: two more sweeps with events at the phase
+    # boundaries (a diagnostic pass of its own: the events cost some 20 us a
+    # sub-sweep, so the line's `value` is not measured with them)
+    breakdown = None
+    if (rank == 0 and world == 1 and vs_batches and not args.force_collective
+            and not args.no_breakdown):
+        g.set_option("phase_timing", 1)
+        g.core.phase_stats(reset=True)
+        timed(sharded, g, n, args.batch, 2, 0, draws)
+        draws += 2
+        ms5, timed_batches = g.core.phase_stats(reset=True)
+        g.set_option("phase_timing", 0)
+        if timed_batches:
+            names = ("tables_per_value", "score_and_sample",
+                     "handed_over_rows", "statistics",
+                     "group_set_and_caches")
+            breakdown = {name: 1e3 * ms / timed_batches
+                         for name, ms in zip(names, ms5)}
+            breakdown["unit"] = "us per sub-sweep (HIP events)"
+            breakdown["sub_sweeps_timed"] = timed_batches
+
 
     # the same job at other sub-sweep sizes (value depends on it: the
     # per-batch kernels and launch gaps do not shrink with the batch)
@@ -597,28 +624,6 @@ def run_rank(args):
             "ms_per_step": 1e3 * dt_b / steps_b, "steps": steps_b,
             "kernel": took[0] if took else "k_sweep_sample",
             "kernel_avg_launch_ms": ms_b / max(launches_b, 1)})
-
-    comm_ms, comm_count = (g.core.comm_stats() if native_comm else (0.0, 0))
-
-    # where a sub-sweep's time goes: two more sweeps with events at the phase
-    # boundaries (a diagnostic pass of its own: the events cost some 20 us a
-    # sub-sweep, so the line's `value` is not measured with them)
-    breakdown = None
-    if rank == 0 and world == 1 and vs_batches and not args.force_collective:
-        g.set_option("phase_timing", 1)
-        g.core.phase_stats(reset=True)
-        timed(sharded, g, n, args.batch, 2, 0, draws)
-        draws += 2
-        ms5, timed_batches = g.core.phase_stats(reset=True)
-        g.set_option("phase_timing", 0)
-        if timed_batches:
-            names = ("tables_per_value", "score_and_sample",
-                     "handed_over_rows", "statistics",
-                     "group_set_and_caches")
-            breakdown = {name: 1e3 * ms / timed_batches
-                         for name, ms in zip(names, ms5)}
-            breakdown["unit"] = "us per sub-sweep (HIP events)"
-            breakdown["sub_sweeps_timed"] = timed_batches
 
     # the general-row configurations (any feature list the value-sorted
     # kernels do not take), exact and with scan sampling
@@ -787,6 +792,7 @@ def run_rank(args):
                                          args.d, args.batch),
                 "rows_per_gpu": n, "groups": k, "dim": args.dim,
                 "batch_rows": args.batch,
+                "groups_at_end_of_timed_region": groups_at_end,
                 "parallelism": "rows sharded over %d GPU(s), all-reduce of "
                                "statistic deltas per sub-sweep" % world,
                 "collectives": ("none" if not sharded_collective(

@@ -2412,8 +2412,11 @@ struct Gibbs {
                            by_pos ? old_row.p : old_packed.p,
                            by_pos ? new_row.p : new_packed.p, merge_stage.p);
         HIP_CHECK(hipGetLastError());
-        LAUNCH(k_merge_float_reduce, (size_t)L.words, merge_stage.p,
-               (int)blocks, L.words, merge_image.p);
+        hipLaunchKernelGGL(k_merge_float_reduce,
+                           dim3((unsigned)((L.words + 63) / 64)), dim3(64), 0,
+                           stream(), merge_stage.p, (int)blocks, L.words,
+                           merge_image.p);
+        HIP_CHECK(hipGetLastError());
     }
     void merge_float_apply(const double * image, bool reset = false) {
         const MergeLayout L = merge_layout();
@@ -2631,8 +2634,11 @@ struct Gibbs {
                     // (a zero-length segment never matches a word)
                     push(img.cnt[f], (size_t)K() * feats[f]->dim());
                 }
-                LAUNCH(k_stage_reduce, (size_t)L.words, seg, vs_stage.p,
-                       (int)blocks, L.words);
+                hipLaunchKernelGGL(k_stage_reduce,
+                                   dim3((unsigned)((L.words + 63) / 64)),
+                                   dim3(64), 0, stream(), seg, vs_stage.p,
+                                   (int)blocks, L.words);
+                HIP_CHECK(hipGetLastError());
                 staged_applies += 1;
                 return;
             }

@@ -4232,7 +4232,15 @@ __global__ void k_stage_reduce(WordSegments seg,
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= words) return;
     int32_t d = 0;
-    for (int r = 0; r < rows; ++r) d += stage[(size_t)r * words + i];
+    int r = 0;
+    for (; r + 8 <= rows; r += 8) {   // eight loads in flight
+        int32_t v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = stage[(size_t)(r + q) * words + i];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) d += v[q];
+    }
+    for (; r < rows; ++r) d += stage[(size_t)r * words + i];
     if (d == 0) return;
     int j = 0;
     while ((unsigned long long)i >= seg.end[j]) ++j;
@@ -4303,7 +4311,15 @@ __global__ void k_merge_float_reduce(const double * __restrict__ stage,
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= words) return;
     double d = 0.0;
-    for (int r = 0; r < rows; ++r) d += stage[(size_t)r * words + i];
+    int r = 0;
+    for (; r + 8 <= rows; r += 8) {   // eight loads in flight, added in order
+        double v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = stage[(size_t)(r + q) * words + i];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) d += v[q];
+    }
+    for (; r < rows; ++r) d += stage[(size_t)r * words + i];
     image[i] = d;
 }
 // a replica's float statistics AS such an image (count, sum x, sum x^2;

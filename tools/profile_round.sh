@@ -11,7 +11,7 @@ out=gpurun_out/$tag
 mkdir -p $out
 repo=$PWD
 cd /tmp && export TMPDIR=/tmp && cd $repo
-B="bench.py --cpu-rows 0 --other-batches= --other-configs="
+B="bench.py --cpu-rows 0 --other-batches= --other-configs= --no-breakdown"
 SQ="SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY"
 
 # one configuration: trace (+ timeline of a sub-sweep), SQ / FETCH / WRITE
@@ -20,6 +20,9 @@ profile() {
   name=$1; anchor=$2; shift 2
   rocprofv3 --kernel-trace --stats --output-format csv -d $out/t_$name -- python3 $B --steps 3 --warmup 2 "$@" > $out/bench_${name}_under_rocprof.json 2> $out/t_$name.log
   cp $(ls $out/t_$name/*/*kernel_stats.csv | head -1) $out/kernel_stats_$name.csv
+  rm -rf $out/t_$name
+  # (the sequence of one sub-sweep from a trace of its own: --stats perturbs)
+  rocprofv3 --kernel-trace --output-format csv -d $out/t_$name -- python3 $B --steps 3 --warmup 2 "$@" > /dev/null 2>&1
   python3 tools/batch_timeline.py $out/t_$name "$anchor" > $out/timeline_$name.txt 2>/dev/null
   for pass in SQ FETCH_SIZE WRITE_SIZE; do
     ctr=$pass; [ $pass = SQ ] && ctr="$SQ"
