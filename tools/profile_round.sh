@@ -49,8 +49,11 @@ python3 tools/counters.py $out/counters.json \
        $out/p_c2_b65536_SQ $out/p_c5_SQ $out/p_c5_FETCH_SIZE $out/p_c5_WRITE_SIZE \
        $out/p_c3_SQ $out/p_c3_FETCH_SIZE $out/p_c3_WRITE_SIZE > $out/counters.log 2>&1
 rm -rf $out/p_* $out/p.log
-# the bench line of record (with the CPU baseline), the other configurations
-python3 bench.py 2> $out/bench.log | tail -1 > $out/bench.json
+# bench.py looks the counters up under profiles/ (keyed by the sources' hash)
+cp $out/counters.json profiles/${tag}_counters.json
+# the bench line of record (the driver's command, with the CPU baseline), the
+# other configurations
+python3 bench.py --gpus 1 --steps 20 --warmup 5 2> $out/bench.log | tail -1 > $out/bench.json
 : > $out/bench_other_configs.jsonl
 for c in nich gp bb dd16; do
   python3 $B --steps 3 --warmup 1 --config $c 2>/dev/null | tail -1 >> $out/bench_other_configs.jsonl
