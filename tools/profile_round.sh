@@ -64,5 +64,5 @@ python3 $B --steps 10 --values zipf 2>/dev/null | tail -1 >> $out/bench_other_co
 python3 $B --steps 10 --d 0 2>/dev/null | tail -1 >> $out/bench_other_configs.jsonl
 python3 $B --steps 10 --opt sampling=1 2>/dev/null | tail -1 >> $out/bench_other_configs.jsonl
 python3 $B --steps 10 --batch 65536 --opt sampling=1 2>/dev/null | tail -1 >> $out/bench_other_configs.jsonl
-python3 $B --force-collective 2>/dev/null | tail -1 > $out/bench_collective_one_rank.json
+python3 $B --steps 20 --warmup 5 --force-collective 2>/dev/null | tail -1 > $out/bench_collective_one_rank.json
 ls -la $out
