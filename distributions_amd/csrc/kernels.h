@@ -2649,7 +2649,11 @@ __device__ __forceinline__ void vs_sum_and_scan(
         uniform_fp lp, const float * lp_vec, uniform_fp prefix, int K,
         const int (&g)[kVsR],
         const float (&l_own)[kVsR], const float (&u)[kVsR],
-        const bool (&active)[kVsR], int (&found)[kVsR]) {
+        const bool (&active)[kVsR], int (&found)[kVsR]
+#ifdef DIST_VS_STAMPS
+        , int & chunks_done
+#endif
+        ) {
     int gchunk[kVsR], gpiece[kVsR];
 #pragma unroll
     for (int r = 0; r < kVsR; ++r) {
@@ -2677,6 +2681,9 @@ __device__ __forceinline__ void vs_sum_and_scan(
          ++c, k0 += kVsUnroll) {
         float l[kVsUnroll];
         vs_fetch_chunk(lp, k0, l);
+#ifdef DIST_VS_STAMPS
+        ++chunks_done;
+#endif
         if (__any(gchunk[0] == c || gchunk[1] == c)) {
             // own slots of a group-sorted tile are neighbours: only the
             // eight-entry pieces that hold one take the per-lane select
@@ -2710,6 +2717,9 @@ __device__ __forceinline__ void vs_sum_and_scan(
     for (int c = 0, k0 = 0; k0 < K; ++c, k0 += kVsUnroll) {
         float l[kVsUnroll];
         vs_fetch_chunk(lp, k0, l);
+#ifdef DIST_VS_STAMPS
+        ++chunks_done;
+#endif
         if (__any(gchunk[0] == c || gchunk[1] == c)) {
 #pragma unroll
             for (int b = 0; b < kVsUnroll / 8; ++b) {
@@ -2795,6 +2805,7 @@ void k_vs_sample(
     // with a band tile everything else
 #ifdef DIST_VS_STAMPS   // diagnostic build only (make stamps): costs 3 us
     unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0;
+    int chunks_done = 0;   // chunks of both recurrences, both vectors
     if (T.stamps) st0 = __builtin_amdgcn_s_memtime();
 #endif
     const bool band = id < n_band_ids;
@@ -2875,7 +2886,11 @@ void k_vs_sample(
         vs_sum_and_scan(as_uniform(vec), vec,
                         T.PA ? as_uniform(T.PA + (size_t)x
                                           * (T.Kpad / kVsUnroll)) : nullptr,
-                        K, g, l_own, u, inA, f);
+                        K, g, l_own, u, inA, f
+#ifdef DIST_VS_STAMPS
+                        , chunks_done
+#endif
+                        );
 #pragma unroll
         for (int r = 0; r < kVsR; ++r) g2[r] = inA[r] ? f[r] : g2[r];
     }
@@ -2888,7 +2903,11 @@ void k_vs_sample(
         vs_sum_and_scan(as_uniform(vec), vec,
                         T.PB ? as_uniform(T.PB + (size_t)x
                                           * (T.Kpad / kVsUnroll)) : nullptr,
-                        K, g, l_own, u, inB, f);
+                        K, g, l_own, u, inB, f
+#ifdef DIST_VS_STAMPS
+                        , chunks_done
+#endif
+                        );
 #pragma unroll
         for (int r = 0; r < kVsR; ++r) g2[r] = inB[r] ? f[r] : g2[r];
     }
@@ -2912,7 +2931,8 @@ void k_vs_sample(
         out[5] = (unsigned long long)__builtin_amdgcn_s_getreg(
                      (4 << 0) | (0 << 6) | (31 << 11))
                | ((unsigned long long)__builtin_amdgcn_s_getreg(
-                     (20 << 0) | (0 << 6) | (3 << 11)) << 32);
+                     (20 << 0) | (0 << 6) | (3 << 11)) << 32)
+               | ((unsigned long long)chunks_done << 40);
     }
 #endif
 }

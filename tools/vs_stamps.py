@@ -23,6 +23,7 @@ def report(path):
     sh = ((hw >> 12) & 1).astype(np.int64)
     se = ((hw >> 13) & 7).astype(np.int64)
     xcc = ((hw >> 32) & 15).astype(np.int64)
+    chunks = (hw >> 40).astype(np.int64)   # chunks of 32 links the wave ran
     # s_memtime bases differ between CUs: times relative to the first wave of
     # the LAST launch on the same CU (a wave with nothing to do leaves the
     # stamps of an older launch behind)
@@ -33,8 +34,8 @@ def report(path):
         recent = m & (st[:, 0] >= st[m, 0].max() - 100_000)
         st[recent] -= st[recent, 0].min()
         keep |= recent
-    st, hw, simd, cu, sh, se, xcc = (v[keep] for v in (st, hw, simd, cu, sh,
-                                                       se, xcc))
+    st, hw, simd, cu, sh, se, xcc, chunks = (
+        v[keep] for v in (st, hw, simd, cu, sh, se, xcc, chunks))
     key = (((xcc * 8 + se) * 2 + sh) * 16 + cu) * 4 + simd
     span = st[:, 4].max()
     print("%d waves on %d XCDs, launch spans %d cycles" % (
@@ -67,6 +68,26 @@ def report(path):
     print("  sum of wave lifetimes per SIMD / span: min %.2f median %.2f max "
           "%.2f" % (work.min() / span, np.median(work) / span,
                     work.max() / span))
+    if chunks.any():
+        # is the span the heaviest SIMD's work?
+        load = np.bincount(inv, weights=chunks)
+        cukeys, cuinv = np.unique(keys // 4, return_inverse=True)
+        cuload = np.bincount(cuinv, weights=load)
+        cuend = np.zeros(len(cukeys), np.int64)
+        np.maximum.at(cuend, cuinv, end)
+        print("  chunks per wave: mean %.1f min %d max %d; per SIMD: mean %.0f "
+              "min %d max %d; per CU: mean %.0f min %d max %d" % (
+                  chunks.mean(), chunks.min(), chunks.max(), load.mean(),
+                  load.min(), load.max(), cuload.mean(), cuload.min(),
+                  cuload.max()))
+        print("  corr(SIMD finish, SIMD chunks) %.2f  corr(CU finish, CU "
+              "chunks) %.2f  corr(SIMD finish, its CU's chunks) %.2f" % (
+                  np.corrcoef(end, load)[0, 1],
+                  np.corrcoef(cuend, cuload)[0, 1],
+                  np.corrcoef(end, cuload[cuinv])[0, 1]))
+        slope = np.polyfit(cuload, cuend, 1)
+        print("  CU finish ~ %.0f + %.1f cycles per chunk of that CU" % (
+            slope[1], slope[0]))
     grid = np.linspace(0, span, 11)
     alive = [(int(((st[:, 0] <= t) & (st[:, 4] > t)).sum())) for t in grid]
     print("  waves alive at 0%..100% of the span:", alive)
