@@ -785,7 +785,7 @@ struct Gibbs {
     DeviceBuf<int2> struct_moves;           // {dst, src} slot copies
     // ordered replay of float statistics: events sorted stably by group
     DeviceBuf<uint32_t> ev_keys, ev_vals, ev_keys_sorted, ev_vals_sorted;
-    DeviceBuf<uint32_t> seg_begin, seg_end;
+    DeviceBuf<uint32_t> seg_begin;   // [begin | end] of every group's events
     DeviceBuf<unsigned char> sort_temp;
     DeviceBuf<uint32_t> pow_lo, pow_hi;   // 16807^i, 16807^(4096 i) mod 2^31-1
     uint32_t n_pow_hi = 0;
@@ -2301,27 +2301,31 @@ struct Gibbs {
         while ((1ull << bits) < Kn + 1) bits += 1;
         ev_keys.reserve(n_ev, 0); ev_vals.reserve(n_ev, 0);
         ev_keys_sorted.reserve(n_ev, 0); ev_vals_sorted.reserve(n_ev, 0);
-        seg_begin.reserve(grow_capacity(Kn + 1), 0);
-        seg_end.reserve(grow_capacity(Kn + 1), 0);
+        // (begin | end in one buffer: one fill)
+        seg_begin.reserve(grow_capacity(2 * (Kn + 1)), 0);
+        uint32_t * const seg_end_p = seg_begin.p + (Kn + 1);
         const size_t tb = sort_pairs_temp_bytes(n_ev, bits);
         sort_temp.reserve(tb + 256, 0);
         LAUNCH(k_replay_events, n_rows, old_dev, new_dev, n_rows,
                (uint32_t)Kn, ev_keys.p, ev_vals.p);
         sort_pairs(sort_temp.p, tb, ev_keys.p, ev_keys_sorted.p, ev_vals.p,
                    ev_vals_sorted.p, n_ev, bits, stream());
-        HIP_CHECK(hipMemsetAsync(seg_begin.p, 0, (Kn + 1) * 4, stream()));
-        HIP_CHECK(hipMemsetAsync(seg_end.p, 0, (Kn + 1) * 4, stream()));
+        HIP_CHECK(hipMemsetAsync(seg_begin.p, 0, 2 * (Kn + 1) * 4, stream()));
         LAUNCH(k_replay_bounds, n_ev, ev_keys_sorted.p, n_ev, seg_begin.p,
-               seg_end.p);
+               seg_end_p);
+        ReplayFeatures R;
+        R.n = 0;
         for (int f = 0; f < F(); ++f) {
             if (!has_float_stats(feats[f]->sh.kind)) continue;
             DIST_REQUIRE(vals[f], "replay: no values for an ordered feature");
-            hipLaunchKernelGGL(k_replay_sorted, dim3((unsigned)Kn), dim3(64),
-                               0, stream(), feats[f]->view(), vals[f],
-                               row_begin, ev_vals_sorted.p, seg_begin.p,
-                               seg_end.p);
-            HIP_CHECK(hipGetLastError());
+            R.s[R.n] = feats[f]->view();
+            R.values[R.n] = vals[f];
+            R.n += 1;
         }
+        hipLaunchKernelGGL(k_replay_sorted, dim3((unsigned)Kn, (unsigned)R.n),
+                           dim3(64), 0, stream(), R, row_begin,
+                           ev_vals_sorted.p, seg_begin.p, seg_end_p);
+        HIP_CHECK(hipGetLastError());
     }
     // Multi-rank exchange of the order-dependent statistics: the moves of the
     // open batch in row order (slot indices of the batch snapshot) ...

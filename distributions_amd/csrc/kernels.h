@@ -4449,11 +4449,20 @@ __global__ void k_replay_bounds(const uint32_t * __restrict__ keys_sorted,
 // one wave per group: 64 events are fetched at a time (coalesced ids, gathered
 // values) and then applied one after the other, every lane computing the same
 // scalar update (nich.hpp:125-165 / gp.hpp:109-135)
+// (blockIdx.y: the ordered feature -- they replay side by side, the longest
+// chain sets the launch's time)
+struct ReplayFeatures {
+    int n;
+    SlaveView s[kMaxF];
+    const uint32_t * values[kMaxF];
+};
 __global__ __launch_bounds__(64) void k_replay_sorted(
-        SlaveView s, const uint32_t * __restrict__ values, size_t row_begin,
+        ReplayFeatures R, size_t row_begin,
         const uint32_t * __restrict__ vals_sorted,
         const uint32_t * __restrict__ seg_begin,
         const uint32_t * __restrict__ seg_end) {
+    const SlaveView & s = R.s[blockIdx.y];
+    const uint32_t * __restrict__ values = R.values[blockIdx.y];
     const int k = blockIdx.x;
     const int lane = threadIdx.x;
     const uint32_t lo = seg_begin[k], hi = seg_end[k];
