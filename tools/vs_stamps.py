@@ -88,6 +88,17 @@ def report(path):
         slope = np.polyfit(cuload, cuend, 1)
         print("  CU finish ~ %.0f + %.1f cycles per chunk of that CU" % (
             slope[1], slope[0]))
+    if chunks.any():
+        # cycles of the two vector phases per chunk, by the tile's chunk count
+        dur = (st[:, 3] - st[:, 1]).astype(np.float64)
+        per = dur / np.maximum(chunks, 1)
+        print("  vector phases per chunk: p10 %.0f median %.0f p90 %.0f p99 "
+              "%.0f cycles; waves above 2x the median: %d (%.1f %% of the "
+              "vector-phase time)" % (
+                  np.percentile(per, 10), np.median(per),
+                  np.percentile(per, 90), np.percentile(per, 99),
+                  int((per > 2 * np.median(per)).sum()),
+                  100.0 * dur[per > 2 * np.median(per)].sum() / dur.sum()))
     grid = np.linspace(0, span, 11)
     alive = [(int(((st[:, 0] <= t) & (st[:, 4] > t)).sum())) for t in grid]
     print("  waves alive at 0%..100% of the span:", alive)
@@ -112,8 +123,15 @@ def run(batch=1_000_000):
     dev = torch.device("cuda", 0)
     gen = torch.Generator(device=dev)
     gen.manual_seed(1)
-    col = torch.randint(0, dim, (n,), generator=gen, device=dev,
-                        dtype=torch.int32)
+    if os.environ.get("DIST_STAMPS_VALUES") == "zipf":   # bench.py --values zipf
+        w = 1.0 / torch.arange(1, dim + 1, device=dev,
+                               dtype=torch.float64) ** 1.1
+        cdf = torch.cumsum(w / w.sum(), 0).to(torch.float32)
+        u = torch.rand((n,), generator=gen, device=dev)
+        col = torch.searchsorted(cdf, u).clamp_(max=dim - 1).to(torch.int32)
+    else:
+        col = torch.randint(0, dim, (n,), generator=gen, device=dev,
+                            dtype=torch.int32)
     assign = torch.arange(n, device=dev, dtype=torch.int64).remainder(k).to(
         torch.int32)
     g = engine.Gibbs(1.0, 0.2, [engine.dd_shared([0.5] * dim)])
