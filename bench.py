@@ -547,6 +547,7 @@ def run_rank(args):
         t0 = time.perf_counter()
         for i in range(steps):
             step(warmup + i)
+        timed.host_enqueue_s = time.perf_counter() - t0
         # the host's copy of the group set is part of the job: a sweep may
         # leave it to be pulled on demand (device-normalised runs stay open),
         # so it is demanded here, inside the timed region
@@ -571,6 +572,7 @@ def run_rank(args):
         column_host = columns[0][:min(args.cpu_rows, n)].cpu().numpy()
 
     dt = timed(sharded, g, n, args.batch, args.steps, args.warmup, 0)
+    host_enqueue_ms = 1e3 * timed.host_enqueue_s / max(args.steps, 1)
     ms, launches, rows = g.kernel_stats()
     vs_batches, generic_batches = g.path_counts()
     streamed = g.core.debug_counts()["stream_batches"]
@@ -622,6 +624,7 @@ def run_rank(args):
         variants.append({
             "batch_rows": b, "value": float(n) * world * steps_b / dt_b,
             "ms_per_step": 1e3 * dt_b / steps_b, "steps": steps_b,
+            "host_enqueue_ms_per_step": 1e3 * timed.host_enqueue_s / steps_b,
             "kernel": took[0] if took else "k_sweep_sample",
             "kernel_avg_launch_ms": ms_b / max(launches_b, 1)})
 
@@ -780,6 +783,8 @@ def run_rank(args):
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps,
+            # (the host's share: what queueing a step's launches took it)
+            "host_enqueue_ms_per_step": host_enqueue_ms,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,

@@ -797,6 +797,8 @@ struct Gibbs {
     DeviceBuf<int> row_size;
 
     size_t batch_begin = 0, batch_end = 0;   // rows of the open batch
+    uint32_t batch_seed = 0;                 // ... and its entropy
+    uint64_t batch_draw_base = 0;
     bool batch_open = false;
     bool batch_value_sorted = false;
     bool moves_in_row_order = false;   // old_row/new_row hold the open batch
@@ -827,6 +829,9 @@ struct Gibbs {
         bool one_chunk_per_value = false;  // every value's rows in ONE chunk
         bool mixed_chunks = false;         // some chunks hold several values
         DeviceBuf<uint32_t> val_start;    // [nvals + 1] first position per value
+        DeviceBuf<uint32_t> chunk_first;  // [nvals + 1] first chunk per value
+        // rows handed over per chunk (VsDefer): zero between batches
+        DeviceBuf<uint32_t> def_counts;
         DeviceBuf<uint32_t> other_pos;    // positions the tiles do not cover
         uint32_t n_other = 0;
         uint32_t n_values_present = 0;    // values with at least one row
@@ -980,8 +985,26 @@ struct Gibbs {
     // buffers with it; the kernels read the group count from dev_state) and
     // the host mirrors (py.counts, tracker) are stale; sweep_async pulls the
     // state back before it returns.
+    // (two slots: k_vs_tables reads one and writes the other, dev_cur says
+    // which one holds the state of record)
     DeviceBuf<DevState> dev_state;
+    int dev_cur = 0;
+    DevState * dev_ptr() const { return dev_state.p + dev_cur; }
     DeviceBuf<int32_t> snap_counts;   // group sizes at batch entry
+    // The fused launch between two batches (k_vs_tables: group set, caches
+    // and per-value tables in one kernel) reads the per-group statistics from
+    // one set of buffers and writes them, normalised, to another: these are
+    // the other set (swapped with the live ones after every such launch).
+    DeviceBuf<int32_t> alt_counts, alt_i0, alt_i1, alt_snap;
+    // 0: k_normalise + k_batch_finish + k_vs_prepare as three launches (and
+    // the handed-over rows as a fourth); 1 (default): k_vs_tables, the
+    // handed-over rows inside k_vs_apply
+    int fused_tables_mode = 1;
+    uint64_t fused_batches = 0;
+    // the open device-normalised run's last batch left its group set to the
+    // next k_vs_tables (or to finish_pending())
+    bool finish_pending = false;
+    bool batch_fused = false;   // the open batch went through k_vs_tables
     bool async_active = false;
     // 0 never, 1 where it applies (2: the same; default)
     int device_normalise_mode = 2;
@@ -1154,7 +1177,7 @@ struct Gibbs {
         ensure_pow_tables(r1 - r0);
         P.pow_lo = pow_lo.p;
         P.pow_hi = pow_hi.p;
-        P.dev = async_active ? dev_state.p : nullptr;
+        P.dev = async_active ? dev_ptr() : nullptr;
         return P;
     }
 
@@ -1820,15 +1843,13 @@ struct Gibbs {
                                        std::min<uint32_t>(64 * kVsR,
                                                           h[x] - off)});
         c->n_tiles = (uint32_t)tiles.size();
-        c->tiles.upload(tiles.data(), tiles.size());
+        std::vector<VsTile> narrow;
         if (c->n_tiles < kVsNarrowBelowTiles || narrow_mode == 2) {
-            std::vector<VsTile> narrow;
             for (uint32_t x = 0; x < nv; ++x)
                 for (uint32_t off = 0; off < h[x]; off += 64)
                     narrow.push_back(VsTile{x, start[x] + off,
                                             std::min<uint32_t>(64, h[x] - off)});
             c->n_narrow_tiles = (uint32_t)narrow.size();
-            c->narrow_tiles.upload(narrow.data(), narrow.size());
         }
         for (uint32_t x = 0; x < nv; ++x) c->n_values_present += h[x] != 0;
         // apply work items: up to kVsApplyRows rows of one value -- or, where
@@ -1861,6 +1882,31 @@ struct Gibbs {
             if (h[x] > (uint32_t)kVsApplyRows) c->one_chunk_per_value = false;
         for (auto & ch : chunks) c->mixed_chunks |= ch.x == kVsMixedChunk;
         c->chunks.upload(chunks.data(), chunks.size());
+        // every tile's rows lie in one chunk (both lists ascend in position)
+        auto set_chunks = [&](std::vector<VsTile> & list) {
+            uint32_t ci = 0;
+            for (auto & t : list) {
+                while (ci + 1 < chunks.size()
+                       && chunks[ci].pos + chunks[ci].n <= t.pos) ++ci;
+                t.chunk = ci;
+            }
+        };
+        set_chunks(tiles);
+        set_chunks(narrow);
+        c->tiles.upload(tiles.data(), tiles.size());
+        if (!narrow.empty())
+            c->narrow_tiles.upload(narrow.data(), narrow.size());
+        {
+            std::vector<uint32_t> first(nv + 1, 0);
+            uint32_t ci = 0;
+            for (uint32_t x = 0; x <= nv; ++x) {
+                while (ci < chunks.size()
+                       && chunks[ci].pos + chunks[ci].n <= start[x]) ++ci;
+                first[x] = ci;   // (the chunk that holds the value's first row)
+            }
+            c->chunk_first.upload(first.data(), first.size());
+        }
+        c->def_counts.reserve(std::max<size_t>(chunks.size(), 1), 0);   // zeros
         // rows whose value is outside the table: generic kernel, by position
         c->n_other = h[nv];
         if (c->n_other) {
@@ -1896,14 +1942,20 @@ struct Gibbs {
         VsCache * c;
         VsTables T;
         bool narrow;
+        bool fused;
         template <int KIND>
         void go() {
             const uint32_t nv = (uint32_t)self->vs_nvals();
-            hipLaunchKernelGGL((k_vs_prepare<KIND>), dim3(nv), dim3(kBlock),
-                               T.PA ? (size_t)T.Kpad * 8 : 0,
-                               stream(), *P, T, self->deferred_count.p,
-                               c->n_other);
+            if (fused)
+                self->launch_tables<KIND>(*P, T);
+            else
+                hipLaunchKernelGGL((k_vs_prepare<KIND>), dim3(nv), dim3(kBlock),
+                                   T.PA ? (size_t)T.Kpad * 8 : 0,
+                                   stream(), *P, T, self->deferred_count.p,
+                                   c->n_other);
             HIP_CHECK(hipGetLastError());
+            const VsDefer D{self->deferred.p, self->deferred_count.p,
+                            fused ? c->def_counts.p : nullptr, c->chunks.p};
             self->phase_mark(1);
             self->mark(self->ev0);
             // a launch that cannot fill the chip spreads out: a wave per
@@ -1917,8 +1969,7 @@ struct Gibbs {
                 hipLaunchKernelGGL(                                          \
                     (k_vs_narrow<KIND, HQ>), dim3(c->n_narrow_tiles),        \
                     dim3(64), lds, stream(), *P, T, c->narrow_tiles.p,       \
-                    c->n_narrow_tiles, c->sorted_rows.p, self->deferred.p,   \
-                    self->deferred_count.p)
+                    c->n_narrow_tiles, c->sorted_rows.p, D)
                 const bool whole =
                     self->narrow_read_ahead
                         ? self->narrow_read_ahead == 8
@@ -1942,18 +1993,85 @@ struct Gibbs {
             if (c->n_tiles && small)
                 hipLaunchKernelGGL((k_vs_sample<KIND, 64>), grid, dim3(64), 0,
                                    stream(), *P, T, c->tiles.p, c->n_tiles,
-                                   band_ids, c->sorted_rows.p,
-                                   self->deferred.p, self->deferred_count.p);
+                                   band_ids, c->sorted_rows.p, D);
             else if (c->n_tiles)   // else every value lies beyond the table
                 hipLaunchKernelGGL((k_vs_sample<KIND, kVsSampleBlock>), grid,
                                    dim3(kVsSampleBlock), 0,
                                    stream(), *P, T, c->tiles.p, c->n_tiles,
-                                   band_ids, c->sorted_rows.p,
-                                   self->deferred.p, self->deferred_count.p);
+                                   band_ids, c->sorted_rows.p, D);
             HIP_CHECK(hipGetLastError());
             self->mark(self->ev1);
         }
     };
+    // May this batch of the open device-normalised run take the fused launch
+    // (k_vs_tables; the handed-over rows inside k_vs_apply)?  Its LDS holds
+    // four words per group; k_vs_apply must be the sorting form with a staging
+    // matrix (its sort buffers are the handed-over rows' strips, and
+    // k_vs_reduce writes what the fused launch reads).
+    bool fused_ok(const VsCache & c, int Kpad) const {
+        if (!fused_tables_mode || !async_active || sampling_mode != 0)
+            return false;
+        if (Kpad > 8192 || c.mixed_chunks || any_float_stats()) return false;
+        const size_t lds_sort =
+            ((size_t)K() * 2 + kVsApplyBlock / 64 + 4 * kVsApplyRows + 4) * 4;
+        if (lds_sort > 144 * 1024) return false;
+        return (size_t)c.n_chunks * K() <= ((size_t)1 << 22);
+    }
+    // k_vs_tables for the open batch; afterwards the OUT buffers are the live
+    // ones and P points at them
+    template <int KIND>
+    void launch_tables(SweepParams & P, const VsTables & T) {
+        Slave & f = *feats[0];
+        TablesParams A;
+        memset(&A, 0, sizeof(A));
+        A.i0_in = f.i0.p;
+        A.i1_in = f.i1.p;
+        A.counts_in = py.d_counts.p;
+        A.snap_in = snap_counts.p;
+        A.dev_in = dev_ptr();
+        std::swap(f.i0.p, alt_i0.p);   std::swap(f.i0.cap, alt_i0.cap);
+        std::swap(f.i1.p, alt_i1.p);   std::swap(f.i1.cap, alt_i1.cap);
+        std::swap(py.d_counts.p, alt_counts.p);
+        std::swap(py.d_counts.cap, alt_counts.cap);
+        std::swap(snap_counts.p, alt_snap.p);
+        std::swap(snap_counts.cap, alt_snap.cap);
+        dev_cur ^= 1;
+        A.feat = f.view();
+        A.counts_out = py.d_counts.p;
+        A.snap_out = snap_counts.p;
+        A.dev_out = dev_ptr();
+        A.shifted = py.d_shifted.p;
+        A.base = base.p;
+        A.base_single = base_single.p;
+        A.scalars = scalars.p;
+        A.p2g = d_maps.p;
+        A.g2p = reinterpret_cast<int32_t *>(d_maps.p + maps_pcap);
+        A.alpha = alpha;
+        A.d = d;
+        A.n_empty = py.n_empty;
+        A.sample_size = py.sample_size;
+        A.assign_pos = P.assign_pos;
+        const size_t lds = ((size_t)T.Kpad * 4 + 2) * 4;
+        int device = 0;
+        HIP_CHECK(hipGetDevice(&device));
+        static std::atomic<size_t> opted_in[64];
+        std::atomic<size_t> & have = opted_in[device & 63];
+        if (lds > 64 * 1024 && lds > have.load(std::memory_order_relaxed)) {
+            HIP_CHECK(hipFuncSetAttribute(
+                reinterpret_cast<const void *>(&k_vs_tables<KIND>),
+                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            have.store(lds, std::memory_order_relaxed);
+        }
+        hipLaunchKernelGGL((k_vs_tables<KIND>), dim3(T.n_values), dim3(kBlock),
+                           lds, stream(), A, T);
+        HIP_CHECK(hipGetLastError());
+        finish_pending = false;   // (this launch normalised the group set)
+        base_valid = true;
+        P.feat[0] = f.view();
+        P.counts = py.d_counts.p;
+        P.dev = dev_ptr();
+        fused_batches += 1;
+    }
 
     // Tables (k_vs_prepare) pay when several tiles share a value's vector;
     // with a tile or so per value the tile builds the vector itself.
@@ -2101,11 +2219,17 @@ struct Gibbs {
     void sample_value_sorted(SweepParams & P) {
         VsCache & c = vs_get(P.row_begin, P.row_end);
         phase_mark(0);
+        const int Kpad = (K() + kVsUnroll - 1) / kVsUnroll * kVsUnroll;
+        const bool fused = sampling_mode != 1 && !use_stream(c)
+                           && fused_ok(c, Kpad);
+        batch_fused = fused;
+        // the last batch left its group set to a fused launch: any other
+        // path wants it normalised and the caches rebuilt first
+        if (!fused) run_pending_finish();
         if (sampling_mode == 1) return sample_value_scan(P, c);
         if (use_stream(c)) return sample_value_stream(P, c);
         const size_t n = P.row_end - P.row_begin;
         const uint32_t nv = (uint32_t)vs_nvals();
-        const int Kpad = (K() + kVsUnroll - 1) / kVsUnroll * kVsUnroll;
         // (headroom: K creeps up by a group per batch; no realloc per step)
         vsLA.reserve(grow_capacity((size_t)nv * Kpad), 0);
         vsLB.reserve(grow_capacity((size_t)nv * Kpad), 0);
@@ -2146,12 +2270,15 @@ struct Gibbs {
         deferred.reserve(std::max<size_t>(n, 1), 0);
         deferred_count.reserve(1, 0);
         // base[], base_single[] and the scalars; the few handed-over rows
-        // do not pay for a gather table
-        prepare(P, false);
-        if (c.n_other)
-            HIP_CHECK(hipMemcpyAsync(deferred.p, c.other_pos.p,
-                                     4 * (size_t)c.n_other,
-                                     hipMemcpyDeviceToDevice, stream()));
+        // do not pay for a gather table (fused: k_vs_tables writes them, and
+        // rows beyond the tables are their chunk's to sample, k_vs_apply)
+        if (!fused) {
+            prepare(P, false);
+            if (c.n_other)
+                HIP_CHECK(hipMemcpyAsync(deferred.p, c.other_pos.p,
+                                         4 * (size_t)c.n_other,
+                                         hipMemcpyDeviceToDevice, stream()));
+        }
         P.sorted_rows = c.sorted_rows.p;
         P.assign_pos = c.assign_pos.p;
         VsLaunch L{this, &P, &c,
@@ -2160,7 +2287,7 @@ struct Gibbs {
                             prefix ? vsPB.p : nullptr,
                             bands ? vsBandMode.p : nullptr,
                             bands ? vsBandTile.p : nullptr, c.val_start.p,
-                            nv, nullptr}, narrow};
+                            nv, nullptr, c.chunk_first.p}, narrow, fused};
         // DIST_VS_STAMPS=<file>: per-wave phase stamps of every launch (the
         // last one stays in the file): tools/vs_stamps.py
         static const char * stamps_path = getenv("DIST_VS_STAMPS");
@@ -2185,7 +2312,7 @@ struct Gibbs {
             }
         }
         phase_mark(2);
-        launch_deferred(P);
+        if (!fused) launch_deferred(P);
         phase_mark(3);
     }
     struct DeferredLaunch {
@@ -2225,6 +2352,8 @@ struct Gibbs {
                      "rows without a group yet: init_sequential first");
         batch_begin = r0;
         batch_end = r1;
+        batch_seed = seed;
+        batch_draw_base = draw_base;
         batch_open = true;
         batch_value_sorted = false;
         moves_in_row_order = false;
@@ -2234,6 +2363,8 @@ struct Gibbs {
         upload_maps();
         SweepParams P = params(r0, r1, seed, draw_base);
         batch_value_sorted = use_value_sorted(r1 - r0);
+        batch_fused = false;
+        if (!batch_value_sorted) run_pending_finish();
         drop_overlapping_caches(r0, r1, batch_value_sorted);
         if (!batch_value_sorted) flush_assign_pos();
         if (batch_value_sorted) {
@@ -2446,9 +2577,12 @@ struct Gibbs {
     // zeroed delta image)
     void apply_ints(StatImage img) {
         const size_t n = batch_end - batch_begin;
-        SweepParams P = params(batch_begin, batch_end, 0, 0);
+        // (the batch's entropy too: a fused batch's chunks sample the rows
+        // they were handed)
+        SweepParams P = params(batch_begin, batch_end, batch_seed,
+                               batch_draw_base);
         const size_t lds_sort =
-            ((size_t)K() * 2 + kVsApplyBlock / 64 + 4 * kVsApplyRows) * 4;
+            ((size_t)K() * 2 + kVsApplyBlock / 64 + 4 * kVsApplyRows + 4) * 4;
         const size_t lds_plain = (size_t)K() * 4;
         // a 1024-thread workgroup may take most of the CU's 160 KiB of LDS
         const size_t lds_limit = 144 * 1024;
@@ -2497,6 +2631,12 @@ struct Gibbs {
             }
             const dim3 rgrid((K() + kVsReduceGroups - 1) / kVsReduceGroups),
                 rblock(kVsReduceGroups * kVsReduceSlices);
+            // (fused batches: the chunk samples its handed-over rows itself)
+            DIST_REQUIRE(!batch_fused || (sort && stage),
+                         "internal: fused batch without the sorting apply");
+            const VsDefer D{deferred.p, deferred_count.p,
+                            batch_fused ? c.def_counts.p : nullptr,
+                            c.chunks.p};
 #define VS_APPLY(KIND, SORT, LDS)                                            \
             do {                                                             \
                 /* beyond the default opt-in: raised (never lowered) once  \
@@ -2516,14 +2656,14 @@ struct Gibbs {
                                    LDS, stream(), P, img, c.chunks.p,        \
                                    c.sorted_rows.p, d_p2g_ptr,               \
                                    c.assign_pos.p, (uint32_t)vs_nvals(),     \
-                                   refresh, sole, stage);                    \
+                                   refresh, sole, stage, D);                 \
                 if (stage)                                                   \
                     hipLaunchKernelGGL((k_vs_reduce<KIND>), rgrid, rblock,   \
                                        0, stream(), img, stage, c.chunks.p,  \
                                        c.n_chunks, K(),                      \
                                        (uint32_t)vs_nvals(), pairs,          \
                                        pairs_seq,                            \
-                                       async_active ? dev_state.p : nullptr);\
+                                       async_active ? dev_ptr() : nullptr);  \
             } while (0)
             // chunks of several values first (their rows of the staging
             // matrix must be there when k_vs_reduce runs)
@@ -2553,6 +2693,8 @@ struct Gibbs {
             else if (gp) VS_APPLY(DIST_GP, false, lds_plain);
             else if (bnb && sort) VS_APPLY(DIST_BNB, true, lds_sort);
             else if (bnb) VS_APPLY(DIST_BNB, false, lds_plain);
+            else if (sort && feats[0]->sh.kind == DIST_DPD)
+                VS_APPLY(DIST_DPD, true, lds_sort);   // (its rows' scorer)
             else if (sort) VS_APPLY(DIST_DD, true, lds_sort);
             else VS_APPLY(DIST_DD, false, lds_plain);
 #undef VS_APPLY
@@ -2866,7 +3008,7 @@ struct Gibbs {
         N.snap = snap_counts.p;
         N.p2g = d_maps.p;
         N.g2p = reinterpret_cast<int32_t *>(d_maps.p + maps_pcap);
-        N.dev = dev_state.p;
+        N.dev = dev_ptr();
         N.n_empty = py.n_empty;
         const size_t lds = normalise_lds(K());
         int device = 0;
@@ -2887,6 +3029,21 @@ struct Gibbs {
     void batch_finish_device() {
         DIST_REQUIRE(batch_open, "no open batch");
         batch_open = false;
+        if (batch_fused) {
+            // the next k_vs_tables normalises the group set and rebuilds the
+            // caches on its way (or run_pending_finish, whoever comes first)
+            finish_pending = true;
+            return;
+        }
+        finish_kernels();
+    }
+    void run_pending_finish() {
+        if (!finish_pending) return;
+        finish_pending = false;
+        finish_kernels();
+    }
+    // k_normalise + k_batch_finish on the state the last batch left
+    void finish_kernels() {
         launch_normalise();
         FinishParams Q;
         memset(&Q, 0, sizeof(Q));
@@ -2912,7 +3069,7 @@ struct Gibbs {
         base_valid = true;
         Q.p2g = d_maps.p;
         Q.g2p = reinterpret_cast<int32_t *>(d_maps.p + maps_pcap);
-        Q.dev = dev_state.p;
+        Q.dev = dev_ptr();
         Q.snap = snap_counts.p;
         hipLaunchKernelGGL(k_batch_finish,
                            dim3((unsigned)((cells + kBlock - 1) / kBlock),
@@ -2926,9 +3083,11 @@ struct Gibbs {
         // thread closing it must drain THAT stream, not its own
         if (async_stream && async_stream != stream())
             HIP_CHECK(hipStreamSynchronize(async_stream));
+        run_pending_finish();   // (a fused batch left its group set open)
         sync();
-        DevState st;
-        dev_state.download(&st, 1);
+        DevState both[2];
+        dev_state.download(both, 2);
+        const DevState st = both[dev_cur];
         const size_t Kn = (size_t)st.K;
         py.counts.resize(Kn);
         py.d_counts.download(py.counts.data(), Kn);
@@ -2990,11 +3149,29 @@ struct Gibbs {
         st.global_size = (uint32_t)tracker.g2p.size();
         st.first_new_global = st.global_size;
         st.nonempty = K0 - py.n_empty;
-        dev_state.upload(&st, 1);
+        const DevState both[2] = {st, st};
+        dev_state.upload(both, 2);
+        dev_cur = 0;
+        finish_pending = false;
         snap_counts.reserve(grow_capacity((size_t)bound), 0);
         HIP_CHECK(hipMemcpyAsync(snap_counts.p, py.d_counts.p,
                                  (size_t)K0 * 4, hipMemcpyDeviceToDevice,
                                  stream()));
+        // the other set of per-group buffers (k_vs_tables): as large as the
+        // live ones, whichever way round they are swapped by now
+        alt_counts.reserve(std::max(py.d_counts.cap, alt_counts.cap), 0);
+        py.d_counts.reserve(alt_counts.cap, (size_t)K0);
+        alt_snap.reserve(std::max(snap_counts.cap, alt_snap.cap), 0);
+        snap_counts.reserve(alt_snap.cap, (size_t)K0);
+        if (F() == 1) {
+            Slave & f = *feats[0];
+            const size_t cap = std::max<size_t>(
+                {f.i0.cap, f.i1.cap, alt_i0.cap, alt_i1.cap, (size_t)f.cap});
+            alt_i0.reserve(cap, 0);
+            alt_i1.reserve(cap, 0);
+            f.i0.reserve(cap, (size_t)K0);
+            f.i1.reserve(cap, (size_t)K0);
+        }
         if (!base_valid) {   // (with the true group count, before K() bounds)
             SweepParams P0 = params(0, 0, 0, 0);
             prepare(P0, false);
@@ -4471,6 +4648,13 @@ int dist_gibbs_set_option(dist_gibbs_t * g, const char * name, int value) {
             // scored by the program kernels when its tables exist
             DIST_REQUIRE(value == 0 || value == 1, "program_all: 0 or 1");
             g->impl->program_all = value;
+        } else if (key == "fused_tables") {
+            // device-normalised runs of the value-sorted path: 1 (default)
+            // group set, caches and per-value tables in ONE launch between
+            // two batches (k_vs_tables), the handed-over rows inside
+            // k_vs_apply; 0 the separate launches
+            DIST_REQUIRE(value == 0 || value == 1, "fused_tables: 0 or 1");
+            g->impl->fused_tables_mode = value;
         } else if (key == "sequential_chain") {
             // 1 (default): the device-resident chain kernel; 0: every row
             // as a batch of one
@@ -4491,11 +4675,11 @@ int dist_gibbs_path_counts(const dist_gibbs_t * g, uint64_t * value_sorted,
 int dist_gibbs_debug_counts(dist_gibbs_t * g, uint64_t * out, size_t n) {
     return guarded([&] {
         Gibbs & e = *g->impl;
-        uint64_t v[13] = {e.vs_batches, e.generic_batches, e.band_batches,
+        uint64_t v[14] = {e.vs_batches, e.generic_batches, e.band_batches,
                           e.prefix_batches, 0, 0, e.stream_batches,
                           e.async_batches, e.narrow_batches,
                           e.scratch_batches, e.fold_batches, e.scan_batches,
-                          e.merged_batches};
+                          e.merged_batches, e.fused_batches};
         if (e.last_bands && !e.batch_open && e.vsBandMode.p) {
             // values whose arg-max group's rows had a tile of their own in
             // the last value-sorted launch
@@ -4508,7 +4692,7 @@ int dist_gibbs_debug_counts(dist_gibbs_t * g, uint64_t * out, size_t n) {
             e.deferred_count.download(&d, 1);
             v[5] = d;
         }
-        for (size_t i = 0; i < n && i < 13; ++i) out[i] = v[i];
+        for (size_t i = 0; i < n && i < 14; ++i) out[i] = v[i];
     });
 }
 int dist_gibbs_phase_stats(dist_gibbs_t * g, double ms_out[5],

@@ -2049,6 +2049,46 @@ __device__ __forceinline__ int strip_sample(const float * strip, int n,
     return n - 1;
 }
 
+// One row by one wave (k_rows_wave's body; k_vs_apply runs it for the rows
+// its chunk was handed): `sl` = the wave's strip of LDS (K floats padded to a
+// multiple of 64), `s_exp` = fmath's table in LDS, `out` = where in
+// old_packed / new_packed the move is left.
+template <int KIND0, int KIND1, int NF>
+__device__ __forceinline__ void wave_row_update(
+        const SweepParams & P, float * sl, const uint32_t * s_exp, float ea,
+        float eb, int K, int lane, size_t row, uint32_t global_id,
+        size_t out) {
+    const RowScorer<KIND0, KIND1, NF> rs(P, row, global_id);
+    const int Kl = rs.Kl;
+    // scores and vector_max (vector_math.cc:74-83; max is order-free)
+    float m = -INFINITY;
+    for (int k = lane; k < Kl; k += 64) {
+        const float s = rs.at_lane(k);
+        sl[k] = s;
+        m = s > m ? s : m;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const float o = __shfl_xor(m, off);
+        m = o > m ? o : m;
+    }
+    // scores_to_likelihoods: the exponentials in parallel ...
+    for (int k = lane; k < ((Kl + 63) & ~63); k += 64)
+        sl[k] = k < Kl ? fast_exp_nonpos(sl[k] - m, s_exp, ea, eb) : 0.f;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ... their total in index order, then the scan (strip_total /
+    // strip_sample: every lane computes the same)
+    const float total = strip_total(sl, Kl);
+    int g2 = strip_sample(sl, Kl, total * batch_row_unif01(P, row));
+    if (rs.singleton && g2 == rs.g) g2 = K - 1;   // slot g held group K-1
+    if (lane == 0) {
+        P.old_packed[out] = (uint32_t)rs.g;
+        P.new_packed[out] = (uint32_t)g2;
+    }
+    __builtin_amdgcn_wave_barrier();   // before the strip is reused
+}
+
 // One WAVE per row, for the rows that come one at a time: the hand-overs of
 // the value-sorted kernel, tiny batches, the sequential chain.  Lanes score 64
 // slots at once (coalesced cache reads) and exponentiate them in parallel into
@@ -2094,35 +2134,8 @@ __global__ __launch_bounds__(kBlock) void k_rows_wave(SweepParams P) {
         } else {
             global_id = P.assign[row];
         }
-        const RowScorer<KIND0, KIND1, NF> rs(P, row, global_id);
-        const int Kl = rs.Kl;
-        // scores and vector_max (vector_math.cc:74-83; max is order-free)
-        float m = -INFINITY;
-        for (int k = lane; k < Kl; k += 64) {
-            const float s = rs.at_lane(k);
-            sl[k] = s;
-            m = s > m ? s : m;
-        }
-        for (int off = 32; off > 0; off >>= 1) {
-            const float o = __shfl_xor(m, off);
-            m = o > m ? o : m;
-        }
-        // scores_to_likelihoods: the exponentials in parallel ...
-        for (int k = lane; k < ((Kl + 63) & ~63); k += 64)
-            sl[k] = k < Kl ? fast_exp_nonpos(sl[k] - m, s_exp, ea, eb) : 0.f;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // ... their total in index order, then the scan (strip_total /
-        // strip_sample: every lane computes the same)
-        const float total = strip_total(sl, Kl);
-        int g2 = strip_sample(sl, Kl, total * batch_row_unif01(P, row));
-        if (rs.singleton && g2 == rs.g) g2 = K - 1;   // slot g held group K-1
-        if (lane == 0) {
-            P.old_packed[out] = (uint32_t)rs.g;
-            P.new_packed[out] = (uint32_t)g2;
-        }
-        __builtin_amdgcn_wave_barrier();   // before the strip is reused
+        wave_row_update<KIND0, KIND1, NF>(P, sl, s_exp, ea, eb, K, lane, row,
+                                          global_id, out);
     }
 }
 
@@ -2362,11 +2375,34 @@ constexpr int kVsUnroll = 32;   // entries per scalar-loaded chunk
 // into both halves from its scalar register (tools/microbench/pk_add.hip:
 // 1.75x the rows per second of v_sub_f32, bit-identical)
 constexpr int kVsR = 2;
+// rows per apply work item (k_vs_apply), all of one value: a multiple of the
+// tile sizes, so a tile's rows lie in one chunk
+constexpr int kVsApplyRows = 4096;
 struct VsTile {
     uint32_t x;      // the tile's value
     uint32_t pos;    // first position in the sorted row list
     uint32_t n;      // rows in the tile (<= 64 * kVsR)
+    uint32_t chunk;  // the apply chunk (k_vs_apply work item) the rows lie in
 };
+// Where a tile leaves the rows its shortcut does not cover.  Either ONE list
+// for the launch (`list`, `count`: a wave-per-row launch follows), or -- when
+// `chunk_counts` is set -- a list per apply chunk, kept in the chunk's own
+// stretch of `list` (positions chunks[c].pos ...): k_vs_apply then samples
+// the handed-over rows of its chunk itself, before it adds up the moves, and
+// no launch sits between the two kernels.
+struct VsDefer {
+    uint32_t * list;
+    uint32_t * count;
+    uint32_t * chunk_counts;
+    const VsTile * chunks;
+};
+__device__ __forceinline__ void vs_hand_over(const VsDefer & D, uint32_t chunk,
+                                             uint32_t at) {
+    if (D.chunk_counts)
+        D.list[D.chunks[chunk].pos + atomicAdd(&D.chunk_counts[chunk], 1u)] = at;
+    else
+        D.list[atomicAdd(D.count, 1u)] = at;
+}
 struct VsTables {
     float * LA;      // [nvals][Kpad]
     float * LB;
@@ -2394,6 +2430,9 @@ struct VsTables {
     // DIST_VS_STAMPS=<file>; tools/vs_stamps.py): per wave of k_vs_sample
     // five s_memtime stamps and HW_ID; null otherwise
     unsigned long long * stamps;
+    // [nvals] index of the first apply chunk of each value (chunks of one
+    // value each, kVsApplyRows rows apart: a band tile's rows find theirs)
+    const uint32_t * chunk_first;
 };
 constexpr uint32_t kVsBandWalkRows = 8192;
 
@@ -2602,6 +2641,405 @@ __global__ __launch_bounds__(kBlock) void k_vs_prepare(
     }
 }
 
+// ---------------------------------------------------------------------------
+// ONE launch between a batch's statistics and the next batch's sampling
+// (device-normalised runs of the value-sorted path, integer statistics):
+// k_normalise, k_batch_finish and k_vs_prepare in one kernel, so that a
+// sub-sweep is tables -> sample -> apply -> reduce.  A launch costs this chip
+// 2.4 us and every dependent trip to memory inside one about a microsecond
+// (profiles/r4_launch_cost.txt: a grid barrier costs 7-12 us, a last-block
+// ticket no less than the launch it saves), so the three kernels' work is
+// done by the workgroups of the per-value tables REDUNDANTLY where it is
+// cheap, and nobody waits for anybody:
+//  * every workgroup compares the group sizes with those at batch entry and
+//    derives the normalisation of the group set for itself (mixture.hpp:84-89,
+//    108-119, as k_normalise does): which groups vanish, which survivor fills
+//    which vacated slot, how many empty groups are appended;
+//  * the per-group statistics are read through that plan from the IN buffers
+//    (counts, i0, i1: what the last batch left) and never written there;
+//    workgroup 0 writes them, normalised, to the OUT buffers, which the
+//    batch's other kernels use (the host swaps the two after the launch), with
+//    the driver's scores (clustering.hpp:151-161, 215-230), the cache entries,
+//    the id maps (mixture.hpp:474-497) and the new DevState;
+//  * workgroup x owns column x of the categorical counts and of the cache:
+//    it moves / clears the cells of moved / appended groups in place and
+//    writes S[x][.] (dd.hpp:399-421);
+//  * then the value's tables as k_vs_prepare builds them, from the scores it
+//    has in LDS: the same float operations in the same order.
+struct TablesParams {
+    SlaveView feat;              // i0 / i1: the OUT buffers
+    const int32_t * i0_in;
+    const int32_t * i1_in;
+    const int32_t * counts_in;
+    int32_t * counts_out;
+    const int32_t * snap_in;     // group sizes at the last batch's entry
+    int32_t * snap_out;
+    const DevState * dev_in;
+    DevState * dev_out;
+    float * shifted;
+    float * base;
+    float * base_single;
+    SweepScalars * scalars;
+    uint32_t * p2g;
+    int32_t * g2p;
+    float alpha, d;
+    int n_empty;                 // invariant of the chain
+    long long sample_size;       // rows in the mixture (invariant)
+    const uint32_t * assign_pos; // the rows' groups by position (band walk)
+};
+template <int KIND>
+__global__ __launch_bounds__(kBlock) void k_vs_tables(TablesParams A,
+                                                      VsTables T) {
+    // [Kpad] scores, then LA | [Kpad] LB | [Kpad + 2] emptied-before, then own
+    // scores | [Kpad] the slot each slot's group comes from
+    extern __shared__ float tb_lds[];
+    __shared__ float r_m1[kBlock / 64], r_m2[kBlock / 64];
+    __shared__ int r_i1[kBlock / 64];
+    __shared__ int s_sum[2][kBlock / 64];
+    __shared__ float sh_M, sh_mB;
+    __shared__ uint32_t sh_lo, sh_hi, sh_n;
+    __shared__ int sh_amax;
+    const int Kpad = T.Kpad;
+    float * sc = tb_lds;
+    float * lbuf = sc + Kpad;
+    int * before = reinterpret_cast<int *>(lbuf + Kpad);
+    float * own = reinterpret_cast<float *>(before);
+    int * src_of = before + Kpad + 2;
+    const uint32_t x = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    SlaveView v = A.feat;
+    v.kind = KIND;
+    const int K0 = A.dev_in->K;
+    const uint32_t global_size0 = A.dev_in->global_size;
+    auto emptied_at = [&](int k) {
+        return A.snap_in[k] > 0 && A.counts_in[k] == 0;
+    };
+    // ---- the plan: vanished and filled groups since the last batch's entry
+    int removed = 0, n_created = 0;
+    {
+        int e = 0, c = 0;
+        for (int k = tid; k < K0; k += kBlock) {
+            const int was = A.snap_in[k], now = A.counts_in[k];
+            e += (was > 0 && now == 0);
+            c += (was == 0 && now > 0);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            e += __shfl_xor(e, off);
+            c += __shfl_xor(c, off);
+        }
+        if (lane == 0) { s_sum[0][wave] = e; s_sum[1][wave] = c; }
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < kBlock / 64; ++w) {
+            removed += s_sum[0][w];
+            n_created += s_sum[1][w];
+        }
+    }
+    const int size = K0 - removed;
+    const int k_new = size;
+    const int K1 = size + n_created;
+    const int nonempty = K1 - A.n_empty;
+    if (removed > 0) {
+        // before[k] = vanished groups in [0, k); then, as k_normalise: the i-th
+        // removal (descending slots) pulls in what sits in slot K0 - 1 - i at
+        // that time, so a vacated slot in front of the new end follows that
+        // chain to the survivor it ends up with
+        __syncthreads();   // (s_sum is reused)
+        const int per = (K0 + kBlock - 1) / kBlock;
+        const int lo = min(K0, tid * per), hi = min(K0, lo + per);
+        int mine = 0;
+        for (int k = lo; k < hi; ++k) mine += emptied_at(k);
+        int incl = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int up = __shfl_up(incl, off);
+            if (lane >= off) incl += up;
+        }
+        if (lane == 63) s_sum[0][wave] = incl;
+        __syncthreads();
+        int run = incl - mine;
+        for (int w = 0; w < wave; ++w) run += s_sum[0][w];
+        for (int k = lo; k < hi; ++k) {
+            before[k] = run;
+            run += emptied_at(k);
+        }
+        if (hi == K0 && lo < K0) before[K0] = run;
+        __syncthreads();
+        for (int k = tid; k < size; k += kBlock) {
+            int t = k;
+            if (before[k + 1] != before[k]) {
+                do {
+                    t = K0 - 1 - (removed - before[t + 1]);
+                } while (before[t + 1] != before[t]);
+            }
+            src_of[k] = t;
+        }
+        __syncthreads();
+    }
+    // ---- this value's column of the categorical counts, in place: moved
+    // groups' cells follow them (all reads before any write: a source slot
+    // may be one that is cleared for an appended group), appended groups'
+    // cells are zero (Group::init, dd.hpp:113-121)
+    if (is_cat(KIND) && (removed > 0 || n_created > 0)) {
+        int * moved = reinterpret_cast<int *>(lbuf);
+        if (removed > 0) {
+            for (int k = tid; k < size; k += kBlock)
+                if (src_of[k] != k)
+                    moved[k] = v.cnt[(size_t)src_of[k] * v.dim + x];
+            __syncthreads();
+            for (int k = tid; k < size; k += kBlock)
+                if (src_of[k] != k) v.cnt[(size_t)k * v.dim + x] = moved[k];
+        }
+        for (int k = k_new + tid; k < K1; k += kBlock)
+            v.cnt[(size_t)k * v.dim + x] = 0;
+        __syncthreads();
+    }
+    // ---- every group's statistics through the plan, its cache entry, its
+    // score for this value (k_vs_prepare's pass 1), its own-slot score
+    const bool owner = x == 0;
+    const float shift = py_shift(A.sample_size - 1, A.alpha);
+    const float empty_score = py_empty_score(A.alpha, A.d, nonempty, A.n_empty);
+    const float empty_single =
+        py_empty_score(A.alpha, A.d, nonempty - 1, A.n_empty);
+    const float lf = KIND == DIST_GP ? fast_log_factorial(x) : 0.f;
+    float m1 = -INFINITY, m2 = -INFINITY;
+    int i1 = 0x7fffffff;
+    for (int k = tid; k < K1; k += kBlock) {
+        const bool fresh = k >= k_new;
+        const int ks = (removed > 0 && !fresh) ? src_of[k] : k;
+        const int n = fresh ? 0 : A.counts_in[ks];
+        const Stats st = {fresh ? 0 : A.i0_in[ks], fresh ? 0 : A.i1_in[ks],
+                          0.f, 0.f};
+        int c = 0;
+        Entry e = {0.f, 0.f, 0.f, 0.f};
+        if (is_cat(KIND)) {
+            c = v.cnt[(size_t)k * v.dim + x];
+            e.c0 = fast_log(v.alpha_sum + (float)st.i0);
+            e.c1 = fast_log(v.prior[x] + (float)c);
+            v.S[(size_t)x * v.cap + k] = e.c1;
+        } else {
+            e = scorer_init(KIND, v.p, st);
+        }
+        const float shifted = n ? py_nonempty_score(n, A.d) : empty_score;
+        const float base = shifted + shift;
+        const float s = accumulate(KIND, base, e, x, lf, v.p);
+        sc[k] = s;
+        if (s > m1) { m2 = m1; m1 = s; i1 = k; }
+        else if (s > m2) m2 = s;
+        // the score a row of this value sees in its own slot k once it is
+        // taken out (vs_own_score); +inf: no such row or score, -inf: the row
+        // would be alone (handed over)
+        bool has;
+        if (is_cat(KIND)) has = c >= 1;
+        else if (KIND == DIST_GP || KIND == DIST_BNB)
+            has = (uint32_t)st.i0 >= 1u && (uint32_t)st.i1 >= x;
+        else has = (x ? st.i0 : st.i1) >= 1;
+        float so = INFINITY;
+        if (n == 1) {
+            so = -INFINITY;
+        } else if (n >= 2 && has) {
+            Entry er = {0.f, 0.f, 0.f, 0.f};
+            if (is_cat(KIND)) {
+                er.c0 = fast_log(v.alpha_sum + (float)(st.i0 - 1));
+                er.c1 = fast_log(v.prior[x] + (float)(c - 1));
+            } else {
+                Stats s2 = st;
+                stats_remove(KIND, s2, x);
+                er = scorer_init(KIND, v.p, s2);
+            }
+            so = accumulate(KIND, py_nonempty_score(n - 1, A.d) + shift, er,
+                            x, lf, v.p);
+        }
+        own[k] = so;
+        if (owner) {
+            A.counts_out[k] = n;
+            A.snap_out[k] = n;
+            v.i0[k] = st.i0;
+            v.i1[k] = st.i1;
+            if (fresh) { v.f0[k] = 0.f; v.f1[k] = 0.f; }
+            A.shifted[k] = shifted;
+            A.base[k] = base;
+            A.base_single[k] = (n == 0 ? empty_single : shifted) + shift;
+            v.c0[k] = e.c0;
+            if (!is_cat(KIND)) { v.c1[k] = e.c1; v.c2[k] = e.c2; v.c3[k] = e.c3; }
+        }
+    }
+    // (max, first arg-max, max of the rest) over the workgroup
+    auto fold = [](float & a1, float & a2, int & ai, float b1, float b2,
+                   int bi) {
+        if (a1 > b1 || (a1 == b1 && ai < bi)) {
+            a2 = fmaxf(a2, b1);
+        } else {
+            a2 = fmaxf(b2, a1);
+            a1 = b1;
+            ai = bi;
+        }
+    };
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float b1 = __shfl_xor(m1, off), b2 = __shfl_xor(m2, off);
+        const int bi = __shfl_xor(i1, off);
+        fold(m1, m2, i1, b1, b2, bi);
+    }
+    if (lane == 0) { r_m1[wave] = m1; r_m2[wave] = m2; r_i1[wave] = i1; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < kBlock / 64; ++w)
+            fold(m1, m2, i1, r_m1[w], r_m2[w], r_i1[w]);
+        const float M = m1;
+        const int g = i1;
+        const float so = own[g];
+        // (the arg-max group's rows: own score against the rest's maximum)
+        const float mB = (so != INFINITY && so != -INFINITY) ? fmaxf(so, m2) : M;
+        T.M[x] = M; T.mB[x] = mB; T.argmax[x] = g;
+        sh_M = M; sh_mB = mB; sh_amax = g;
+        sh_lo = 0xFFFFFFFFu; sh_hi = 0u; sh_n = 0u;
+    }
+    __syncthreads();
+    const float M = sh_M, mB = sh_mB;
+    const int amax = sh_amax;
+    const float ea = u2f(g_tables_dev.exp_ab[0]);
+    const float eb = u2f(g_tables_dev.exp_ab[1]);
+    float * la = T.LA + (size_t)x * Kpad;
+    float * lb = T.LB + (size_t)x * Kpad;
+    for (int k = tid; k < Kpad; k += kBlock) {
+        float a = 0.f, b = 0.f;
+        if (k < K1) {
+            const float s = sc[k];
+            a = fast_exp_nonpos(s - M, g_tables_dev.exp_table, ea, eb);
+            b = fast_exp_nonpos(s - mB, g_tables_dev.exp_table, ea, eb);
+        }
+        la[k] = a;
+        lb[k] = b;
+        sc[k] = a;      // (the running sums below read the copies in LDS)
+        lbuf[k] = b;
+    }
+    // ---- workgroup 0: the id maps (mixture.hpp:474-497), the scalars, the
+    // new state
+    if (owner) {
+        if (removed > 0) {
+            // the ids of the vanished groups retire before any slot is
+            // overwritten
+            for (int k = tid; k < K0; k += kBlock)
+                if (emptied_at(k)) A.g2p[A.p2g[k]] = -1;
+            __syncthreads();
+            for (int k = tid; k < size; k += kBlock) {
+                const int t = src_of[k];
+                if (t != k) {
+                    const uint32_t gid = A.p2g[t];
+                    A.p2g[k] = gid;
+                    A.g2p[gid] = k;
+                }
+            }
+            __syncthreads();
+        }
+        for (int k = k_new + tid; k < K1; k += kBlock) {
+            const uint32_t gid = global_size0 + (uint32_t)(k - k_new);
+            A.p2g[k] = gid;
+            A.g2p[gid] = k;
+        }
+        if (tid == 0) {
+            DevState st;
+            st.K = K1;
+            st.k_new = k_new;
+            st.created = n_created;
+            st.removed = removed;
+            st.global_size = global_size0 + (uint32_t)n_created;
+            st.first_new_global = global_size0;
+            st.nonempty = nonempty;
+            st.pad = A.dev_in->pad + (removed > 0 ? 1 : 0);
+            *A.dev_out = st;
+            A.scalars->shift = shift;
+            A.scalars->shift_full = py_shift(A.sample_size, A.alpha);
+            A.scalars->empty_single = empty_single;
+        }
+    }
+    // ---- the running sums and the arg-max group's band (see k_vs_prepare)
+    if (T.PA == nullptr && T.band_mode == nullptr) return;
+    __syncthreads();   // the copies in LDS are complete
+    const bool chains = T.PA != nullptr;
+    // (a batch that moved groups: the walk below would read the id map while
+    // workgroup 0 rewrites it -- no bands, every tile runs both passes)
+    const bool bands_ok = removed == 0;
+    bool walk = false;
+    if (chains && wave < 2) {
+        if (lane == 0) {
+            const float4 * src =
+                reinterpret_cast<const float4 *>(wave ? lbuf : sc);
+            const int nchunks = Kpad / kVsUnroll;
+            float * dst = (wave ? T.PB : T.PA) + (size_t)x * nchunks;
+            constexpr int Q = kVsUnroll / 4;
+            float4 even[Q], odd[Q];   // ping-pong: no register copies
+#pragma unroll
+            for (int q = 0; q < Q; ++q) even[q] = src[q];
+            float run = 0.f;
+            auto add_chunk = [&run](const float4 (&w)[Q]) {
+#pragma unroll
+                for (int q = 0; q < Q; ++q) {
+                    run += w[q].x;
+                    run += w[q].y;
+                    run += w[q].z;
+                    run += w[q].w;
+                }
+            };
+            for (int c = 0; c < nchunks; c += 2) {
+                const int c1 = c + 1 < nchunks ? c + 1 : c;
+#pragma unroll
+                for (int q = 0; q < Q; ++q) odd[q] = src[c1 * Q + q];
+                __builtin_amdgcn_sched_barrier(0);   // loads first
+                dst[c] = run;
+                add_chunk(even);
+                __builtin_amdgcn_sched_barrier(0);
+                if (c + 1 >= nchunks) break;
+                const int c2 = c + 2 < nchunks ? c + 2 : c;
+#pragma unroll
+                for (int q = 0; q < Q; ++q) even[q] = src[c2 * Q + q];
+                __builtin_amdgcn_sched_barrier(0);
+                dst[c + 1] = run;
+                add_chunk(odd);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    } else if (T.band_mode && bands_ok) {
+        const uint32_t begin = T.val_start[x];
+        walk = T.val_start[x + 1] - begin <= kVsBandWalkRows;
+        const uint32_t end = walk ? T.val_start[x + 1] : begin;
+        const uint32_t first = chains ? 128u : 0u;   // walking threads
+        const uint32_t step = kBlock - first;
+        constexpr int U = 4;
+        for (uint32_t base = begin + (threadIdx.x - first); base < end;
+             base += U * step) {
+            uint32_t gid[U], slot[U];
+#pragma unroll
+            for (int q = 0; q < U; ++q) {
+                const uint32_t i = base + q * step;
+                gid[q] = i < end ? A.assign_pos[i] : 0u;
+            }
+#pragma unroll
+            for (int q = 0; q < U; ++q) slot[q] = (uint32_t)A.g2p[gid[q]];
+#pragma unroll
+            for (int q = 0; q < U; ++q) {
+                const uint32_t i = base + q * step;
+                if (i < end && slot[q] == (uint32_t)amax) {
+                    atomicMin(&sh_lo, i);
+                    atomicMax(&sh_hi, i);
+                    atomicAdd(&sh_n, 1u);
+                }
+            }
+        }
+    }
+    if (T.band_mode == nullptr) return;
+    __syncthreads();
+    if (threadIdx.x == kBlock - 1) {   // (a walking thread: it knows `walk`)
+        const uint32_t n = sh_n;
+        const bool band = n > 0 && sh_hi - sh_lo + 1u == n
+                          && n <= 64u * kVsR;
+        T.band_mode[x] = (walk && (band || n == 0)) ? 1 : 0;
+        T.band_tile[x] = VsTile{x, band ? sh_lo : 0u, band ? n : 0u, 0u};
+    }
+}
+
 // The two order-sensitive recurrences for the lanes whose likelihood vector
 // is `lp` (wave-uniform), own slot replaced by the lane's l_own:
 //   total = ((l_0 + l_1) + l_2) + ...                  random.cc:100-103
@@ -2794,8 +3232,7 @@ __attribute__((amdgpu_waves_per_eu(8, 8)))
 void k_vs_sample(
         SweepParams P, VsTables T, const VsTile * __restrict__ tiles,
         uint32_t n_tiles, uint32_t n_band_ids,
-        const uint32_t * __restrict__ sorted_rows,
-        uint32_t * __restrict__ deferred, uint32_t * deferred_count) {
+        const uint32_t * __restrict__ sorted_rows, VsDefer D) {
     const int lane = threadIdx.x & 63;
     const uint32_t id = __builtin_amdgcn_readfirstlane(
         blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6));
@@ -2858,7 +3295,14 @@ void k_vs_sample(
                 defer = !classB && s_own > M;   // table rounding lifted it
             }
             if (defer) {
-                deferred[atomicAdd(deferred_count, 1u)] = pos + kVsR * lane + r;
+                const uint32_t at = pos + kVsR * lane + r;
+                // (a band tile's rows may straddle two chunks of its value)
+                const uint32_t chunk =
+                    !D.chunk_counts ? 0u
+                    : band ? T.chunk_first[x]
+                                 + (at - T.val_start[x]) / (uint32_t)kVsApplyRows
+                           : mine->chunk;
+                vs_hand_over(D, chunk, at);
                 valid[r] = false;
             } else {
                 l_own[r] = fast_exp_nonpos(s_own - m, g_tables_dev.exp_table,
@@ -3258,7 +3702,7 @@ template <int KIND, int HQ>
 __global__ __launch_bounds__(64) void k_vs_narrow(
         SweepParams P, VsTables T, const VsTile * __restrict__ tiles,
         uint32_t n_tiles, const uint32_t * __restrict__ sorted_rows,
-        uint32_t * __restrict__ deferred, uint32_t * deferred_count) {
+        VsDefer D) {
     extern __shared__ float4 s_narrow[];   // [2][(Kpad + 2 * kVsUnroll) / 4]
     const int lane = threadIdx.x;
     const uint32_t id = blockIdx.x;
@@ -3315,7 +3759,7 @@ __global__ __launch_bounds__(64) void k_vs_narrow(
             defer = !is_b && s_own > M;   // table rounding lifted it
         }
         if (defer) {
-            deferred[atomicAdd(deferred_count, 1u)] = at;
+            vs_hand_over(D, tiles[id].chunk, at);
             valid = false;
         } else {
             l_own = fast_exp_nonpos(s_own - m, g_tables_dev.exp_table, ea, eb);
@@ -3694,7 +4138,6 @@ void k_vs_stream(
 //   BB:     reduce: counts += sum_c d, (x ? heads : tails) += sum_{c: x} d
 //   GP/BNB: reduce: counts, count += sum_c d, sum += sum_c x_c d
 // `stage` null (matrix too large: wide value tables): the atomics as before.
-constexpr int kVsApplyRows = 4096;
 constexpr int kVsApplyBlock = 1024;   // one workgroup per chunk: keep the CU busy
 
 // SORT: also reorder the chunk's rows by their NEW group (counting sort in
@@ -3709,7 +4152,7 @@ __global__ __launch_bounds__(kVsApplyBlock) void k_vs_apply(
         uint32_t * __restrict__ sorted_rows,
         const uint32_t * __restrict__ p2g, uint32_t * __restrict__ assign_pos,
         uint32_t nvals, int refresh_cells, int sole_owner,
-        int32_t * __restrict__ stage) {
+        int32_t * __restrict__ stage, VsDefer D) {
     extern __shared__ int vs_lds[];
     const int K = sweep_K(P);
     int * delta = vs_lds;                 // [K]
@@ -3723,6 +4166,41 @@ __global__ __launch_bounds__(kVsApplyBlock) void k_vs_apply(
     const uint32_t pos = chunks[blockIdx.x].pos;
     const uint32_t n = chunks[blockIdx.x].n;
     if (x == 0xFFFFFFFEu) return;   // several values: k_vs_apply_mixed's
+    // The rows of this chunk that the tiles handed over (VsDefer: alone in
+    // their group, own score above the value's maximum) -- or the whole chunk
+    // when its values lie beyond the tables -- are sampled here, a wave per
+    // row as k_rows_wave does it, before the moves are added up: the strips
+    // lie where the sort keeps its copies later on.  (GP's float statistics
+    // want the moves before this kernel runs: the launch in between stays.)
+    if (SORT && KIND != DIST_GP && D.chunk_counts) {
+        const uint32_t n_def = x >= nvals ? n : D.chunk_counts[blockIdx.x];
+        if (n_def) {   // (uniform over the workgroup)
+            __shared__ uint32_t s_exp[1024];
+            for (int i = threadIdx.x; i < 1024; i += kVsApplyBlock)
+                s_exp[i] = g_tables_dev.exp_table[i];
+            __syncthreads();
+            const float ea = u2f(g_tables_dev.exp_ab[0]);
+            const float eb = u2f(g_tables_dev.exp_ab[1]);
+            const int strip = (K + 63) & ~63;
+            const int waves = min(kVsApplyBlock / 64, 4 * kVsApplyRows / strip);
+            const int wave = threadIdx.x >> 6;
+            // (16-byte aligned: the recurrences read them as float4; the host
+            // leaves four words of slack behind the sort's buffers)
+            float * sl = reinterpret_cast<float *>(
+                             ((unsigned long long)rows_l + 15ull) & ~15ull)
+                         + (size_t)wave * strip;
+            if (wave < waves)
+                for (uint32_t item = wave; item < n_def; item += waves) {
+                    const uint32_t at = x >= nvals ? pos + item
+                                                   : D.list[pos + item];
+                    wave_row_update<KIND, -1, 1>(
+                        P, sl, s_exp, ea, eb, K, threadIdx.x & 63,
+                        P.row_begin + sorted_rows[at], assign_pos[at], at);
+                }
+            __syncthreads();   // (their moves are read below)
+            if (threadIdx.x == 0 && x < nvals) D.chunk_counts[blockIdx.x] = 0;
+        }
+    }
     for (int k = threadIdx.x; k < K; k += kVsApplyBlock) {
         delta[k] = 0;
         if (SORT) hist[k] = 0;
@@ -3754,7 +4232,7 @@ __global__ __launch_bounds__(kVsApplyBlock) void k_vs_apply(
     const int dim = P.feat[0].dim;
     for (int k = threadIdx.x; k < K; k += kVsApplyBlock) {
         const int dlt = delta[k];
-        if (stage) stage[(size_t)blockIdx.x * K + k] = dlt;
+        if (stage) stage[(size_t)blockIdx.x * P.K + k] = dlt;
         if (dlt == 0) continue;
         if (!stage) {
             atomicAdd(&img.counts[k], dlt);
@@ -3864,7 +4342,7 @@ __global__ __launch_bounds__(kVsApplyBlock) void k_vs_apply_mixed(
     for (int k = threadIdx.x; k < K; k += kVsApplyBlock) {
         const int dlt = delta[k];
         if (stage) {
-            stage[(size_t)blockIdx.x * K + k] = dlt;
+            stage[(size_t)blockIdx.x * P.K + k] = dlt;
         } else if (dlt != 0) {
             atomicAdd(&img.counts[k], dlt);
             atomicAdd(&img.i0[0][k], dlt);     // count_sum
@@ -3901,6 +4379,9 @@ void k_vs_reduce(StatImage img, const int32_t * __restrict__ stage,
                  const VsTile * __restrict__ chunks, uint32_t n_chunks, int K,
                  uint32_t nvals, unsigned long long * host_pairs,
                  unsigned int seq, const DevState * dev) {
+    // (the rows of the staging matrix are the host's bound apart: their
+    // addresses do not wait for the group count of record)
+    const int stride = K;
     if (dev) K = dev->K;   // (see SweepParams::dev)
     __shared__ int s_a[kVsReduceSlices][kVsReduceGroups];
     __shared__ int s_b[kVsReduceSlices][kVsReduceGroups];
@@ -3908,9 +4389,9 @@ void k_vs_reduce(StatImage img, const int32_t * __restrict__ stage,
     const int slice = threadIdx.x / kVsReduceGroups;
     const int k = blockIdx.x * kVsReduceGroups + kk;
     int a = 0, b = 0;   // a: plain sum; b: BB heads part / GP value-weighted
-    if (k < K) {
+    if (k < stride) {   // (slots past the group count hold zeros or nothing)
         for (uint32_t c = slice; c < n_chunks; c += kVsReduceSlices) {
-            const int d = stage[(size_t)c * K + k];
+            const int d = stage[(size_t)c * stride + k];
             const uint32_t x = chunks[c].x;
             a += d;
             if (KIND == DIST_BB) b += x ? d : 0;

@@ -323,24 +323,27 @@ def test_group_creation_and_removal(config, mode, empty):
 def test_device_side_normalisation_under_group_churn(config, dim, stream,
                                                      empty):
     """Sweeps that stay on the value-sorted path normalise the group set on
-    the device (k_normalise) and are queued without a host round trip.  Many
-    small groups and a large alpha make groups die and empty groups fill in
-    nearly every batch, several per batch: the device-normalised engine, the
-    host-normalised engine and the oracle agree bit for bit, ids included."""
+    the device and are queued without a host round trip: in the one launch
+    that also builds the next batch's tables (k_vs_tables, the default) or by
+    k_normalise + k_batch_finish (fused_tables = 0).  Many small groups and a
+    large alpha make groups die and empty groups fill in nearly every batch,
+    several per batch: both device-normalised engines, the host-normalised
+    engine and the oracle agree bit for bit, ids included."""
     from distributions_amd import engine
     n, k = 6000, 900
     osh, gsh, vals, assign = workloads.make(config, n, k, dim=dim)
     orc = ol.OracleMixture(30.0, 0.6, osh)
     orc.init_from_assignments(vals, assign, k, empty)
     engines = []
-    for normalise in (1, 0):
+    for normalise, fused in ((1, 1), (0, 0), (1, 0)):
         gpu = engine.Gibbs(30.0, 0.6, gsh)
         gpu.set_option("value_sorted", 2)
         gpu.set_option("value_stream", stream)
         gpu.set_option("device_normalise", normalise)
-        # (tables: one engine through k_vs_narrow, the other through the
+        gpu.set_option("fused_tables", fused)
+        # (tables: one engine through k_vs_narrow, the others through the
         # 128-row tiles)
-        gpu.set_option("narrow_tiles", 2 * normalise)
+        gpu.set_option("narrow_tiles", 2 * fused)
         gpu.set_option("narrow_read_ahead", 4)
         gpu.load_rows(vals, assign, k, empty)
         engines.append(gpu)
@@ -361,6 +364,11 @@ def test_device_side_normalisation_under_group_churn(config, dim, stream,
     assert len(set(sizes)) > 1                    # the group set did change
     assert engines[0].core.debug_counts()["device_normalised"] > 0
     assert engines[1].core.debug_counts()["device_normalised"] == 0
+    assert engines[2].core.debug_counts()["device_normalised"] > 0
+    # (the table-free kernel keeps the separate launches)
+    fused = engines[0].core.debug_counts()["fused_batches"]
+    assert (fused > 0) == (stream == 0)
+    assert engines[2].core.debug_counts()["fused_batches"] == 0
     # and the host-driven paths pick the state up where the device left it
     st2 = orc.gibbs_sequential(0, 300, st)
     assert engines[0].sweep_sequential(0, 300, st) == st2
