@@ -42,6 +42,11 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s
 SIMDS = 1024            # 256 CUs x 4 SIMDs
 CLOCK_GHZ = 2.4         # MI355X_MICROARCH.md: max clock
+COUNTERS_FILE = "r4_counters.json"   # tools/counters.py, this round's sources
+# what one wave64 vector instruction costs its SIMD when issued back to back,
+# by class (tools/microbench/valu_issue.hip, profiles/r2_final_valu_issue.txt)
+ISSUE_CYCLES_PACKED = 4.19   # v_pk_*, also shifts and compares
+ISSUE_CYCLES_PLAIN = 2.3     # plain f32 / int32 operations
 METRIC = ("row-Gibbs-updates/sec (score+sample+suffstat) at N=10M, K=1024; "
           "1/2/4/8 GPU")
 
@@ -97,10 +102,12 @@ def parse():
                     help="comma-separated sub-sweep sizes timed besides "
                          "--batch (a few steps each, reported in "
                          "`batch_variants`; empty = none)")
-    ap.add_argument("--other-configs", default="gp_nich,mixed",
-                    help="N = 1: general-row configurations timed besides "
-                         "the headline one (a few steps each, exact and scan "
-                         "sampling, reported in `other_configs`; empty = none)")
+    ap.add_argument("--other-configs", default="gp_nich,mixed,dpd",
+                    help="N = 1: the other BASELINE configurations timed "
+                         "besides the headline one (a few steps each, exact "
+                         "and scan sampling, reported in `other_configs` and "
+                         "as scalars in `config`; dpd = BASELINE configs[4] "
+                         "at K = 8192, V = 10 000; empty = none)")
     ap.add_argument("--opt", action="append", default=[],
                     metavar="NAME=VALUE",
                     help="any other engine option (dist_gibbs_set_option), "
@@ -204,10 +211,10 @@ def source_hash():
 
 def committed_counters(kernel):
     """Per-launch counter means of `kernel` from the committed rocprofv3
-    --pmc passes (profiles/r3_counters.json, written by tools/counters.py on
+    --pmc passes (profiles/r4_counters.json, written by tools/counters.py on
     the GPU box from separate passes of this command).  None when there is no
     record or the kernel sources changed since it was taken."""
-    path = os.path.join(ROOT, "profiles", "r3_counters.json")
+    path = os.path.join(ROOT, "profiles", COUNTERS_FILE)
     try:
         rec = json.load(open(path))
     except (OSError, ValueError):
@@ -506,6 +513,7 @@ def run_rank(args):
     seed_state = _core.rng_seed(args.seed)
 
     def build_job(n, row_offset, args=args):
+        k = args.groups   # (a sub-job may have its own: C5 runs at K = 8192)
         gen = torch.Generator(device=dev)
         gen.manual_seed(args.seed + rank)
         assign = (torch.arange(n, device=dev, dtype=torch.int64)
@@ -575,9 +583,14 @@ def run_rank(args):
     host_enqueue_ms = 1e3 * timed.host_enqueue_s / max(args.steps, 1)
     ms, launches, rows = g.kernel_stats()
     vs_batches, generic_batches = g.path_counts()
-    streamed = g.core.debug_counts()["stream_batches"]
-    narrow = g.core.debug_counts()["narrow_batches"]
-    scratched = g.core.debug_counts()["scratch_batches"]
+    # what the engine that ran the timed region says about itself (read
+    # here: `g` is rebuilt further down)
+    timed_counts = g.core.debug_counts()
+    timed_words = g.core.stat_words()
+    streamed = timed_counts["stream_batches"]
+    narrow = timed_counts["narrow_batches"]
+    scratched = timed_counts["scratch_batches"]
+    scanned = timed_counts["scan_batches"]
     draws = args.warmup + args.steps
     groups_at_end = len(g)
     comm_ms, comm_count = (g.core.comm_stats() if native_comm else (0.0, 0))
@@ -643,9 +656,13 @@ def run_rank(args):
                     ("scan sampling + merged float statistics "
                      "(tolerance-level, opt-in)",
                      ["sampling=1", "float_stats=1"])):
+                if cfg == "dpd" and "float_stats=1" in opts:
+                    continue   # (integer statistics only)
                 sub = argparse.Namespace(**vars(args))
                 sub.config = cfg
                 sub.opt = list(args.opt) + opts
+                if cfg == "dpd":   # BASELINE configs[4]
+                    sub.groups, sub.dim = 8192, 10000
                 if len(others) == 0:
                     del sharded, g, columns
                     g = sharded = columns = None
@@ -662,8 +679,18 @@ def run_rank(args):
                     "unit": "row-updates/s", "steps": steps_o,
                     "ms_per_step": 1e3 * dt_o / steps_o,
                     "batch_rows": args.batch,
-                    "kernel": "k_rows_scratch" if counts_o["scratch_batches"]
-                              else "k_sweep_sample",
+                    "groups": sub.groups,
+                    "kernel": ("k_vs_scan_rows" if counts_o["scan_batches"]
+                               and counts_o["value_sorted_batches"]
+                               else "k_vs_stream" if counts_o["stream_batches"]
+                               else "k_vs_sample"
+                               if counts_o["value_sorted_batches"]
+                               else "k_rows_scratch, scan mode"
+                               if "sampling=1" in opts
+                               and counts_o["scratch_batches"]
+                               else "k_rows_scratch"
+                               if counts_o["scratch_batches"]
+                               else "k_sweep_sample"),
                     "folded": bool(counts_o["fold_batches"]),
                     "kernel_avg_launch_ms": ms_o / max(launches_o, 1)})
                 del g2, sh2
@@ -690,7 +717,11 @@ def run_rank(args):
                   "steps": steps_s, "ms_per_step": 1e3 * dt_s / steps_s}
 
     total_rows = float(n) * world * args.steps
-    if vs_batches and streamed:
+    if vs_batches and scanned:
+        kernel = "k_vs_scan_rows<%s>" % args.config
+    elif scratched and "sampling=1" in [o.replace(" ", "") for o in args.opt]:
+        kernel = "k_rows_scratch<%s, scan>" % args.config
+    elif vs_batches and streamed:
         kernel = "k_vs_stream<%s>" % args.config
     elif vs_batches and narrow:
         kernel = "k_vs_narrow<%s>" % args.config
@@ -749,6 +780,20 @@ def run_rank(args):
             tiles = rows_per_launch / 128.0
             useful = (1.5 * k * tiles) / (ctr["valu_instructions"] * scale)
         roof["useful_frac"] = useful
+        # the same busy fraction with the instructions priced by class
+        # instead of 4 cycles each: the packed adds the algorithm needs
+        # (counted analytically, as for useful_frac) at the packed cost, every
+        # other vector instruction at the plain-operation cost -- compares and
+        # shifts among them cost more, so this is a lower bound on the issue
+        # utilisation as `frac` is an upper one
+        weighted = None
+        if useful is not None and secs == secs:
+            packed = 1.5 * k * (rows_per_launch / 128.0)
+            other = max(ctr["valu_instructions"] * scale - packed, 0.0)
+            weighted = ((packed * ISSUE_CYCLES_PACKED
+                         + other * ISSUE_CYCLES_PLAIN)
+                        / (SIMDS * CLOCK_GHZ * 1e9 * secs))
+        roof["frac_weighted"] = weighted
         roof.update({
             "traffic": traffic,
             "algorithmic_bytes_per_row": bytes_per_row,
@@ -758,7 +803,7 @@ def run_rank(args):
             "avg_launch_ms": avg_ms if secs == secs else None,
             "launches": launches,
             "counters": (None if ctr is None else
-                         {"file": "profiles/r3_counters.json",
+                         {"file": "profiles/" + COUNTERS_FILE,
                           "stale": ctr["stale"],
                           "rows_per_launch": ctr["rows_per_launch"]}),
             "timed_every": args.kernel_timing,
@@ -807,9 +852,26 @@ def run_rank(args):
                 "comm_ranks": world if sharded_collective(world, args) else 0,
                 "group_set": ("normalised on the device, the host's copy "
                               "pulled once at the end of the timed region"
-                              if g.core.debug_counts()["device_normalised"]
+                              if timed_counts["device_normalised"]
                               else "normalised by the host after every "
                                    "sub-sweep"),
+                "launches_per_sub_sweep": (
+                    "4: k_vs_tables, score+sample, k_vs_apply, k_vs_reduce"
+                    if timed_counts["fused_batches"] else "separate launches"),
+                # the other BASELINE configurations of this run as scalars
+                # (row-updates/s, exact mode; the records are in
+                # `other_configs` / `batch_variants`)
+                "b65536_value": next((v["value"] for v in variants
+                                      if v["batch_rows"] == 65536), None),
+                "c3_value": next((o["value"] for o in others
+                                  if o["config"] == "gp_nich"
+                                  and o["sampling"] == "exact"), None),
+                "c5_value": next((o["value"] for o in others
+                                  if o["config"] == "dpd"
+                                  and o["sampling"] == "exact"), None),
+                "mixed_value": next((o["value"] for o in others
+                                     if o["config"] == "mixed"
+                                     and o["sampling"] == "exact"), None),
             },
             "roofline": roof,
             "step_breakdown": breakdown,
@@ -822,7 +884,7 @@ def run_rank(args):
                 "all_reduce_avg_us": (1e3 * comm_ms / comm_count
                                       if comm_count else None),
                 "timed": comm_count,
-                "words_per_all_reduce": g.core.stat_words(),
+                "words_per_all_reduce": timed_words,
                 "note": "HIP events around the library's in-place all-reduce "
                         "of the int32 delta image, every `timed_every`-th "
                         "sub-sweep of the timed region and the variants"}

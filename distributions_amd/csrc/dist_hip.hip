@@ -12,7 +12,6 @@
 #include <cstring>
 #include <memory>
 #include <atomic>
-#include <chrono>
 #include <map>
 #include <mutex>
 #include <set>
@@ -722,8 +721,12 @@ struct PyDriver {
 struct Tracker {
     std::vector<uint32_t> p2g;
     std::vector<int32_t> g2p;   // -1 = retired
+    // how often the host changed what a packed index means (a group
+    // swap-removed, the set rebuilt): see Gibbs::run_epoch
+    uint64_t repacked = 0;
 
     void init(size_t n) {
+        repacked += 1;
         p2g.clear();
         g2p.clear();
         for (size_t i = 0; i < n; ++i) add_group();
@@ -737,6 +740,7 @@ struct Tracker {
     void remove_group(uint32_t packed) {
         DIST_REQUIRE(packed < p2g.size(),
                      "bad packed id: " + std::to_string(packed));
+        repacked += 1;
         g2p[p2g[packed]] = -1;
         p2g[packed] = p2g.back();
         p2g.pop_back();
@@ -832,6 +836,11 @@ struct Gibbs {
         DeviceBuf<uint32_t> chunk_first;  // [nvals + 1] first chunk per value
         // rows handed over per chunk (VsDefer): zero between batches
         DeviceBuf<uint32_t> def_counts;
+        // where each group's rows begin in each chunk after its last sort
+        // (VsOffsets), the stamps that say whether that still holds
+        DeviceBuf<int> grp_off;
+        DeviceBuf<uint32_t> off_epoch;
+        int off_stride = 0;
         DeviceBuf<uint32_t> other_pos;    // positions the tiles do not cover
         uint32_t n_other = 0;
         uint32_t n_values_present = 0;    // values with at least one row
@@ -856,10 +865,13 @@ struct Gibbs {
     // sequential chain): such caches are written back and dropped.
     void drop_overlapping_caches(size_t r0, size_t r1, bool keep_exact) {
         for (size_t i = 0; i < vs_cache.size();) {
-            VsCache & c = *vs_cache[i];
-            const bool overlap = c.r0 < r1 && r0 < c.r1;
-            const bool exact = c.r0 == r0 && c.r1 == r1;
+            // (the compact copy of the ranges: a pass at 65 536 rows per batch
+            // has 153 of them, and walking the objects themselves cost the
+            // host 15 us per look)
+            const bool overlap = vs_ranges[i].first < r1 && r0 < vs_ranges[i].second;
+            const bool exact = vs_ranges[i].first == r0 && vs_ranges[i].second == r1;
             if (!overlap || (exact && keep_exact)) { ++i; continue; }
+            VsCache & c = *vs_cache[i];
             if (c.dirty) {
                 const size_t n = c.r1 - c.r0;
                 LAUNCH(k_pos_scatter, n, c.assign_pos.p, c.sorted_rows.p,
@@ -867,10 +879,19 @@ struct Gibbs {
             }
             sync();   // the cache's buffers are freed below
             vs_cache.erase(vs_cache.begin() + (long)i);
+            vs_ranges.erase(vs_ranges.begin() + (long)i);
+            vs_last = 0;
         }
     }
     std::vector<std::unique_ptr<VsCache>> vs_cache;
-    DeviceBuf<float> vsLA, vsLB, vsM, vsmB, vsPA, vsPB;
+    std::vector<std::pair<size_t, size_t>> vs_ranges;   // [r0, r1) of each
+    size_t vs_last = 0;   // where the last look-up found its range
+    DeviceBuf<float> vsLA, vsLB, vsM, vsmB, vsPA, vsPB, vsOwn;
+    // the removal epoch (DevState::pad) the groups' recorded offsets are
+    // stamped with (VsOffsets): carried from one device-normalised run to the
+    // next as long as the host did not re-pack the groups in between
+    uint32_t run_epoch = 0;
+    uint64_t repacked_seen = ~0ull;
     DeviceBuf<int32_t> vs_stage;   // [chunks][K] deltas of the open batch
     DeviceBuf<int> vsBandMode;     // VsTables::band_mode
     DeviceBuf<VsTile> vsBandTile;  // VsTables::band_tile
@@ -1112,6 +1133,9 @@ struct Gibbs {
             (void)hipEventDestroy(pr.first);
             (void)hipEventDestroy(pr.second);
         }
+        if (peek_pending) (void)hipEventSynchronize(peek_event);
+        if (peek_event) (void)hipEventDestroy(peek_event);
+        if (pinned_state) (void)hipHostFree(pinned_state);
         if (pinned_counts) (void)hipHostFree(pinned_counts);
         if (pinned_seq) (void)hipHostFree(pinned_seq);
         if (pinned_pairs) (void)hipHostFree(pinned_pairs);
@@ -1373,6 +1397,8 @@ struct Gibbs {
         // value tables of the count-valued ones)
         max_value.assign((size_t)F(), 0);
         vs_cache.clear();
+        vs_ranges.clear();
+        vs_last = 0;
         fold_cache.clear();
         for (int f = 0; f < F(); ++f) {
             const int kind = feats[f]->sh.kind;
@@ -1809,8 +1835,18 @@ struct Gibbs {
     }
 
     VsCache & vs_get(size_t r0, size_t r1) {
-        for (auto & c : vs_cache)
-            if (c->r0 == r0 && c->r1 == r1) return *c;
+        // (a pass visits its ranges in order: the one after the last hit first)
+        const std::pair<size_t, size_t> want(r0, r1);
+        for (size_t probe : {vs_last, vs_last + 1})
+            if (probe < vs_ranges.size() && vs_ranges[probe] == want) {
+                vs_last = probe;
+                return *vs_cache[probe];
+            }
+        for (size_t i = 0; i < vs_ranges.size(); ++i)
+            if (vs_ranges[i] == want) {
+                vs_last = i;
+                return *vs_cache[i];
+            }
         std::unique_ptr<VsCache> c(new VsCache());
         c->r0 = r0;
         c->r1 = r1;
@@ -1931,8 +1967,11 @@ struct Gibbs {
             flush_assign_pos();
             sync();   // the evicted range's buffers are freed below
             vs_cache.erase(vs_cache.begin());
+            vs_ranges.erase(vs_ranges.begin());
         }
         vs_cache.push_back(std::move(c));
+        vs_ranges.push_back(want);
+        vs_last = vs_cache.size() - 1;
         return *vs_cache.back();
     }
 
@@ -1947,13 +1986,17 @@ struct Gibbs {
         void go() {
             const uint32_t nv = (uint32_t)self->vs_nvals();
             if (fused)
-                self->launch_tables<KIND>(*P, T);
+                self->launch_tables<KIND>(*P, T, *c);
             else
                 hipLaunchKernelGGL((k_vs_prepare<KIND>), dim3(nv), dim3(kBlock),
                                    T.PA ? (size_t)T.Kpad * 8 : 0,
                                    stream(), *P, T, self->deferred_count.p,
                                    c->n_other);
             HIP_CHECK(hipGetLastError());
+            // (A variant in which the tile's own wave sampled such rows on a
+            // strip of LDS once its tile was done -- off k_vs_apply's path --
+            // was measured: k_vs_apply 17.4 -> 14.8 us on average, k_vs_sample
+            // 79 -> 86: its 64 registers spill.)
             const VsDefer D{self->deferred.p, self->deferred_count.p,
                             fused ? c->def_counts.p : nullptr, c->chunks.p};
             self->phase_mark(1);
@@ -1964,7 +2007,7 @@ struct Gibbs {
                 // (waves alone or in pairs on their SIMDs read a whole chunk
                 // ahead; more of them half a chunk, and four fit)
                 const size_t lds =
-                    2 * ((size_t)T.Kpad + 2 * kVsUnroll) * sizeof(float);
+                    2 * ((size_t)T.Kuse + 2 * kVsUnroll) * sizeof(float);
 #define VS_NARROW(HQ)                                                        \
                 hipLaunchKernelGGL(                                          \
                     (k_vs_narrow<KIND, HQ>), dim3(c->n_narrow_tiles),        \
@@ -2011,7 +2054,8 @@ struct Gibbs {
     bool fused_ok(const VsCache & c, int Kpad) const {
         if (!fused_tables_mode || !async_active || sampling_mode != 0)
             return false;
-        if (Kpad > 8192 || c.mixed_chunks || any_float_stats()) return false;
+        if (Kpad > kTablesMaxK || c.mixed_chunks || any_float_stats())
+            return false;
         const size_t lds_sort =
             ((size_t)K() * 2 + kVsApplyBlock / 64 + 4 * kVsApplyRows + 4) * 4;
         if (lds_sort > 144 * 1024) return false;
@@ -2020,7 +2064,7 @@ struct Gibbs {
     // k_vs_tables for the open batch; afterwards the OUT buffers are the live
     // ones and P points at them
     template <int KIND>
-    void launch_tables(SweepParams & P, const VsTables & T) {
+    void launch_tables(SweepParams & P, const VsTables & T, VsCache & c) {
         Slave & f = *feats[0];
         TablesParams A;
         memset(&A, 0, sizeof(A));
@@ -2050,7 +2094,8 @@ struct Gibbs {
         A.d = d;
         A.n_empty = py.n_empty;
         A.sample_size = py.sample_size;
-        A.assign_pos = P.assign_pos;
+        A.offsets = VsOffsets{c.grp_off.p, c.off_epoch.p, c.off_stride};
+        A.k_limit = T.Kuse;
         const size_t lds = ((size_t)T.Kpad * 4 + 2) * 4;
         int device = 0;
         HIP_CHECK(hipGetDevice(&device));
@@ -2062,8 +2107,8 @@ struct Gibbs {
                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             have.store(lds, std::memory_order_relaxed);
         }
-        hipLaunchKernelGGL((k_vs_tables<KIND>), dim3(T.n_values), dim3(kBlock),
-                           lds, stream(), A, T);
+        hipLaunchKernelGGL((k_vs_tables<KIND>), dim3(T.n_values),
+                           dim3(kTablesBlock), lds, stream(), A, T);
         HIP_CHECK(hipGetLastError());
         finish_pending = false;   // (this launch normalised the group set)
         base_valid = true;
@@ -2236,9 +2281,15 @@ struct Gibbs {
         vsM.reserve(nv, 0);
         vsmB.reserve(nv, 0);
         vsArg.reserve(nv, 0);
+        // (what this launch walks and keeps in LDS: the group count's bound
+        // at this batch; Kpad, the run's, is the tables' row stride)
+        const int Kuse =
+            fused ? std::min(Kpad, (k_limit() + kVsUnroll - 1) / kVsUnroll
+                                       * kVsUnroll)
+                  : Kpad;
         // chunk-boundary running sums: worth their serial pass in
         // k_vs_prepare once the sampling kernel is throughput-bound
-        const bool narrow = use_narrow(c, Kpad);
+        const bool narrow = use_narrow(c, Kuse);
         narrow_batches += narrow ? 1 : 0;
         const bool large = !narrow
                            && c.n_tiles >= (uint32_t)running_sums_min_tiles;
@@ -2267,6 +2318,7 @@ struct Gibbs {
             vsPA.reserve(grow_capacity((size_t)nv * (Kpad / kVsUnroll)), 0);
             vsPB.reserve(grow_capacity((size_t)nv * (Kpad / kVsUnroll)), 0);
         }
+        if (fused) vsOwn.reserve(grow_capacity((size_t)nv * Kpad), 0);
         deferred.reserve(std::max<size_t>(n, 1), 0);
         deferred_count.reserve(1, 0);
         // base[], base_single[] and the scalars; the few handed-over rows
@@ -2287,7 +2339,8 @@ struct Gibbs {
                             prefix ? vsPB.p : nullptr,
                             bands ? vsBandMode.p : nullptr,
                             bands ? vsBandTile.p : nullptr, c.val_start.p,
-                            nv, nullptr, c.chunk_first.p}, narrow, fused};
+                            nv, nullptr, c.chunk_first.p,
+                            fused ? vsOwn.p : nullptr, Kuse}, narrow, fused};
         // DIST_VS_STAMPS=<file>: per-wave phase stamps of every launch (the
         // last one stays in the file): tools/vs_stamps.py
         static const char * stamps_path = getenv("DIST_VS_STAMPS");
@@ -2637,6 +2690,20 @@ struct Gibbs {
             const VsDefer D{deferred.p, deferred_count.p,
                             batch_fused ? c.def_counts.p : nullptr,
                             c.chunks.p};
+            // the sorting form of a device-normalised run leaves the groups'
+            // offsets per chunk (bands without a walk, k_vs_tables); any
+            // other form clears the stamps of a range that has some
+            VsOffsets O{nullptr, c.off_epoch.p, 0};
+            if (sort && async_active && c.one_chunk_per_value) {
+                if (c.off_stride < K() + 2) {
+                    c.off_stride = (int)grow_capacity((size_t)K() + 2);
+                    c.grp_off.release();
+                    c.grp_off.reserve((size_t)c.n_chunks * c.off_stride, 0);
+                    c.off_epoch.release();
+                    c.off_epoch.reserve(std::max<size_t>(c.n_chunks, 1), 0);
+                }
+                O = VsOffsets{c.grp_off.p, c.off_epoch.p, c.off_stride};
+            }
 #define VS_APPLY(KIND, SORT, LDS)                                            \
             do {                                                             \
                 /* beyond the default opt-in: raised (never lowered) once  \
@@ -2656,14 +2723,15 @@ struct Gibbs {
                                    LDS, stream(), P, img, c.chunks.p,        \
                                    c.sorted_rows.p, d_p2g_ptr,               \
                                    c.assign_pos.p, (uint32_t)vs_nvals(),     \
-                                   refresh, sole, stage, D);                 \
+                                   refresh, sole, stage, D, O);              \
                 if (stage)                                                   \
                     hipLaunchKernelGGL((k_vs_reduce<KIND>), rgrid, rblock,   \
                                        0, stream(), img, stage, c.chunks.p,  \
                                        c.n_chunks, K(),                      \
                                        (uint32_t)vs_nvals(), pairs,          \
                                        pairs_seq,                            \
-                                       async_active ? dev_ptr() : nullptr);  \
+                                       async_active ? dev_ptr() : nullptr,   \
+                                       k_limit());                           \
             } while (0)
             // chunks of several values first (their rows of the staging
             // matrix must be there when k_vs_reduce runs)
@@ -3088,6 +3156,7 @@ struct Gibbs {
         DevState both[2];
         dev_state.download(both, 2);
         const DevState st = both[dev_cur];
+        run_epoch = (uint32_t)st.pad;   // (where the next run goes on)
         const size_t Kn = (size_t)st.K;
         py.counts.resize(Kn);
         py.d_counts.download(py.counts.data(), Kn);
@@ -3110,14 +3179,56 @@ struct Gibbs {
     // into is reserved up front (growing a buffer synchronises), the state
     // the kernels read is put on the device, and K() becomes the bound.
     hipEvent_t async_own0 = nullptr, async_own1 = nullptr;
-    std::vector<size_t> async_rows;   // rows of each batch sampled (timing)
-    std::vector<char> async_timed;    // ... and whether its events were set
+    std::vector<size_t> async_rows;   // rows of each TIMED batch of the run
     // A run stays open when its sweep returns (the host's mirrors are pulled
     // by the next call that is not another such sweep: settle()), so that
     // consecutive sweeps pay for the hand-over of the state once: room for
     // kAsyncSweeps sweeps like the first is reserved where the kernels' LDS
     // allows, and async_left counts the batches still covered.
     static constexpr size_t kAsyncSweeps = 8;
+    // ... and with the fused launch (whose work follows the per-launch bound
+    // on the group count, k_limit(), not the run's) as many sweeps as its
+    // LDS allows, up to this many batches
+    static constexpr size_t kAsyncMaxBatches = 16384;
+    // The group count is at most this when batch `index` of the open run is
+    // sampled: every batch can fill each empty group once.  K_seen is the
+    // device's own count, copied back without waiting for it (async_peek).
+    size_t run_batches = 0;          // batches sampled in the open run
+    int K_seen = 0;
+    size_t K_seen_batch = 0;
+    DevState * pinned_state = nullptr;
+    hipEvent_t peek_event = nullptr;
+    bool peek_pending = false;
+    size_t peek_batch = 0;
+    int k_limit() const {
+        if (!async_active) return K();
+        const size_t grown = (size_t)K_seen
+            + (run_batches - K_seen_batch + 1) * (size_t)py.n_empty;
+        return (int)std::min<size_t>((size_t)K(), grown);
+    }
+    // the device's state on its way to pinned memory (no wait); the next
+    // sweep of the run picks it up if it has arrived
+    void async_peek() {
+        if (!pinned_state) {
+            HIP_CHECK(hipHostMalloc((void **)&pinned_state, sizeof(DevState),
+                                    hipHostMallocDefault));
+            HIP_CHECK(hipEventCreateWithFlags(&peek_event,
+                                              hipEventDisableTiming));
+        }
+        if (peek_pending) return;   // (one in flight)
+        HIP_CHECK(hipMemcpyAsync(pinned_state, dev_ptr(), sizeof(DevState),
+                                 hipMemcpyDeviceToHost, stream()));
+        HIP_CHECK(hipEventRecord(peek_event, stream()));
+        peek_pending = true;
+        peek_batch = run_batches;
+    }
+    void async_peek_collect() {
+        if (!peek_pending || hipEventQuery(peek_event) != hipSuccess) return;
+        peek_pending = false;
+        // (the state before the last batch's own moves were normalised)
+        K_seen = pinned_state->K + py.n_empty;
+        K_seen_batch = peek_batch;
+    }
     size_t async_left = 0;
     int async_K0 = 0;                    // the group count the run began with
     hipStream_t async_stream = nullptr;  // the stream the run is queued on
@@ -3127,11 +3238,25 @@ struct Gibbs {
     DeviceBuf<int> agree_flag;
     void async_begin(size_t n_first) {
         const int K0 = K();
+        const size_t ne = (size_t)py.n_empty;
         size_t n_batches = kAsyncSweeps * n_first;
-        if (!async_bound_fits((size_t)K0 + n_batches * (size_t)py.n_empty)
-            || n_batches > 4096)
+        if (fused_tables_mode && (size_t)K0 + n_first * ne + 64 <= kTablesMaxK) {
+            const size_t room = ((size_t)kTablesMaxK - 64 - (size_t)K0) / ne;
+            const size_t sweeps =
+                std::min(room, kAsyncMaxBatches) / std::max<size_t>(n_first, 1);
+            n_batches = std::max<size_t>(sweeps, 1) * n_first;
+        }
+        if (!async_bound_fits((size_t)K0 + n_batches * ne)
+            || n_batches > kAsyncMaxBatches)
             n_batches = n_first;
         async_left = n_batches;
+        run_batches = 0;
+        K_seen = K0;
+        K_seen_batch = 0;
+        if (peek_pending) {   // (a copy of another run's state: not wanted)
+            (void)hipEventSynchronize(peek_event);
+            peek_pending = false;
+        }
         const int bound = K0 + (int)n_batches * py.n_empty;
         py.reserve(bound);
         for (auto & s : feats) s->reserve(bound);
@@ -3149,6 +3274,19 @@ struct Gibbs {
         st.global_size = (uint32_t)tracker.g2p.size();
         st.first_new_global = st.global_size;
         st.nonempty = K0 - py.n_empty;
+        // (DevState::pad: the removal epoch the groups' recorded offsets are
+        // stamped with, VsOffsets; it moves on once per batch at most)
+        if (tracker.repacked != repacked_seen || run_epoch == 0u)
+            run_epoch = (run_epoch + (1u << 20)) & ~((1u << 20) - 1u);
+        repacked_seen = tracker.repacked;
+        if (run_epoch == 0u) {   // wrapped: no old stamp may match again
+            for (auto & c : vs_cache)
+                if (c->off_epoch.p)
+                    HIP_CHECK(hipMemsetAsync(c->off_epoch.p, 0,
+                                             c->off_epoch.cap * 4, stream()));
+            run_epoch = 1u << 20;
+        }
+        st.pad = (int)run_epoch;
         const DevState both[2] = {st, st};
         dev_state.upload(both, 2);
         dev_cur = 0;
@@ -3176,15 +3314,9 @@ struct Gibbs {
             SweepParams P0 = params(0, 0, 0, 0);
             prepare(P0, false);
         }
-        while (ev_pool.size() < 2 * n_batches) {
-            hipEvent_t e = nullptr;
-            HIP_CHECK(hipEventCreate(&e));
-            ev_pool.push_back(e);
-        }
         async_own0 = ev0;
         async_own1 = ev1;
         async_rows.clear();
-        async_timed.clear();
         py.counts.resize((size_t)bound, 0);   // from here on K() is the bound
         async_K0 = K0;
         async_stream = stream();
@@ -3193,14 +3325,26 @@ struct Gibbs {
     }
     // sample one batch of a device-normalised run (its events from the pool)
     void async_sample(size_t b, size_t e, uint32_t seed, uint64_t draw_base) {
-        const size_t i = async_rows.size();
-        ev0 = ev_pool[2 * i];
-        ev1 = ev_pool[2 * i + 1];
+        // (events only for the batches kernel_timing picks: batch_sample's
+        // own rule, looked at before it counts the batch)
+        const bool will_time =
+            e > b && kernel_timing > 0
+            && timing_tick % (uint64_t)kernel_timing == 0;
+        if (will_time) {
+            const size_t i = async_rows.size();
+            while (ev_pool.size() < 2 * (i + 1)) {
+                hipEvent_t ev = nullptr;
+                HIP_CHECK(hipEventCreate(&ev));
+                ev_pool.push_back(ev);
+            }
+            ev0 = ev_pool[2 * i];
+            ev1 = ev_pool[2 * i + 1];
+        }
         batch_sample(b, e, seed, draw_base);
         DIST_REQUIRE(e == b || batch_value_sorted,
                      "internal: device-normalised run left its path");
-        async_rows.push_back(e - b);
-        async_timed.push_back(e > b && timing_this_batch ? 1 : 0);
+        if (will_time) async_rows.push_back(e - b);
+        run_batches += 1;
         async_batches += 1;
     }
     // back to host-driven operation; `failed`: on the way out of an error
@@ -3212,6 +3356,7 @@ struct Gibbs {
             batch_open = false;
             (void)hipStreamSynchronize(stream());
             async_active = false;
+            tracker.repacked += 1;   // (recorded offsets: not to be trusted)
             try { pull_host_state(); } catch (...) {}
             return;
         }
@@ -3226,7 +3371,7 @@ struct Gibbs {
         async_active = false;
         collect_comm_timing();
         for (size_t i = 0; i < async_rows.size(); ++i) {
-            if (!async_rows[i] || !async_timed[i]) continue;
+            if (!async_rows[i]) continue;
             float ms = 0.f;
             HIP_CHECK(hipEventElapsedTime(&ms, ev_pool[2 * i],
                                           ev_pool[2 * i + 1]));
@@ -3240,6 +3385,7 @@ struct Gibbs {
         const size_t n_batches = (r1 - r0 + batch - 1) / batch;
         if (!async_active) async_begin(n_batches);   // else: it goes on
         async_left -= n_batches;
+        async_peek_collect();
         try {
             for (size_t b = r0; b < r1; b += batch) {
                 async_sample(b, std::min(r1, b + batch), seed, draw_base);
@@ -3248,6 +3394,7 @@ struct Gibbs {
                 batch_finish_device();
                 phase_mark(5);
             }
+            async_peek();
         } catch (...) {
             async_end(true);
             throw;
@@ -4303,26 +4450,34 @@ int dist_gibbs_sweep_sharded(dist_gibbs_t * g, dist_comm_t * c,
         // flag when a run is opened: the layout of the delta image depends
         // on it).  Like the single-engine sweep, the run then stays open
         // across passes of the same tiling; any other call settles it.
+        // Whether an open run goes on is decided by ALL ranks, on every
+        // call: a rank whose run was settled in between (any other entry
+        // point does that -- a look at the group count, a checkpoint) would
+        // otherwise issue the one-word agreement while its peers issue the
+        // delta all-reduce, collectives of different size and operation.
         Gibbs * open = g->impl.open();
-        bool on_device = false;
-        if (open->async_active && !open->batch_open
-            && open->sharded_batches == n_batches
-            && open->sharded_batch_rows == batch_rows
-            && n_batches <= open->async_left) {
-            on_device = true;   // the open run goes on
-        } else {
-            Gibbs & s = *g->impl;   // (settles an open run)
-            int mine = s.sharded_device_normalise
-                       && s.async_eligible_sharded(n_batches, batch_rows)
-                           ? 1 : 0;
-            s.agree_flag.reserve(1, 0);
-            HIP_CHECK(hipMemcpyAsync(s.agree_flag.p, &mine, sizeof(int),
+        auto agree = [&](Gibbs & e, int mine) {
+            e.agree_flag.reserve(1, 0);
+            HIP_CHECK(hipMemcpyAsync(e.agree_flag.p, &mine, sizeof(int),
                                      hipMemcpyHostToDevice, stream()));
-            RCCL_CHECK(rccl().all_reduce(s.agree_flag.p, s.agree_flag.p, 1,
+            RCCL_CHECK(rccl().all_reduce(e.agree_flag.p, e.agree_flag.p, 1,
                                          ncclInt32, ncclMin, c->comm,
                                          stream()));
-            s.agree_flag.download(&mine, 1);
-            on_device = mine != 0;
+            e.agree_flag.download(&mine, 1);
+            return mine != 0;
+        };
+        bool on_device = agree(
+            *open, open->async_active && !open->batch_open
+                       && open->sharded_batches == n_batches
+                       && open->sharded_batch_rows == batch_rows
+                       && n_batches <= open->async_left
+                   ? 1 : 0);   // the open runs go on, everywhere or nowhere
+        if (!on_device) {
+            Gibbs & s = *g->impl;   // (settles an open run)
+            on_device = agree(
+                s, s.sharded_device_normalise
+                       && s.async_eligible_sharded(n_batches, batch_rows)
+                   ? 1 : 0);
             if (on_device) {
                 s.async_begin(n_batches);
                 s.sharded_batches = n_batches;
@@ -4330,7 +4485,10 @@ int dist_gibbs_sweep_sharded(dist_gibbs_t * g, dist_comm_t * c,
             }
         }
         Gibbs & e = *open;
-        if (on_device) e.async_left -= std::min(e.async_left, n_batches);
+        if (on_device) {
+            e.async_left -= std::min(e.async_left, n_batches);
+            e.async_peek_collect();
+        }
         try {
             for (size_t b = 0; b < n_batches; ++b) {
                 const size_t r0 = std::min(e.n_rows, b * batch_rows);
@@ -4375,6 +4533,7 @@ int dist_gibbs_sweep_sharded(dist_gibbs_t * g, dist_comm_t * c,
                 if (on_device) e.batch_finish_device();
                 else e.batch_finish();
             }
+            if (on_device) e.async_peek();
         } catch (...) {
             if (on_device) e.async_end(true);
             throw;

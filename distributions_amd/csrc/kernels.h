@@ -2060,12 +2060,22 @@ __device__ __forceinline__ void wave_row_update(
         size_t out) {
     const RowScorer<KIND0, KIND1, NF> rs(P, row, global_id);
     const int Kl = rs.Kl;
-    // scores and vector_max (vector_math.cc:74-83; max is order-free)
+    // scores and vector_max (vector_math.cc:74-83; max is order-free); four
+    // slots per lane and round, so that their gathers are in flight together
+    // (a round is a trip to memory: the row's latency is the rounds')
     float m = -INFINITY;
-    for (int k = lane; k < Kl; k += 64) {
-        const float s = rs.at_lane(k);
-        sl[k] = s;
-        m = s > m ? s : m;
+    constexpr int U = 4;
+    for (int k0 = lane; k0 < Kl; k0 += 64 * U) {
+        float s[U];
+#pragma unroll
+        for (int q = 0; q < U; ++q)
+            s[q] = k0 + 64 * q < Kl ? rs.at_lane(k0 + 64 * q) : -INFINITY;
+#pragma unroll
+        for (int q = 0; q < U; ++q)
+            if (k0 + 64 * q < Kl) {
+                sl[k0 + 64 * q] = s[q];
+                m = s[q] > m ? s[q] : m;
+            }
     }
     for (int off = 32; off > 0; off >>= 1) {
         const float o = __shfl_xor(m, off);
@@ -2430,9 +2440,18 @@ struct VsTables {
     // DIST_VS_STAMPS=<file>; tools/vs_stamps.py): per wave of k_vs_sample
     // five s_memtime stamps and HW_ID; null otherwise
     unsigned long long * stamps;
-    // [nvals] index of the first apply chunk of each value (chunks of one
-    // value each, kVsApplyRows rows apart: a band tile's rows find theirs)
+    // [nvals + 1] index of the first apply chunk of each value (chunks of
+    // one value each, kVsApplyRows rows apart: a band tile's rows find theirs)
     const uint32_t * chunk_first;
+    // [nvals][Kpad] (k_vs_tables; null otherwise) the own-slot likelihood of a
+    // row of value x that sits in group k, taken out of it -- what the tiles'
+    // set-up computes per row from three gathers and three logarithms -- or
+    // -1: the row is handed over
+    float * own;
+    // what the launch walks (speculative loads, k_vs_narrow's copies in LDS):
+    // the bound on the group count at THIS batch, a multiple of kVsUnroll,
+    // <= Kpad (which stays the run's row stride)
+    int Kuse;
 };
 constexpr uint32_t kVsBandWalkRows = 8192;
 
@@ -2666,6 +2685,17 @@ __global__ __launch_bounds__(kBlock) void k_vs_prepare(
 //    writes S[x][.] (dd.hpp:399-421);
 //  * then the value's tables as k_vs_prepare builds them, from the scores it
 //    has in LDS: the same float operations in the same order.
+// Where k_vs_apply (sorting form) leaves, per chunk, the position at which
+// each group's rows begin after its sort -- off[c * stride + k], k <= the
+// host's bound on the group count -- stamped with the run's removal epoch
+// (DevState::pad: packed indices mean the same as long as no group was
+// swap-removed).  k_vs_tables reads the arg-max group's band of rows from it
+// instead of walking the value's rows.
+struct VsOffsets {
+    int * off;
+    uint32_t * epoch;   // [chunks]; 0 = no offsets
+    int stride;
+};
 struct TablesParams {
     SlaveView feat;              // i0 / i1: the OUT buffers
     const int32_t * i0_in;
@@ -2685,53 +2715,74 @@ struct TablesParams {
     float alpha, d;
     int n_empty;                 // invariant of the chain
     long long sample_size;       // rows in the mixture (invariant)
-    const uint32_t * assign_pos; // the rows' groups by position (band walk)
+    VsOffsets offsets;           // (off == nullptr: none recorded)
+    // what the group count can be at most at THIS launch (the run's bound,
+    // T.Kpad, sizes the buffers; a run that stays open for many sweeps would
+    // otherwise have every launch walk the whole bound)
+    int k_limit;
 };
+constexpr int kTablesBlock = 1024;
+constexpr int kTablesPer = 8;            // groups per thread
+constexpr int kTablesMaxK = kTablesBlock * kTablesPer;
 template <int KIND>
-__global__ __launch_bounds__(kBlock) void k_vs_tables(TablesParams A,
-                                                      VsTables T) {
-    // [Kpad] scores, then LA | [Kpad] LB | [Kpad + 2] emptied-before, then own
-    // scores | [Kpad] the slot each slot's group comes from
+__global__ __launch_bounds__(kTablesBlock) void k_vs_tables(TablesParams A,
+                                                            VsTables T) {
+    // [Kpad] LA | [Kpad] LB for the running sums | the plan of a batch that
+    // swap-removes groups: [Kpad + 2] vanished-before | [Kpad] the slot each
+    // slot's group comes from
     extern __shared__ float tb_lds[];
-    __shared__ float r_m1[kBlock / 64], r_m2[kBlock / 64];
-    __shared__ int r_i1[kBlock / 64];
-    __shared__ int s_sum[2][kBlock / 64];
-    __shared__ float sh_M, sh_mB;
-    __shared__ uint32_t sh_lo, sh_hi, sh_n;
-    __shared__ int sh_amax;
+    constexpr int kWaves = kTablesBlock / 64;
+    __shared__ float r_m1[kWaves], r_m2[kWaves];
+    __shared__ int r_i1[kWaves];
+    __shared__ int s_sum[2][kWaves];
+    __shared__ float sh_so;
     const int Kpad = T.Kpad;
-    float * sc = tb_lds;
-    float * lbuf = sc + Kpad;
-    int * before = reinterpret_cast<int *>(lbuf + Kpad);
-    float * own = reinterpret_cast<float *>(before);
-    int * src_of = before + Kpad + 2;
     const uint32_t x = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     SlaveView v = A.feat;
     v.kind = KIND;
+    // ---- everything the kernel reads per group, in ONE trip to memory: the
+    // loads assume that no group vanished (slot k's group stays in slot k),
+    // the usual case; a batch that swap-removed groups reads again below
+    int was[kTablesPer], now[kTablesPer], st0[kTablesPer], st1[kTablesPer],
+        cell[kTablesPer];
+#pragma unroll
+    for (int e = 0; e < kTablesPer; ++e) {
+        const int k = tid + e * kTablesBlock;
+        was[e] = now[e] = st0[e] = st1[e] = cell[e] = 0;
+        if (k < A.k_limit) {   // (<= Kpad: the buffers are that large)
+            was[e] = A.snap_in[k];
+            now[e] = A.counts_in[k];
+            st0[e] = A.i0_in[k];
+            st1[e] = A.i1_in[k];
+            if (is_cat(KIND)) cell[e] = v.cnt[(size_t)k * v.dim + x];
+        }
+    }
+    const float prior_x = is_cat(KIND) ? v.prior[x] : 0.f;
     const int K0 = A.dev_in->K;
     const uint32_t global_size0 = A.dev_in->global_size;
-    auto emptied_at = [&](int k) {
-        return A.snap_in[k] > 0 && A.counts_in[k] == 0;
-    };
+    const uint32_t epoch0 = (uint32_t)A.dev_in->pad;
     // ---- the plan: vanished and filled groups since the last batch's entry
     int removed = 0, n_created = 0;
     {
-        int e = 0, c = 0;
-        for (int k = tid; k < K0; k += kBlock) {
-            const int was = A.snap_in[k], now = A.counts_in[k];
-            e += (was > 0 && now == 0);
-            c += (was == 0 && now > 0);
+        int e_sum = 0, c_sum = 0;
+#pragma unroll
+        for (int e = 0; e < kTablesPer; ++e) {
+            const int k = tid + e * kTablesBlock;
+            if (k < K0) {
+                e_sum += (was[e] > 0 && now[e] == 0);
+                c_sum += (was[e] == 0 && now[e] > 0);
+            }
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
-            e += __shfl_xor(e, off);
-            c += __shfl_xor(c, off);
+            e_sum += __shfl_xor(e_sum, off);
+            c_sum += __shfl_xor(c_sum, off);
         }
-        if (lane == 0) { s_sum[0][wave] = e; s_sum[1][wave] = c; }
+        if (lane == 0) { s_sum[0][wave] = e_sum; s_sum[1][wave] = c_sum; }
         __syncthreads();
 #pragma unroll
-        for (int w = 0; w < kBlock / 64; ++w) {
+        for (int w = 0; w < kWaves; ++w) {
             removed += s_sum[0][w];
             n_created += s_sum[1][w];
         }
@@ -2740,13 +2791,18 @@ __global__ __launch_bounds__(kBlock) void k_vs_tables(TablesParams A,
     const int k_new = size;
     const int K1 = size + n_created;
     const int nonempty = K1 - A.n_empty;
+    int * before = reinterpret_cast<int *>(tb_lds + 2 * (size_t)Kpad);
+    int * src_of = before + Kpad + 2;
+    auto emptied_at = [&](int k) {
+        return A.snap_in[k] > 0 && A.counts_in[k] == 0;
+    };
     if (removed > 0) {
         // before[k] = vanished groups in [0, k); then, as k_normalise: the i-th
         // removal (descending slots) pulls in what sits in slot K0 - 1 - i at
         // that time, so a vacated slot in front of the new end follows that
         // chain to the survivor it ends up with
         __syncthreads();   // (s_sum is reused)
-        const int per = (K0 + kBlock - 1) / kBlock;
+        const int per = (K0 + kTablesBlock - 1) / kTablesBlock;
         const int lo = min(K0, tid * per), hi = min(K0, lo + per);
         int mine = 0;
         for (int k = lo; k < hi; ++k) mine += emptied_at(k);
@@ -2766,7 +2822,7 @@ __global__ __launch_bounds__(kBlock) void k_vs_tables(TablesParams A,
         }
         if (hi == K0 && lo < K0) before[K0] = run;
         __syncthreads();
-        for (int k = tid; k < size; k += kBlock) {
+        for (int k = tid; k < size; k += kTablesBlock) {
             int t = k;
             if (before[k + 1] != before[k]) {
                 do {
@@ -2776,55 +2832,68 @@ __global__ __launch_bounds__(kBlock) void k_vs_tables(TablesParams A,
             src_of[k] = t;
         }
         __syncthreads();
-    }
-    // ---- this value's column of the categorical counts, in place: moved
-    // groups' cells follow them (all reads before any write: a source slot
-    // may be one that is cleared for an appended group), appended groups'
-    // cells are zero (Group::init, dd.hpp:113-121)
-    if (is_cat(KIND) && (removed > 0 || n_created > 0)) {
-        int * moved = reinterpret_cast<int *>(lbuf);
-        if (removed > 0) {
-            for (int k = tid; k < size; k += kBlock)
-                if (src_of[k] != k)
-                    moved[k] = v.cnt[(size_t)src_of[k] * v.dim + x];
-            __syncthreads();
-            for (int k = tid; k < size; k += kBlock)
-                if (src_of[k] != k) v.cnt[(size_t)k * v.dim + x] = moved[k];
+        // the statistics again, through the plan; this value's column of the
+        // categorical counts follows the moved groups in place (all reads
+        // before any write: a source slot may be cleared below)
+#pragma unroll
+        for (int e = 0; e < kTablesPer; ++e) {
+            const int k = tid + e * kTablesBlock;
+            if (k < size) {
+                const int t = src_of[k];
+                now[e] = A.counts_in[t];
+                st0[e] = A.i0_in[t];
+                st1[e] = A.i1_in[t];
+                if (is_cat(KIND)) cell[e] = v.cnt[(size_t)t * v.dim + x];
+            }
         }
-        for (int k = k_new + tid; k < K1; k += kBlock)
-            v.cnt[(size_t)k * v.dim + x] = 0;
         __syncthreads();
+        if (is_cat(KIND)) {
+#pragma unroll
+            for (int e = 0; e < kTablesPer; ++e) {
+                const int k = tid + e * kTablesBlock;
+                if (k < size && src_of[k] != k)
+                    v.cnt[(size_t)k * v.dim + x] = cell[e];
+            }
+        }
     }
-    // ---- every group's statistics through the plan, its cache entry, its
-    // score for this value (k_vs_prepare's pass 1), its own-slot score
+    // ---- every group's cache entry, its score for this value (k_vs_prepare's
+    // pass 1), its own-slot score; appended groups are empty (Group::init,
+    // dd.hpp:113-121)
     const bool owner = x == 0;
     const float shift = py_shift(A.sample_size - 1, A.alpha);
     const float empty_score = py_empty_score(A.alpha, A.d, nonempty, A.n_empty);
     const float empty_single =
         py_empty_score(A.alpha, A.d, nonempty - 1, A.n_empty);
     const float lf = KIND == DIST_GP ? fast_log_factorial(x) : 0.f;
+    float sc[kTablesPer], so[kTablesPer];
     float m1 = -INFINITY, m2 = -INFINITY;
     int i1 = 0x7fffffff;
-    for (int k = tid; k < K1; k += kBlock) {
+#pragma unroll
+    for (int e = 0; e < kTablesPer; ++e) {
+        const int k = tid + e * kTablesBlock;
+        sc[e] = 0.f;
+        so[e] = INFINITY;
+        if (k >= K1) continue;
         const bool fresh = k >= k_new;
-        const int ks = (removed > 0 && !fresh) ? src_of[k] : k;
-        const int n = fresh ? 0 : A.counts_in[ks];
-        const Stats st = {fresh ? 0 : A.i0_in[ks], fresh ? 0 : A.i1_in[ks],
-                          0.f, 0.f};
-        int c = 0;
-        Entry e = {0.f, 0.f, 0.f, 0.f};
+        if (fresh) {
+            now[e] = st0[e] = st1[e] = cell[e] = 0;
+            if (is_cat(KIND)) v.cnt[(size_t)k * v.dim + x] = 0;
+        }
+        const int n = now[e];
+        const Stats st = {st0[e], st1[e], 0.f, 0.f};
+        const int c = cell[e];
+        Entry en = {0.f, 0.f, 0.f, 0.f};
         if (is_cat(KIND)) {
-            c = v.cnt[(size_t)k * v.dim + x];
-            e.c0 = fast_log(v.alpha_sum + (float)st.i0);
-            e.c1 = fast_log(v.prior[x] + (float)c);
-            v.S[(size_t)x * v.cap + k] = e.c1;
+            en.c0 = fast_log(v.alpha_sum + (float)st.i0);
+            en.c1 = fast_log(prior_x + (float)c);
+            v.S[(size_t)x * v.cap + k] = en.c1;
         } else {
-            e = scorer_init(KIND, v.p, st);
+            en = scorer_init(KIND, v.p, st);
         }
         const float shifted = n ? py_nonempty_score(n, A.d) : empty_score;
         const float base = shifted + shift;
-        const float s = accumulate(KIND, base, e, x, lf, v.p);
-        sc[k] = s;
+        const float s = accumulate(KIND, base, en, x, lf, v.p);
+        sc[e] = s;
         if (s > m1) { m2 = m1; m1 = s; i1 = k; }
         else if (s > m2) m2 = s;
         // the score a row of this value sees in its own slot k once it is
@@ -2835,23 +2904,21 @@ __global__ __launch_bounds__(kBlock) void k_vs_tables(TablesParams A,
         else if (KIND == DIST_GP || KIND == DIST_BNB)
             has = (uint32_t)st.i0 >= 1u && (uint32_t)st.i1 >= x;
         else has = (x ? st.i0 : st.i1) >= 1;
-        float so = INFINITY;
         if (n == 1) {
-            so = -INFINITY;
+            so[e] = -INFINITY;
         } else if (n >= 2 && has) {
             Entry er = {0.f, 0.f, 0.f, 0.f};
             if (is_cat(KIND)) {
                 er.c0 = fast_log(v.alpha_sum + (float)(st.i0 - 1));
-                er.c1 = fast_log(v.prior[x] + (float)(c - 1));
+                er.c1 = fast_log(prior_x + (float)(c - 1));
             } else {
                 Stats s2 = st;
                 stats_remove(KIND, s2, x);
                 er = scorer_init(KIND, v.p, s2);
             }
-            so = accumulate(KIND, py_nonempty_score(n - 1, A.d) + shift, er,
-                            x, lf, v.p);
+            so[e] = accumulate(KIND, py_nonempty_score(n - 1, A.d) + shift,
+                               er, x, lf, v.p);
         }
-        own[k] = so;
         if (owner) {
             A.counts_out[k] = n;
             A.snap_out[k] = n;
@@ -2861,11 +2928,14 @@ __global__ __launch_bounds__(kBlock) void k_vs_tables(TablesParams A,
             A.shifted[k] = shifted;
             A.base[k] = base;
             A.base_single[k] = (n == 0 ? empty_single : shifted) + shift;
-            v.c0[k] = e.c0;
-            if (!is_cat(KIND)) { v.c1[k] = e.c1; v.c2[k] = e.c2; v.c3[k] = e.c3; }
+            v.c0[k] = en.c0;
+            if (!is_cat(KIND)) {
+                v.c1[k] = en.c1; v.c2[k] = en.c2; v.c3[k] = en.c3;
+            }
         }
     }
-    // (max, first arg-max, max of the rest) over the workgroup
+    // (max, first arg-max, max of the rest) over the workgroup: within the
+    // wave by shuffles, the waves' results folded by every thread for itself
     auto fold = [](float & a1, float & a2, int & ai, float b1, float b2,
                    int bi) {
         if (a1 > b1 || (a1 == b1 && ai < bi)) {
@@ -2884,36 +2954,57 @@ __global__ __launch_bounds__(kBlock) void k_vs_tables(TablesParams A,
     }
     if (lane == 0) { r_m1[wave] = m1; r_m2[wave] = m2; r_i1[wave] = i1; }
     __syncthreads();
-    if (tid == 0) {
-        for (int w = 1; w < kBlock / 64; ++w)
-            fold(m1, m2, i1, r_m1[w], r_m2[w], r_i1[w]);
-        const float M = m1;
-        const int g = i1;
-        const float so = own[g];
-        // (the arg-max group's rows: own score against the rest's maximum)
-        const float mB = (so != INFINITY && so != -INFINITY) ? fmaxf(so, m2) : M;
-        T.M[x] = M; T.mB[x] = mB; T.argmax[x] = g;
-        sh_M = M; sh_mB = mB; sh_amax = g;
-        sh_lo = 0xFFFFFFFFu; sh_hi = 0u; sh_n = 0u;
+    m1 = r_m1[0]; m2 = r_m2[0]; i1 = r_i1[0];
+#pragma unroll
+    for (int w = 1; w < kWaves; ++w) fold(m1, m2, i1, r_m1[w], r_m2[w], r_i1[w]);
+    const float M = m1;
+    const int amax = i1;
+    // (the arg-max group's rows: own score against the rest's maximum)
+    if (tid == (amax & (kTablesBlock - 1))) {
+        float own_g = INFINITY;
+#pragma unroll
+        for (int e = 0; e < kTablesPer; ++e)
+            if (e == amax / kTablesBlock) own_g = so[e];
+        sh_so = own_g;
     }
     __syncthreads();
-    const float M = sh_M, mB = sh_mB;
-    const int amax = sh_amax;
+    const float so_g = sh_so;
+    const float mB = (so_g != INFINITY && so_g != -INFINITY) ? fmaxf(so_g, m2)
+                                                             : M;
+    if (tid == 0) { T.M[x] = M; T.mB[x] = mB; T.argmax[x] = amax; }
     const float ea = u2f(g_tables_dev.exp_ab[0]);
     const float eb = u2f(g_tables_dev.exp_ab[1]);
     float * la = T.LA + (size_t)x * Kpad;
     float * lb = T.LB + (size_t)x * Kpad;
-    for (int k = tid; k < Kpad; k += kBlock) {
-        float a = 0.f, b = 0.f;
+    float * lds_a = tb_lds;
+    float * lds_b = tb_lds + Kpad;
+    const bool chains = T.PA != nullptr;
+    // (the tiles read whole chunks of kVsUnroll entries up to the group count:
+    // that far the vectors are written, zeros behind the last group)
+    const int Kw = min(Kpad, (K1 + kVsUnroll - 1) / kVsUnroll * kVsUnroll);
+#pragma unroll
+    for (int e = 0; e < kTablesPer; ++e) {
+        const int k = tid + e * kTablesBlock;
+        if (k >= Kw) continue;
+        float a = 0.f, b = 0.f, o = -1.f;
         if (k < K1) {
-            const float s = sc[k];
-            a = fast_exp_nonpos(s - M, g_tables_dev.exp_table, ea, eb);
-            b = fast_exp_nonpos(s - mB, g_tables_dev.exp_table, ea, eb);
+            a = fast_exp_nonpos(sc[e] - M, g_tables_dev.exp_table, ea, eb);
+            b = fast_exp_nonpos(sc[e] - mB, g_tables_dev.exp_table, ea, eb);
+            // the row's own-slot likelihood (k_vs_sample's set-up): -1 = the
+            // row is handed over (alone in its group, or its own score above
+            // the value's maximum through table rounding)
+            const float s_own = so[e];
+            if (s_own != INFINITY && s_own != -INFINITY) {
+                const bool class_b = k == amax;
+                if (class_b || !(s_own > M))
+                    o = fast_exp_nonpos(s_own - (class_b ? mB : M),
+                                        g_tables_dev.exp_table, ea, eb);
+            }
         }
         la[k] = a;
         lb[k] = b;
-        sc[k] = a;      // (the running sums below read the copies in LDS)
-        lbuf[k] = b;
+        if (T.own) T.own[(size_t)x * Kpad + k] = o;
+        if (chains) { lds_a[k] = a; lds_b[k] = b; }
     }
     // ---- workgroup 0: the id maps (mixture.hpp:474-497), the scalars, the
     // new state
@@ -2921,10 +3012,10 @@ __global__ __launch_bounds__(kBlock) void k_vs_tables(TablesParams A,
         if (removed > 0) {
             // the ids of the vanished groups retire before any slot is
             // overwritten
-            for (int k = tid; k < K0; k += kBlock)
+            for (int k = tid; k < K0; k += kTablesBlock)
                 if (emptied_at(k)) A.g2p[A.p2g[k]] = -1;
             __syncthreads();
-            for (int k = tid; k < size; k += kBlock) {
+            for (int k = tid; k < size; k += kTablesBlock) {
                 const int t = src_of[k];
                 if (t != k) {
                     const uint32_t gid = A.p2g[t];
@@ -2934,7 +3025,7 @@ __global__ __launch_bounds__(kBlock) void k_vs_tables(TablesParams A,
             }
             __syncthreads();
         }
-        for (int k = k_new + tid; k < K1; k += kBlock) {
+        for (int k = k_new + tid; k < K1; k += kTablesBlock) {
             const uint32_t gid = global_size0 + (uint32_t)(k - k_new);
             A.p2g[k] = gid;
             A.g2p[gid] = k;
@@ -2948,95 +3039,78 @@ __global__ __launch_bounds__(kBlock) void k_vs_tables(TablesParams A,
             st.global_size = global_size0 + (uint32_t)n_created;
             st.first_new_global = global_size0;
             st.nonempty = nonempty;
-            st.pad = A.dev_in->pad + (removed > 0 ? 1 : 0);
+            st.pad = (int)(epoch0 + (removed > 0 ? 1u : 0u));
             *A.dev_out = st;
             A.scalars->shift = shift;
             A.scalars->shift_full = py_shift(A.sample_size, A.alpha);
             A.scalars->empty_single = empty_single;
         }
     }
-    // ---- the running sums and the arg-max group's band (see k_vs_prepare)
-    if (T.PA == nullptr && T.band_mode == nullptr) return;
-    __syncthreads();   // the copies in LDS are complete
-    const bool chains = T.PA != nullptr;
-    // (a batch that moved groups: the walk below would read the id map while
-    // workgroup 0 rewrites it -- no bands, every tile runs both passes)
-    const bool bands_ok = removed == 0;
-    bool walk = false;
-    if (chains && wave < 2) {
-        if (lane == 0) {
-            const float4 * src =
-                reinterpret_cast<const float4 *>(wave ? lbuf : sc);
-            const int nchunks = Kpad / kVsUnroll;
-            float * dst = (wave ? T.PB : T.PA) + (size_t)x * nchunks;
-            constexpr int Q = kVsUnroll / 4;
-            float4 even[Q], odd[Q];   // ping-pong: no register copies
-#pragma unroll
-            for (int q = 0; q < Q; ++q) even[q] = src[q];
-            float run = 0.f;
-            auto add_chunk = [&run](const float4 (&w)[Q]) {
-#pragma unroll
-                for (int q = 0; q < Q; ++q) {
-                    run += w[q].x;
-                    run += w[q].y;
-                    run += w[q].z;
-                    run += w[q].w;
-                }
-            };
-            for (int c = 0; c < nchunks; c += 2) {
-                const int c1 = c + 1 < nchunks ? c + 1 : c;
-#pragma unroll
-                for (int q = 0; q < Q; ++q) odd[q] = src[c1 * Q + q];
-                __builtin_amdgcn_sched_barrier(0);   // loads first
-                dst[c] = run;
-                add_chunk(even);
-                __builtin_amdgcn_sched_barrier(0);
-                if (c + 1 >= nchunks) break;
-                const int c2 = c + 2 < nchunks ? c + 2 : c;
-#pragma unroll
-                for (int q = 0; q < Q; ++q) even[q] = src[c2 * Q + q];
-                __builtin_amdgcn_sched_barrier(0);
-                dst[c + 1] = run;
-                add_chunk(odd);
-                __builtin_amdgcn_sched_barrier(0);
+    // ---- the arg-max group's band of rows (VsTables::band_tile), from the
+    // offsets the chunk's last sort left: valid while no group was
+    // swap-removed since (the packed indices mean what they meant)
+    if (T.band_mode && tid == 0) {
+        const uint32_t c0 = T.chunk_first[x], c1 = T.chunk_first[x + 1];
+        const uint32_t rows = T.val_start[x + 1] - T.val_start[x];
+        int mode = rows == 0 ? 1 : 0;
+        VsTile band = VsTile{x, 0u, 0u, 0u};
+        if (rows != 0 && c1 - c0 == 1 && removed == 0 && A.offsets.off
+            && A.offsets.epoch[c0] == epoch0 && epoch0 != 0u) {
+            const int * off = A.offsets.off + (size_t)c0 * A.offsets.stride;
+            const int k_then = off[A.offsets.stride - 1];
+            uint32_t lo = 0u, hi = 0u;   // (a group younger than the sort)
+            if (amax < k_then) {
+                lo = (uint32_t)off[amax];
+                hi = (uint32_t)off[amax + 1];
+            }
+            if (hi - lo <= 64u * kVsR) {
+                mode = 1;
+                band = VsTile{x, T.val_start[x] + lo, hi - lo, c0};
             }
         }
-    } else if (T.band_mode && bands_ok) {
-        const uint32_t begin = T.val_start[x];
-        walk = T.val_start[x + 1] - begin <= kVsBandWalkRows;
-        const uint32_t end = walk ? T.val_start[x + 1] : begin;
-        const uint32_t first = chains ? 128u : 0u;   // walking threads
-        const uint32_t step = kBlock - first;
-        constexpr int U = 4;
-        for (uint32_t base = begin + (threadIdx.x - first); base < end;
-             base += U * step) {
-            uint32_t gid[U], slot[U];
-#pragma unroll
-            for (int q = 0; q < U; ++q) {
-                const uint32_t i = base + q * step;
-                gid[q] = i < end ? A.assign_pos[i] : 0u;
-            }
-#pragma unroll
-            for (int q = 0; q < U; ++q) slot[q] = (uint32_t)A.g2p[gid[q]];
-#pragma unroll
-            for (int q = 0; q < U; ++q) {
-                const uint32_t i = base + q * step;
-                if (i < end && slot[q] == (uint32_t)amax) {
-                    atomicMin(&sh_lo, i);
-                    atomicMax(&sh_hi, i);
-                    atomicAdd(&sh_n, 1u);
-                }
-            }
-        }
+        T.band_mode[x] = mode;
+        T.band_tile[x] = band;
     }
-    if (T.band_mode == nullptr) return;
+    // ---- the running sums at the chunk boundaries (see k_vs_prepare): two
+    // lanes walk the copies in LDS
+    if (!chains) return;
     __syncthreads();
-    if (threadIdx.x == kBlock - 1) {   // (a walking thread: it knows `walk`)
-        const uint32_t n = sh_n;
-        const bool band = n > 0 && sh_hi - sh_lo + 1u == n
-                          && n <= 64u * kVsR;
-        T.band_mode[x] = (walk && (band || n == 0)) ? 1 : 0;
-        T.band_tile[x] = VsTile{x, band ? sh_lo : 0u, band ? n : 0u, 0u};
+    if (wave < 2 && lane == 0) {
+        const float4 * src =
+            reinterpret_cast<const float4 *>(wave ? lds_b : lds_a);
+        const int nchunks = Kw / kVsUnroll;
+        float * dst = (wave ? T.PB : T.PA) + (size_t)x * (Kpad / kVsUnroll);
+        constexpr int Q = kVsUnroll / 4;
+        float4 even[Q], odd[Q];   // ping-pong: no register copies
+#pragma unroll
+        for (int q = 0; q < Q; ++q) even[q] = src[q];
+        float run = 0.f;
+        auto add_chunk = [&run](const float4 (&w)[Q]) {
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                run += w[q].x;
+                run += w[q].y;
+                run += w[q].z;
+                run += w[q].w;
+            }
+        };
+        for (int c = 0; c < nchunks; c += 2) {
+            const int c1 = c + 1 < nchunks ? c + 1 : c;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) odd[q] = src[c1 * Q + q];
+            __builtin_amdgcn_sched_barrier(0);   // loads first
+            dst[c] = run;
+            add_chunk(even);
+            __builtin_amdgcn_sched_barrier(0);
+            if (c + 1 >= nchunks) break;
+            const int c2 = c + 2 < nchunks ? c + 2 : c;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) even[q] = src[c2 * Q + q];
+            __builtin_amdgcn_sched_barrier(0);
+            dst[c + 1] = run;
+            add_chunk(odd);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 }
 
@@ -3286,14 +3360,20 @@ void k_vs_sample(
             if (classB ? skip_b : skip_a) valid[r] = false;
         }
         if (valid[r]) {
-            const int n_g = P.counts[g[r]];
-            const float m = classB ? mB : M;
-            float s_own = 0.f;
-            bool defer = (n_g == 1);
-            if (!defer) {
-                s_own = vs_own_score(P, v, g[r], n_g, x, lf, shift);
-                defer = !classB && s_own > M;   // table rounding lifted it
+            float s_own = 0.f, l_tab = 0.f;
+            bool defer;
+            if (T.own) {   // (k_vs_tables did this per (value, group))
+                l_tab = T.own[(size_t)x * T.Kpad + g[r]];
+                defer = l_tab < 0.f;
+            } else {
+                const int n_g = P.counts[g[r]];
+                defer = (n_g == 1);
+                if (!defer) {
+                    s_own = vs_own_score(P, v, g[r], n_g, x, lf, shift);
+                    defer = !classB && s_own > M;   // table rounding lifted it
+                }
             }
+            const float m = classB ? mB : M;
             if (defer) {
                 const uint32_t at = pos + kVsR * lane + r;
                 // (a band tile's rows may straddle two chunks of its value)
@@ -3305,8 +3385,10 @@ void k_vs_sample(
                 vs_hand_over(D, chunk, at);
                 valid[r] = false;
             } else {
-                l_own[r] = fast_exp_nonpos(s_own - m, g_tables_dev.exp_table,
-                                           ea, eb);
+                l_own[r] = T.own ? l_tab
+                                 : fast_exp_nonpos(s_own - m,
+                                                   g_tables_dev.exp_table, ea,
+                                                   eb);
                 u[r] = batch_row_unif01(P, row[r]);
             }
         }
@@ -3716,7 +3798,7 @@ __global__ __launch_bounds__(64) void k_vs_narrow(
     if (T.stamps) st0 = __builtin_amdgcn_s_memtime();
 #endif
     const int Kpad = T.Kpad;
-    const int quads = Kpad / 4;
+    const int quads = T.Kuse / 4;
     const int stride = quads + 2 * kVsUnroll / 4;   // float4s per vector
     // the vector of the rows outside the arg-max group: on its way before
     // the rows' own gathers start
@@ -3750,19 +3832,27 @@ __global__ __launch_bounds__(64) void k_vs_narrow(
         const size_t row = P.row_begin + sorted_rows[at];
         g = P.g2p[P.assign_pos[at]];
         is_b = (g == amax);
-        const int n_g = P.counts[g];
         const float m = is_b ? mB : M;
-        float s_own = 0.f;
-        bool defer = (n_g == 1);
-        if (!defer) {
-            s_own = vs_own_score(P, v, g, n_g, x, lf, shift);
-            defer = !is_b && s_own > M;   // table rounding lifted it
+        float s_own = 0.f, l_tab = 0.f;
+        bool defer;
+        if (T.own) {   // (k_vs_tables did this per (value, group))
+            l_tab = T.own[(size_t)x * Kpad + g];
+            defer = l_tab < 0.f;
+        } else {
+            const int n_g = P.counts[g];
+            defer = (n_g == 1);
+            if (!defer) {
+                s_own = vs_own_score(P, v, g, n_g, x, lf, shift);
+                defer = !is_b && s_own > M;   // table rounding lifted it
+            }
         }
         if (defer) {
             vs_hand_over(D, tiles[id].chunk, at);
             valid = false;
         } else {
-            l_own = fast_exp_nonpos(s_own - m, g_tables_dev.exp_table, ea, eb);
+            l_own = T.own ? l_tab
+                          : fast_exp_nonpos(s_own - m, g_tables_dev.exp_table,
+                                            ea, eb);
             u = batch_row_unif01(P, row);
         }
     }
@@ -4152,7 +4242,7 @@ __global__ __launch_bounds__(kVsApplyBlock) void k_vs_apply(
         uint32_t * __restrict__ sorted_rows,
         const uint32_t * __restrict__ p2g, uint32_t * __restrict__ assign_pos,
         uint32_t nvals, int refresh_cells, int sole_owner,
-        int32_t * __restrict__ stage, VsDefer D) {
+        int32_t * __restrict__ stage, VsDefer D, VsOffsets O) {
     extern __shared__ int vs_lds[];
     const int K = sweep_K(P);
     int * delta = vs_lds;                 // [K]
@@ -4166,6 +4256,12 @@ __global__ __launch_bounds__(kVsApplyBlock) void k_vs_apply(
     const uint32_t pos = chunks[blockIdx.x].pos;
     const uint32_t n = chunks[blockIdx.x].n;
     if (x == 0xFFFFFFFEu) return;   // several values: k_vs_apply_mixed's
+    // (the offsets of the groups' rows after the sort, for k_vs_tables: the
+    // sorting form of a device-normalised run stamps them, anything else
+    // that changes the rows' groups leaves the stamp at 0)
+    if (O.epoch && threadIdx.x == 0)
+        O.epoch[blockIdx.x] =
+            (SORT && O.off && P.dev) ? (uint32_t)P.dev->pad : 0u;
     // The rows of this chunk that the tiles handed over (VsDefer: alone in
     // their group, own score above the value's maximum) -- or the whole chunk
     // when its values lie beyond the tables -- are sampled here, a wave per
@@ -4284,10 +4380,19 @@ __global__ __launch_bounds__(kVsApplyBlock) void k_vs_apply(
     __syncthreads();
     int run = incl - sum;
     for (int w = 0; w < wave; ++w) run += part[w];
+    int * off = (O.off && P.dev)
+                    ? O.off + (size_t)blockIdx.x * O.stride : nullptr;
     for (int k = lo; k < hi; ++k) {
         const int c = hist[k];
         hist[k] = run;
+        if (off) off[k] = run;
         run += c;
+    }
+    // (off[K] = the end; groups that do not exist yet have no rows: the
+    // reader is told how many there were, in the row's last word)
+    if (off && threadIdx.x == 0) {
+        off[K] = (int)n;
+        off[O.stride - 1] = K;
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < n; i += kVsApplyBlock) {
@@ -4378,9 +4483,10 @@ __global__ __launch_bounds__(kVsReduceGroups * kVsReduceSlices)
 void k_vs_reduce(StatImage img, const int32_t * __restrict__ stage,
                  const VsTile * __restrict__ chunks, uint32_t n_chunks, int K,
                  uint32_t nvals, unsigned long long * host_pairs,
-                 unsigned int seq, const DevState * dev) {
+                 unsigned int seq, const DevState * dev, int k_limit) {
     // (the rows of the staging matrix are the host's bound apart: their
-    // addresses do not wait for the group count of record)
+    // addresses do not wait for the group count of record; k_limit: what
+    // that count can be at most at this batch)
     const int stride = K;
     if (dev) K = dev->K;   // (see SweepParams::dev)
     __shared__ int s_a[kVsReduceSlices][kVsReduceGroups];
@@ -4389,7 +4495,7 @@ void k_vs_reduce(StatImage img, const int32_t * __restrict__ stage,
     const int slice = threadIdx.x / kVsReduceGroups;
     const int k = blockIdx.x * kVsReduceGroups + kk;
     int a = 0, b = 0;   // a: plain sum; b: BB heads part / GP value-weighted
-    if (k < stride) {   // (slots past the group count hold zeros or nothing)
+    if (k < k_limit) {   // (slots past the group count: nothing is used)
         for (uint32_t c = slice; c < n_chunks; c += kVsReduceSlices) {
             const int d = stage[(size_t)c * stride + k];
             const uint32_t x = chunks[c].x;

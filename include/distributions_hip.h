@@ -451,9 +451,17 @@ int dist_gibbs_sharded_device_normalise_ok(const dist_gibbs_t * g,
  * is queued on the stream of the thread that swept; a call from another
  * thread drains that stream before it reads the state.  0: never.
  * "sharded_device_normalise" = 1 (default) lets dist_gibbs_sweep_sharded do
- * the same: the ranks agree among themselves (one all-reduce of a flag when a
- * run is opened) whether every one of them can; 0 keeps this rank, and so
- * all of them, on the host-normalised loop;
+ * the same: the ranks agree among themselves, on EVERY call (one all-reduce
+ * of a flag), whether their open runs go on -- a rank whose run was settled
+ * in between by any other call makes all of them open a new one -- and, when
+ * a run is opened, whether every one of them can; 0 keeps this rank, and so
+ * all of them, on the host-normalised loop.  Calls between two passes need
+ * not be the same on every rank;
+ * "fused_tables" = 1 (default): a device-normalised run of the value-sorted
+ * path spends ONE launch between a batch's statistics and the next batch's
+ * sampling (k_vs_tables: group set, caches and per-value tables), and the
+ * rows a tile hands over are sampled by k_vs_apply; 0: k_normalise,
+ * k_batch_finish, k_vs_prepare and k_rows_wave as launches of their own;
  * "rows_scratch" (general rows: any feature list the value-sorted kernels do
  * not take) = 3 (default: k_rows_scratch's loops, every pass scores again),
  * 1 (the likelihoods of the total's pass stay in an HBM scratch column for

@@ -55,15 +55,30 @@ def test_small_single_gpu_run_prints_one_json_line():
     assert out["batch_variants"][0]["batch_rows"] == 50000
     roof = out["roofline"]
     assert roof["bound"] in ("valu", "hbm") and roof["avg_launch_ms"] > 0
-    if roof["frac"] is not None:
-        assert 0.0 < roof["frac"] <= 1.0
-    # the general-row configurations, exact and with scan sampling
+    for key in ("frac", "frac_weighted", "hbm_frac", "valu_frac"):
+        if roof.get(key) is not None:
+            assert 0.0 < roof[key] <= 1.0, (key, roof[key])
+    assert roof["kernel"].startswith(("k_vs_sample", "k_vs_narrow"))
+    # what the line says about the run is the timed engine's own account
+    assert "normalised on the device" in out["config"]["group_set"]
+    assert out["config"]["launches_per_sub_sweep"].startswith("4:")
+    # the other BASELINE configurations, exact and with scan sampling
     got = [(o["config"], o["sampling"].split()[0]) for o in out["other_configs"]]
     assert got == [("gp_nich", "exact"), ("gp_nich", "scan"),
                    ("gp_nich", "scan"), ("mixed", "exact"), ("mixed", "scan"),
-                   ("mixed", "scan")]
-    assert all(o["value"] > 0 and o["kernel"] == "k_rows_scratch"
-               for o in out["other_configs"])
+                   ("mixed", "scan"), ("dpd", "exact"), ("dpd", "scan")]
+    for o in out["other_configs"]:
+        assert o["value"] > 0
+        scan = o["sampling"].startswith("scan")
+        assert ("scan" in o["kernel"]) == scan, o   # a scan run names its kernel
+        if o["config"] != "dpd":
+            assert o["kernel"].startswith("k_rows_scratch")
+        else:
+            assert o["groups"] == 8192
+    cfg = out["config"]
+    assert cfg["c3_value"] == out["other_configs"][0]["value"]
+    assert cfg["c5_value"] == out["other_configs"][6]["value"]
+    assert cfg["b65536_value"] is None     # (this run's variant is 50 000)
     assert out["cpu_baseline"]["reference_kernels"] is None or (
         out["cpu_baseline"]["reference_kernels"]["K=1024"]
         ["vector_exp_elements_per_us"] > 0)

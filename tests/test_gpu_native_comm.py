@@ -24,7 +24,7 @@ pytestmark = pytest.mark.gpu
 K, BATCH, SWEEPS, SEED = 24, 1500, 2, 4242
 
 
-def worker(rank, port, out, config, mode, N):
+def worker(rank, port, out, config, mode, N, peek=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -49,6 +49,11 @@ def worker(rank, port, out, config, mode, N):
     native = sharded.use_native_comm()
     for s in range(SWEEPS):
         sharded.sweep(BATCH, _core.rng_seed(SEED), draw_base=s * N)
+        if peek:
+            # a look at the state between two passes settles the open run:
+            # the next pass must find that out by asking (all ranks do, on
+            # every call) and open a new one
+            assert len(gpu) >= K
     torch.cuda.synchronize()
     np.save(os.path.join(out, "native.npy"), np.array([int(native)]))
     np.save(os.path.join(out, "on_device.npy"),
@@ -69,13 +74,13 @@ def free_port():
     return port
 
 
-@pytest.mark.parametrize("config,mode,N", [
-    ("dd", 2, 9001), ("dd", 0, 9001), ("bb", 1, 9001),
-    ("dd_bb_gp", 1, 6000)])
-def test_native_loop_equals_oracle(tmp_path, config, mode, N):
+@pytest.mark.parametrize("config,mode,N,peek", [
+    ("dd", 2, 9001, False), ("dd", 2, 9001, True), ("dd", 0, 9001, False),
+    ("bb", 1, 9001, False), ("dd_bb_gp", 1, 6000, False)])
+def test_native_loop_equals_oracle(tmp_path, config, mode, N, peek):
     import oracle_lib as ol
     import workloads
-    mp.spawn(worker, args=(free_port(), str(tmp_path), config, mode, N),
+    mp.spawn(worker, args=(free_port(), str(tmp_path), config, mode, N, peek),
              nprocs=1, join=True)
     osh, gsh, vals, assign = workloads.make(config, N, K)
     native = bool(np.load(tmp_path / "native.npy")[0])
