@@ -4204,6 +4204,64 @@ int dist_group_score_value(const dist_shared_t * sh, const uint32_t * group,
     });
 }
 
+size_t dist_scorer_words(const dist_shared_t * sh) {
+    return is_cat(sh->kind) ? (size_t)sh->dim + 1 : 4;
+}
+int dist_scorer_init(const dist_shared_t * sh, const uint32_t * group,
+                     float * state) {
+    return guarded([&] {
+        ensure_host_tables();
+        check_shared(*sh);
+        if (sh->kind == DIST_DD) {   // dd.hpp:226-236
+            float alpha_sum = 0.f;
+            for (int v = 0; v < sh->dim; ++v) {
+                const float alpha = sh->alphas[v] + (float)(int32_t)group[1 + v];
+                state[1 + v] = alpha;
+                alpha_sum += alpha;
+            }
+            state[0] = alpha_sum;
+            return;
+        }
+        if (sh->kind == DIST_DPD) {  // dpd.hpp:312-333
+            const float alpha = sh->p[0];
+            const float total = (float)(size_t)(int32_t)group[0];
+            const float beta_scale = alpha / (alpha + total);
+            state[0] = fast_log(beta_scale * sh->p[1]);
+            const float counts_scale = 1.0f / (alpha + total);
+            for (int v = 0; v < sh->dim; ++v) {
+                float score = sh->betas[v] * beta_scale;
+                const int32_t count = (int32_t)group[1 + v];
+                // (the reference adds the counts it HAS: absent ones add nothing)
+                if (count) score += counts_scale * (float)count;
+                state[1 + v] = fast_log(score);
+            }
+            return;
+        }
+        const Entry e = scorer_init(sh->kind, sh->p, group_to_stats(*sh, group));
+        state[0] = e.c0; state[1] = e.c1; state[2] = e.c2; state[3] = e.c3;
+    });
+}
+int dist_scorer_eval(const dist_shared_t * sh, const float * state,
+                     uint32_t value, float * out) {
+    return guarded([&] {
+        ensure_host_tables();
+        if (sh->kind == DIST_DD) {   // dd.hpp:238-244
+            DIST_REQUIRE(value < (uint32_t)sh->dim, "value out of bounds");
+            *out = fast_log(state[1 + value] / state[0]);
+            return;
+        }
+        if (sh->kind == DIST_DPD) {  // dpd.hpp:335-340
+            DIST_REQUIRE(value == DIST_DPD_OTHER || value < (uint32_t)sh->dim,
+                         "value out of bounds");
+            *out = value == DIST_DPD_OTHER ? state[0] : state[1 + value];
+            return;
+        }
+        const Entry e = {state[0], state[1], state[2], state[3]};
+        const float lf = sh->kind == DIST_GP ? fast_log_factorial(value) : 0.f;
+        *out = score_group(sh->kind, e, value, lf, sh->p);
+    });
+}
+
 int dist_group_score_data(const dist_shared_t * sh, const uint32_t * group,
                           float * out) {
     return guarded([&] {

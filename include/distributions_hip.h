@@ -229,6 +229,20 @@ int dist_group_score_value(const dist_shared_t * shared,
                            float * out);
 int dist_group_score_data(const dist_shared_t * shared, const uint32_t * group,
                           float * out);
+/* Model::Scorer (dd.hpp:222-245, bb.hpp:185-205, gp.hpp:198-217,
+ * nich.hpp:239-259, bnb.hpp:195-223, dpd.hpp:309-341): init caches what eval
+ * needs of ONE group's statistics, eval scores a value from the cache -- the
+ * per-group ("naive") counterpart of the Mixture's vectorised score_value,
+ * the other half of benchmarks/mixture.cc:41-74,119-135.  Host side, O(dim)
+ * / O(1); the state is dist_scorer_words(shared) floats owned by the caller:
+ * alpha_sum and alphas[dim] for DirichletDiscrete, the logarithm for OTHER
+ * and for each of the dim values for DirichletProcessDiscrete, the scalar
+ * members of the reference's Scorer otherwise. */
+size_t dist_scorer_words(const dist_shared_t * shared);
+int dist_scorer_init(const dist_shared_t * shared, const uint32_t * group,
+                     float * state);
+int dist_scorer_eval(const dist_shared_t * shared, const float * state,
+                     uint32_t value, float * out);
 
 /* ---- protobuf wire format of Shared / Group -------------------------------
  * The messages of distributions/io/schema.proto (package

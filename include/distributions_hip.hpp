@@ -179,6 +179,27 @@ struct Model {
                 }
                 return (V)(shared.dim - 1);
             }
+            case DIST_DPD: {   // dpd.hpp:275-305 (values 0 .. dim-1, then OTHER)
+                std::vector<float> ps;
+                for (int v = 0; v < shared.dim; ++v)
+                    ps.push_back(shared.betas[v] * shared.p[0]
+                                 + (float)(int)words[1 + v]);
+                if (shared.p[1] > 0) ps.push_back(shared.p[1] * shared.p[0]);
+                float total = 0.f;
+                for (float & q : ps) {
+                    q = q > 0 ? gamma_(rng, q) : 0.f;       // random.cc:121-137
+                    total += q;
+                }
+                const float scale = 1.f / total;
+                float t = dist_rng_unif01(&rng.state);      // random.hpp:300-313
+                size_t index = ps.size() - 1;
+                for (size_t i = 0; i + 1 < ps.size(); ++i) {
+                    t -= ps[i] * scale;
+                    if (t < 0) { index = i; break; }
+                }
+                return index < (size_t)shared.dim ? (V)index
+                                                  : (V)DIST_DPD_OTHER;
+            }
             case DIST_BB: {
                 const float x = gamma_(rng, shared.p[0] + (float)(int)words[0]);
                 const float y = gamma_(rng, shared.p[1] + (float)(int)words[1]);
@@ -229,10 +250,29 @@ struct Model {
       public:
     };
 
+    // Model::Scorer (dd.hpp:222-245, bb.hpp:185-205, gp.hpp:198-217,
+    // nich.hpp:239-259, bnb.hpp:195-223, dpd.hpp:309-341): one group's
+    // scorer, the per-group counterpart of Mixture::score_value -- what
+    // benchmarks/mixture.cc:41-74 keeps beside the mixture and times
+    // against it.  Host arithmetic (dist_scorer_init / dist_scorer_eval).
+    struct Scorer {
+        std::vector<float> state;
+        void init(const Shared & shared, const Group & group, rng_t &) {
+            state.assign(dist_scorer_words(&shared), 0.f);
+            check(dist_scorer_init(&shared, group.words.data(), state.data()));
+        }
+        float eval(const Shared & shared, const Value & value, rng_t &) const {
+            float out = 0;
+            check(dist_scorer_eval(&shared, state.data(), detail::word(value),
+                                   &out));
+            return out;
+        }
+    };
+
     // MixtureSlave<Model, ...> (mixture.hpp:340-450)
     class Mixture {
       public:
-        Mixture() : ptr_(nullptr) {}
+        Mixture() : ptr_(nullptr), handed_over_(false) {}
         ~Mixture() { if (ptr_) dist_mixture_destroy(ptr_); }
         Mixture(const Mixture &) = delete;
         Mixture & operator=(const Mixture &) = delete;
@@ -240,9 +280,12 @@ struct Model {
         // groups().resize(n) / groups()[i] / groups().push_back(group)
         // BEFORE init(), as the reference's callers fill a mixture
         // (benchmarks/mixture.cc:84-100): host-side groups that init() hands
-        // to the device.  Afterwards the statistics live in HBM and
-        // groups(shared, i) returns a copy.
-        std::vector<Group> & groups() { return staged_; }
+        // to the device.  They stay readable afterwards -- the snapshot init()
+        // took, as benchmarks/mixture.cc:55-66 copies them out of a `const
+        // Mixture &` -- while the LIVE statistics are in HBM:
+        // groups(shared, i) returns a copy of those.  Taking the mutable
+        // reference again tells init() to hand the groups over anew.
+        std::vector<Group> & groups() { handed_over_ = false; return staged_; }
         const std::vector<Group> & groups() const { return staged_; }
         void append(const Shared & shared, const Group & group) {
             check(dist_mixture_append(handle(shared), group.words.data()));
@@ -255,10 +298,10 @@ struct Model {
             return g;
         }
         void init(const Shared & shared, rng_t &) {
-            if (!staged_.empty()) {
+            if (!staged_.empty() && !handed_over_) {
                 check(dist_mixture_clear(handle(shared)));
                 for (const Group & group : staged_) append(shared, group);
-                staged_.clear();
+                handed_over_ = true;
             }
             check(dist_mixture_init(handle(shared)));
         }
@@ -323,6 +366,7 @@ struct Model {
         }
         dist_mixture_t * ptr_;
         std::vector<Group> staged_;
+        bool handed_over_;
     };
 };
 
@@ -345,7 +389,40 @@ struct DirichletDiscrete : Model<DIST_DD, int> {
 typedef Model<DIST_BB, bool> BetaBernoulli;              // models/bb.hpp
 typedef Model<DIST_GP, uint32_t> GammaPoisson;           // models/gp.hpp
 typedef Model<DIST_NICH, float> NormalInverseChiSq;      // models/nich.hpp
-typedef Model<DIST_DPD, uint32_t> DirichletProcessDiscrete;  // models/dpd.hpp
+// models/dpd.hpp: the Shared owns its betas (values 0 .. dim-1 of the dense
+// remap; dist_shared_t carries a pointer to them)
+struct DirichletProcessDiscrete : Model<DIST_DPD, uint32_t> {
+    typedef Model<DIST_DPD, uint32_t> Base;
+    struct Shared : Base::Shared {
+        std::vector<float> storage;
+        Shared() {}
+        Shared(const Shared & other) : Base::Shared(other), storage(other.storage) {
+            repoint();
+        }
+        Shared & operator=(const Shared & other) {
+            static_cast<Base::Shared &>(*this) = other;
+            storage = other.storage;
+            repoint();
+            return *this;
+        }
+        void set_betas(const std::vector<float> & values) {
+            storage = values;
+            this->dim = (int)storage.size();
+            repoint();
+        }
+        // dpd.hpp:141-152: alpha 0.5, beta0 0, a hundred values of 1/100
+        static Shared EXAMPLE() {
+            Shared shared;
+            shared.p[0] = 0.5f;
+            shared.p[1] = 0.0f;
+            shared.set_betas(std::vector<float>(100, (float)(1.0 / 100)));
+            return shared;
+        }
+
+      private:
+        void repoint() { this->betas = storage.empty() ? nullptr : storage.data(); }
+    };
+};
 typedef Model<DIST_BNB, uint32_t> BetaNegativeBinomial;      // models/bnb.hpp
 
 // Clustering<int>::PitmanYor (clustering.hpp:58-234)

@@ -54,6 +54,78 @@ def test_reference_shaped_benchmark_compiles_with_the_include_path_changed():
     assert os.path.exists(BENCH_EXE)
 
 
+REF_HARNESS = os.path.join(ROOT, "oracle", "_ref", "mixture_cc_on_hip")
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/benchmarks"),
+                    reason="the reference's sources exist in the build "
+                           "container only (the binary travels)")
+def test_the_references_own_harness_compiles_against_the_shim():
+    """benchmarks/mixture.cc itself -- the C++ caller SURVEY 8b names -- with
+    only its include path changed: Model::Scorer, Mixture::groups() of a const
+    mixture, Shared::EXAMPLE() of all six models, sample_int, vector_zero,
+    current_time_us, demangle.  Compiled where it lies (oracle/Makefile)."""
+    if os.path.exists(REF_HARNESS):
+        os.remove(REF_HARNESS)
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"),
+                           "_ref/mixture_cc_on_hip"])
+    assert os.path.exists(REF_HARNESS)
+    undefined = subprocess.check_output(["nm", "-D", "--undefined-only",
+                                         REF_HARNESS], text=True)
+    assert "dist_scorer_init" in undefined and "dist_mixture_score_value" in undefined
+
+
+@pytest.mark.gpu
+def test_the_references_own_harness_runs_on_the_gpu():
+    """... and runs: six models, 1 / 10 / 100 / 1000 groups each, both of its
+    columns (per-group Scorers, the Mixture) positive"""
+    if not os.path.exists(REF_HARNESS):
+        pytest.skip("oracle/_ref/mixture_cc_on_hip was not built")
+    out = subprocess.check_output([REF_HARNESS], text=True, timeout=900)
+    rows = [x.split() for x in out.splitlines()
+            if x and x.split()[0] in ("1", "10", "100", "1000")]
+    assert len(rows) == 24, out
+    assert all(float(r[1]) > 0 and float(r[2]) > 0 for r in rows)
+    assert out.count("(cells/us)") == 6
+
+
+SCORER_EXE = os.path.join(ROOT, "examples", "scorer_check")
+
+
+def build_scorer_check():
+    subprocess.check_call(
+        ["g++", "-std=c++11", "-Wall", "-Werror",
+         "-I" + os.path.join(ROOT, "include", "compat"),
+         os.path.join(ROOT, "examples", "scorer_check.cc"),
+         "-L" + os.path.join(ROOT, "distributions_amd"),
+         "-ldistributions_hip",
+         "-Wl,-rpath," + os.path.join(ROOT, "distributions_amd"),
+         "-o", SCORER_EXE])
+
+
+def test_scorer_check_compiles():
+    build_scorer_check()
+
+
+@pytest.mark.gpu
+def test_scorer_eval_equals_score_value_group():
+    """Model::Scorer (init + eval) against the mixture's cached scorer on the
+    device, every model: the reference's own tolerance (tests/util.py:42,
+    1e-3 relative; test_models.py:537-594), bit-identical where the two are
+    the same formula (all but the categorical kinds, whose Scorer divides
+    before it takes the logarithm, dd.hpp:238-244 / dpd.hpp:312-333); and
+    Scorer.eval == Group.score_value bit for bit (dd.hpp:160-167)."""
+    build_scorer_check()
+    lines = subprocess.check_output([SCORER_EXE], text=True).splitlines()
+    got = {x.split()[0]: x.split() for x in lines}
+    assert sorted(got) == ["bb", "bnb", "dd", "dpd", "gp", "nich"]
+    for name, f in got.items():
+        pairs, same, worst = int(f[2]), int(f[4]), float(f[6])
+        assert pairs > 100 and worst < 1e-3, (name, f)
+        if name not in ("dd", "dpd"):
+            assert same == pairs, (name, f)
+
+
 @pytest.mark.gpu
 def test_reference_shaped_benchmark_runs():
     """benchmarks/mixture.cc:104-115 through the compat headers: every model,
