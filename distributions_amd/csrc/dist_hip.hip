@@ -789,6 +789,7 @@ struct Gibbs {
     DeviceBuf<int2> struct_moves;           // {dst, src} slot copies
     // ordered replay of float statistics: events sorted stably by group
     DeviceBuf<uint32_t> ev_keys, ev_vals, ev_keys_sorted, ev_vals_sorted;
+    DeviceBuf<uint32_t> cs_hist, cs_total, cs_base;   // the counting sort's
     DeviceBuf<uint32_t> seg_begin;   // [begin | end] of every group's events
     DeviceBuf<unsigned char> sort_temp;
     DeviceBuf<uint32_t> pow_lo, pow_hi;   // 16807^i, 16807^(4096 i) mod 2^31-1
@@ -901,10 +902,10 @@ struct Gibbs {
     DeviceBuf<ChainResult> chain_result;
     DeviceBuf<int32_t> delta_image;         // dist_gibbs_sweep_sharded
     DeviceBuf<float> own_score;             // k_row_prepass
-    // k_rows_scratch (general rows): 0 = round 2's k_sweep_program /
-    // k_sweep_sample, 1 = likelihoods kept in a scratch column between total
-    // and scan, 2 = scores kept between max and total as well, 3 = the same
-    // lean loops without a scratch (default: measured fastest)
+    // general rows: 3 = k_rows_scratch (default), 0 = k_sweep_program, the
+    // kernel that stays for feature lists k_rows_scratch's table does not
+    // hold (more than 64 parameter slots), kept selectable so that the tests
+    // reach it
     int rows_scratch_mode = 3;
     int rows_scratch_lds_log = 1;     // FastLog's table in LDS where NICH scores
     int rows_scratch_block = 512;     // threads per workgroup
@@ -912,9 +913,8 @@ struct Gibbs {
     // score program when its tables exist (0: only feature lists without a
     // compile-time instance of k_sweep_sample, as in round 2)
     int program_all = 1;
-    DeviceBuf<float> rows_scratch;          // [resident waves][Kpad][64]
     DeviceBuf<float> rows_gtab;             // [W][Kpad], see k_rows_gtab
-    DeviceBuf<float2> rows_snap;            // k_rows_scratch MODE 3
+    DeviceBuf<float2> rows_snap;            // k_rows_scratch, scan mode
     // 0 exact (the reference's float operations in the reference's order:
     // bit-identical assignments; the default and the line of record);
     // 1 scan: tolerance-level sampling (same scores, same draw per row, the
@@ -1561,8 +1561,10 @@ struct Gibbs {
         FoldSpec F;
         memset(&F, 0, sizeof(F));
         uint32_t J = 1;
-        const int Kpad = (K() + 2 * kRowsScan - 1) / (2 * kRowsScan)
-                         * (2 * kRowsScan) + 2 * kRowsScan;
+        // (a multiple of the snapshot distance, a block of padding groups
+        // behind the last: whole blocks are scored, the surplus is masked)
+        const int Kpad = (K() + kRowsSuper - 1) / kRowsSuper * kRowsSuper
+                         + kRowsSuper;
         if (rows_fold_mode == 2 || (rows_fold_mode == 1 && n >= 8192)) {
             const size_t per_code = rows_fold_mode == 2 ? 1 : kFoldRowsPerCode;
             for (int o = 0; o < n_ops; ++o) {
@@ -1621,11 +1623,9 @@ struct Gibbs {
         const int W = next;
         if (W > kRowsMaxW) return false;
         const bool lds_log = nich && rows_scratch_lds_log != 0;
-        // 0 likelihoods in the scratch, 1 scores as well, 2 no scratch,
-        // 3 scan sampling (tolerance-level, option "sampling")
-        const int mode = sampling_mode == 1 ? 3
-                         : rows_scratch_mode == 2 ? 1
-                         : rows_scratch_mode == 3 ? 2 : 0;
+        // the exact loops, or scan sampling (tolerance-level, option
+        // "sampling")
+        const bool scan = sampling_mode == 1;
         const int block = rows_scratch_block;
         // the program's shape at compile time where an instance exists
         if (n_ops > 4) shape = 0;
@@ -1641,10 +1641,8 @@ struct Gibbs {
 #define ROWS_SCRATCH(ID, SHAPE)                                              \
         do {                                                                 \
             shape_id = ID;                                                   \
-            if (mode == 0) ROWS_SCRATCH_M(0, SHAPE);                         \
-            else if (mode == 1) ROWS_SCRATCH_M(1, SHAPE);                    \
-            else if (mode == 2) ROWS_SCRATCH_M(2, SHAPE);                    \
-            else ROWS_SCRATCH_M(3, SHAPE);                                   \
+            if (scan) ROWS_SCRATCH_M(true, SHAPE);                           \
+            else ROWS_SCRATCH_M(false, SHAPE);                               \
         } while (0)
         if (shape == kShapeGN) ROWS_SCRATCH(1, kShapeGN);
         else if (shape == kShapeN) ROWS_SCRATCH(2, kShapeN);
@@ -1657,9 +1655,9 @@ struct Gibbs {
         int dev = 0;
         HIP_CHECK(hipGetDevice(&dev));
         // workgroups of `block` threads resident per CU, per instance
-        static std::atomic<int> per_cu[4][2][6][64];
+        static std::atomic<int> per_cu[2][2][6][64];
         std::atomic<int> & cached =
-            per_cu[mode][lds_log ? 1 : 0][shape_id][dev & 63];
+            per_cu[scan ? 1 : 0][lds_log ? 1 : 0][shape_id][dev & 63];
         int resident = cached.load(std::memory_order_relaxed);
         if (resident == 0 || resident / 4096 != block) {
             int nb = 0;
@@ -1671,14 +1669,8 @@ struct Gibbs {
         }
         const int wgs_per_cu = resident % 4096;
         size_t blocks = (size_t)wgs_per_cu * cu_count();
-        const size_t per_block = (size_t)(block / 64) * Kpad * 64;   // floats
-        // at most 16 GiB of scratch
-        const size_t limit = ((size_t)4 << 30) / std::max<size_t>(per_block, 1);
-        if (limit < 1) return false;
-        blocks = std::max<size_t>(1, std::min(blocks, limit));
         const size_t blocks_cap = blocks;
-        if (mode < 2) rows_scratch.reserve(blocks * per_block, 0);
-        if (mode == 3)
+        if (scan)
             rows_snap.reserve(blocks * (size_t)(block / 64)
                                   * (Kpad / kRowsSuper) * 64, 0);
         rows_gtab.reserve(grow_capacity((size_t)Kpad * W), 0);
@@ -1712,7 +1704,6 @@ struct Gibbs {
         A.seed_batch = P.seed_batch;
         A.pow_lo = P.pow_lo;
         A.pow_hi = P.pow_hi;
-        A.scratch = rows_scratch.p;
         A.snap = rows_snap.p;
         blocks = std::max<size_t>(
             1, std::min(blocks_cap,
@@ -2481,6 +2472,55 @@ struct Gibbs {
         if (!vals) vals = values.data();
         const size_t n_ev = old_dev ? 2 * n_rows : n_rows;
         const size_t Kn = (size_t)K();
+        ReplayFeatures R;
+        R.n = 0;
+        for (int f = 0; f < F(); ++f) {
+            if (!has_float_stats(feats[f]->sh.kind)) continue;
+            DIST_REQUIRE(vals[f], "replay: no values for an ordered feature");
+            R.s[R.n] = feats[f]->view();
+            R.values[R.n] = vals[f];
+            R.n += 1;
+        }
+        if (Kn + 1 <= (size_t)kCsMaxKeys && n_ev < ((size_t)1 << 31)) {
+            // the events sorted stably by group: histogram, scan, scatter
+            // (kernels.h, k_cs_*), straight from the moves
+            const int n_keys = (int)Kn + 1;
+            const int blocks = (int)((n_ev + kCsEvents - 1) / kCsEvents);
+            cs_hist.reserve(grow_capacity((size_t)blocks * n_keys), 0);
+            cs_base.reserve(grow_capacity((size_t)n_keys + 1), 0);
+            cs_total.reserve(grow_capacity((size_t)n_keys), 0);
+            ev_vals_sorted.reserve(n_ev, 0);
+            hipLaunchKernelGGL(k_cs_hist, dim3(blocks), dim3(kCsBlock),
+                               (size_t)n_keys * 4, stream(), old_dev, new_dev,
+                               n_ev, n_keys, cs_hist.p);
+            hipLaunchKernelGGL(k_cs_scan,
+                               dim3((n_keys + kCsBlock - 1) / kCsBlock),
+                               dim3(kCsBlock), 0, stream(), cs_hist.p, blocks,
+                               n_keys, cs_total.p);
+            const size_t lds = (size_t)(kCsBlock / 64 + 1) * n_keys * 4;
+            int device = 0;
+            HIP_CHECK(hipGetDevice(&device));
+            static std::atomic<size_t> opted_in[64];
+            std::atomic<size_t> & have = opted_in[device & 63];
+            if (lds > 64 * 1024 && lds > have.load(std::memory_order_relaxed)) {
+                HIP_CHECK(hipFuncSetAttribute(
+                    reinterpret_cast<const void *>(&k_cs_scatter),
+                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                have.store(lds, std::memory_order_relaxed);
+            }
+            hipLaunchKernelGGL(k_cs_scatter, dim3(blocks), dim3(kCsBlock), lds,
+                               stream(), old_dev, new_dev, n_ev, n_keys,
+                               cs_hist.p, cs_total.p, cs_base.p,
+                               ev_vals_sorted.p);
+            HIP_CHECK(hipGetLastError());
+            hipLaunchKernelGGL(k_replay_sorted,
+                               dim3((unsigned)Kn, (unsigned)R.n), dim3(64), 0,
+                               stream(), R, row_begin, ev_vals_sorted.p,
+                               cs_base.p, cs_base.p + 1);
+            HIP_CHECK(hipGetLastError());
+            return;
+        }
+        // (more groups than the scatter's LDS holds: the library radix sort)
         int bits = 1;   // keys 0..Kn (Kn = padding)
         while ((1ull << bits) < Kn + 1) bits += 1;
         ev_keys.reserve(n_ev, 0); ev_vals.reserve(n_ev, 0);
@@ -2497,15 +2537,6 @@ struct Gibbs {
         HIP_CHECK(hipMemsetAsync(seg_begin.p, 0, 2 * (Kn + 1) * 4, stream()));
         LAUNCH(k_replay_bounds, n_ev, ev_keys_sorted.p, n_ev, seg_begin.p,
                seg_end_p);
-        ReplayFeatures R;
-        R.n = 0;
-        for (int f = 0; f < F(); ++f) {
-            if (!has_float_stats(feats[f]->sh.kind)) continue;
-            DIST_REQUIRE(vals[f], "replay: no values for an ordered feature");
-            R.s[R.n] = feats[f]->view();
-            R.values[R.n] = vals[f];
-            R.n += 1;
-        }
         hipLaunchKernelGGL(k_replay_sorted, dim3((unsigned)Kn, (unsigned)R.n),
                            dim3(64), 0, stream(), R, row_begin,
                            ev_vals_sorted.p, seg_begin.p, seg_end_p);
@@ -4823,11 +4854,9 @@ int dist_gibbs_set_option(dist_gibbs_t * g, const char * name, int value) {
             DIST_REQUIRE(value >= 0, "running_sums_min_tiles: >= 0");
             g->impl->running_sums_min_tiles = value;
         } else if (key == "rows_scratch") {
-            // general rows: 0 every pass scores again (k_sweep_program),
-            // 1 the likelihoods stay in a scratch column between total and
-            // scan (default), 2 the scores between max and total as well,
-            // 3 k_rows_scratch's lean loops without the scratch
-            DIST_REQUIRE(value >= 0 && value <= 3, "rows_scratch: 0 to 3");
+            // general rows: 3 k_rows_scratch (default), 0 k_sweep_program
+            // (what feature lists beyond k_rows_scratch's table take anyway)
+            DIST_REQUIRE(value == 0 || value == 3, "rows_scratch: 0 or 3");
             g->impl->rows_scratch_mode = value;
         } else if (key == "rows_scratch_lds_log") {
             DIST_REQUIRE(value == 0 || value == 1,

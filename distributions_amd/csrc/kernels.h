@@ -1302,22 +1302,15 @@ __global__ __launch_bounds__(kBlock) void k_sweep_program(
 }
 
 // ---------------------------------------------------------------------------
-// k_rows_scratch: general rows with the likelihoods kept between the passes.
+// k_rows_scratch: general rows (any feature list), a lane per row.
 //
 // The three recurrences of a row (max, in-order total, subtractive scan:
 // random.cc:94-106, random.hpp:316-333) each need every group's score; the
-// kernels above evaluate score and exponential again in each pass.  Here the
-// total's pass leaves l[k] = fast_exp(s[k] - max) in a scratch column of K
-// floats per row and the scan reads it back (MODE 0: two score evaluations,
-// one exponential, 8 B of HBM traffic per (row, group)); MODE 1 also keeps
-// the scores of the max pass for the total's pass (one evaluation, 16 B).
+// exact mode evaluates score and exponential again in each pass, eight groups
+// at a time in registers.  (The name is history: round 3 built and measured
+// variants that kept the likelihoods -- or the scores as well -- in an HBM
+// scratch column between the passes; they lost and are gone, see the kernel.)
 // Same float operations in the same order as k_sweep_program: bit-identical.
-//
-// Scratch layout: one block of Kpad x 64 floats per resident WAVE,
-// [k / 4][lane][4]: a lane's four consecutive groups are 16 contiguous bytes,
-// so a pass streams its block with one 1-KiB dwordx4 store / load per four
-// groups; a wave re-uses its block for every 64 rows it takes (grid-stride),
-// so the scratch is (resident waves) x Kpad x 256 B whatever the batch size.
 //
 // The per-group parameters of the whole program sit in one per-batch table
 // (gtab[slot][Kpad]: slot 0 the driver's score, then each op's cache entries,
@@ -1330,15 +1323,12 @@ __global__ __launch_bounds__(kBlock) void k_sweep_program(
 // arithmetic, and reads beyond the table (the padding groups of the last
 // block) return zero.
 // LDSLOG: FastLog's 64 KiB table is copied into LDS (the per-lane gather of
-// nich.cc:60-66 then leaves the vector-memory path to the scratch stream).
+// nich.cc:60-66 then leaves the vector-memory path to the table gathers).
 constexpr int kScratchMaxBlock = 1024;
 constexpr int kRowsBlock = 8;       // groups scored at a time, in registers
 constexpr int kRowsMaxW = 64;       // floats per gtab row
 constexpr int kRowsMaxOps = 8;      // = kMaxF: one op per feature
-// rows of scratch a wave block is padded to (the scan reads two runs of
-// kRowsScan rows ahead)
-constexpr int kRowsScan = 16;
-// MODE 3 (scan sampling): groups per snapshot of the running (sum, max)
+// scan sampling: groups per snapshot of the running (sum, max)
 constexpr int kRowsSuper = 32;
 
 enum { ROP_GATHER = 0,   // s += tab[k][x]           BB, GP, BNB
@@ -1356,7 +1346,7 @@ struct RowsArgs {
     int n_ops;
     int W;                     // slots of gtab
     int K;                     // groups (an upper bound when dev != null)
-    int Kpad;                  // scratch rows per wave block
+    int Kpad;                  // row stride of gtab / fold / snap
     const DevState * dev;
     const float * gtab;        // [W][Kpad]
     const uint32_t * slot;     // k_row_prepass: own slot or 0xFFFFFFFF
@@ -1368,8 +1358,7 @@ struct RowsArgs {
     int pad;
     const uint32_t * pow_lo;
     const uint32_t * pow_hi;
-    float * scratch;
-    float2 * snap;                 // MODE 3: [waves][Kpad / kRowsSuper][64]
+    float2 * snap;                 // scan: [waves][Kpad / kRowsSuper][64]
     // folded leading ops (see FoldSpec): the wave's rows share one joint
     // value `code`, their score before the first remaining op is
     // fold[code][k]; work items are tiles of the code-sorted row list
@@ -1633,7 +1622,7 @@ __device__ __forceinline__ void rows_score_block(
 }
 
 // the score of ONE group with a per-lane group index (vector loads; the same
-// float operations as rows_score_block): MODE 3's second look at the
+// float operations as rows_score_block): the scan mode's second look at the
 // kRowsSuper groups around a row's draw
 template <bool LDSLOG>
 __device__ __forceinline__ float rows_score_lane(
@@ -1673,14 +1662,7 @@ struct RowsRow {
     bool live;
 };
 
-// MODE 0: likelihoods in the scratch, and the scan of a wave's row tile i
-//         runs inside the max pass of its tile i + 1 (the scan only loads and
-//         subtracts, the max pass only computes: fused, the wave has memory
-//         requests in flight while it scores);
-// MODE 1: scores kept for the total's pass as well (one evaluation, 16 B);
-// MODE 2: no scratch: the scan evaluates score and exponential again (rows
-//         whose score is cheap -- one feature -- are faster this way).
-// MODE 3: SCAN SAMPLING, tolerance-level and opt-in (option "sampling" = 1;
+// SCAN: SCAN SAMPLING, tolerance-level and opt-in (option "sampling" = 1;
 //         never the default).  One pass: every score is evaluated once (the
 //         same float operations: the scores are the exact modes' bit for bit)
 //         into a running log-sum-exp -- running maximum m, running sum S of
@@ -1692,7 +1674,7 @@ struct RowsRow {
 //         cumulative likelihood >= u * total), different float summation
 //         order: the index can differ from the exact modes' where u * total
 //         falls within rounding of a boundary.
-template <int MODE, bool LDSLOG, int SHAPE>
+template <bool SCAN, bool LDSLOG, int SHAPE>
 __global__ __launch_bounds__(kScratchMaxBlock) void k_rows_scratch(RowsArgs A) {
     __shared__ uint32_t s_exp[1024];                  // biased, see above
     __shared__ uint32_t s_log[LDSLOG ? 16384 : 1];
@@ -1711,15 +1693,7 @@ __global__ __launch_bounds__(kScratchMaxBlock) void k_rows_scratch(RowsArgs A) {
     const size_t wave_slot =
         (size_t)blockIdx.x * (blockDim.x >> 6)
         + (size_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    // this wave's block of the scratch; groups 4q .. 4q + 3 of the lane's row
-    // at col[q * 64]
-    float4 * col = MODE >= 2
-                       ? nullptr
-                       : reinterpret_cast<float4 *>(
-                             A.scratch + wave_slot * (size_t)A.Kpad * 64)
-                             + lane;
     const int K8 = (K + kRowsBlock - 1) & ~(kRowsBlock - 1);
-    const int K16 = (K + kRowsScan - 1) & ~(kRowsScan - 1);
 
     // work item w: 64 consecutive rows, or (folding) a tile of the
     // code-sorted row list
@@ -1775,11 +1749,6 @@ __global__ __launch_bounds__(kScratchMaxBlock) void k_rows_scratch(RowsArgs A) {
             for (int j = 0; j < kRowsBlock; ++j)
                 s[j] = k0 + j < K ? s[j] : -INFINITY;
         }
-        if (MODE == 1) {
-            col[(size_t)(k0 >> 2) * 64] = make_float4(s[0], s[1], s[2], s[3]);
-            col[(size_t)((k0 >> 2) + 1) * 64] =
-                make_float4(s[4], s[5], s[6], s[7]);
-        }
 #pragma unroll
         for (int j = 0; j < kRowsBlock; ++j) m = fmaxf(m, s[j]);
     };
@@ -1787,15 +1756,8 @@ __global__ __launch_bounds__(kScratchMaxBlock) void k_rows_scratch(RowsArgs A) {
     // +0 beyond the last group
     auto like_block = [&](const RowsRow & r, int k0, float m,
                           float (&s)[kRowsBlock]) {
-        if (MODE == 1) {
-            const float4 a = col[(size_t)(k0 >> 2) * 64];
-            const float4 b = col[(size_t)((k0 >> 2) + 1) * 64];
-            s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w;
-            s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w;
-        } else {
-            rows_score_block<SHAPE, LDSLOG>(A, base_of(r), r.xv, k0, r.g,
-                                            r.s_own, s_log, s);
-        }
+        rows_score_block<SHAPE, LDSLOG>(A, base_of(r), r.xv, k0, r.g, r.s_own,
+                                        s_log, s);
 #pragma unroll
         for (int j = 0; j < kRowsBlock; ++j)
             s[j] = fast_exp_biased(s[j] - m, s_exp, ea, eb);
@@ -1803,26 +1765,6 @@ __global__ __launch_bounds__(kScratchMaxBlock) void k_rows_scratch(RowsArgs A) {
 #pragma unroll
             for (int j = 0; j < kRowsBlock; ++j)
                 s[j] = k0 + j < K ? s[j] : 0.f;
-        }
-    };
-    // sample_from_likelihoods (random.hpp:316-333) over a run of entries:
-    // t never increases, so the index is the number of steps after which t is
-    // still positive (entries beyond K are +0: they count only once t stayed
-    // positive through K - 1, which the final clamp maps to K - 1 as well)
-    auto scan_run = [&](const float (&l)[kRowsScan], float & t, int & steps) {
-#pragma unroll
-        for (int j = 0; j < kRowsScan; ++j) {
-            t -= l[j];
-            steps += t > 0.f ? 1 : 0;
-        }
-    };
-    // a run of kRowsScan likelihoods of the lane's row, from group k0
-    auto load_run = [&](int k0, float (&l)[kRowsScan]) {
-#pragma unroll
-        for (int q = 0; q < kRowsScan / 4; ++q) {
-            const float4 v = col[(size_t)((k0 >> 2) + q) * 64];
-            l[4 * q] = v.x; l[4 * q + 1] = v.y;
-            l[4 * q + 2] = v.z; l[4 * q + 3] = v.w;
         }
     };
     auto draw = [&](const RowsRow & r) {
@@ -1836,7 +1778,7 @@ __global__ __launch_bounds__(kScratchMaxBlock) void k_rows_scratch(RowsArgs A) {
     size_t tile = wave_slot;   // the wave's work item (uniform)
     if (tile >= n_work) return;
     RowsRow cur;
-    if constexpr (MODE == 3) {
+    if constexpr (SCAN) {
         constexpr float kLog2e = 1.44269504088896341f;
         const int n_super = (K + kRowsSuper - 1) / kRowsSuper;
         float2 * snap =
@@ -1912,89 +1854,42 @@ __global__ __launch_bounds__(kScratchMaxBlock) void k_rows_scratch(RowsArgs A) {
         }
         return;
     }
-    load_row(tile, cur);
-    float m = -INFINITY;
-    for (int k0 = 0; k0 < K8; k0 += kRowsBlock) max_block(cur, k0, m);
-    for (;;) {
-        // total in index order (random.cc:100-103); the likelihoods stay
-        // behind in the scratch column
+    // the exact mode: three passes over the groups, every score evaluated in
+    // each (the variants that kept the likelihoods, or the scores as well, in
+    // an HBM scratch column between the passes were measured and lost: 42
+    // instead of 60 instructions per (row, group), but 8 / 16 B of private
+    // write-then-read traffic that tops out at 0.45 of the HBM roof:
+    // profiles/r3_pmc_rows_scratch_mode1.txt)
+    for (; tile < n_work; tile += stride) {
+        load_row(tile, cur);
+        float m = -INFINITY;
+        for (int k0 = 0; k0 < K8; k0 += kRowsBlock) max_block(cur, k0, m);
+        // total in index order (random.cc:100-103)
         float total = 0.f;
         for (int k0 = 0; k0 < K8; k0 += kRowsBlock) {
             float l[kRowsBlock];
             like_block(cur, k0, m, l);
 #pragma unroll
             for (int j = 0; j < kRowsBlock; ++j) total += l[j];
-            if (MODE != 2) {
-                col[(size_t)(k0 >> 2) * 64] =
-                    make_float4(l[0], l[1], l[2], l[3]);
-                col[(size_t)((k0 >> 2) + 1) * 64] =
-                    make_float4(l[4], l[5], l[6], l[7]);
-            }
         }
-        if (MODE != 2)   // (the scan reads runs of kRowsScan rows)
-            for (int k = K8; k < K16; k += 4)
-                col[(size_t)(k >> 2) * 64] = make_float4(0.f, 0.f, 0.f, 0.f);
+        // sample_from_likelihoods (random.hpp:316-333): t never increases, so
+        // the index is the number of steps after which t is still positive
+        // (entries beyond K are +0: they count only once t stayed positive
+        // through K - 1, which the final clamp maps to K - 1 as well)
         float t = total * draw(cur);
         int steps = 0;
-        const size_t next_tile = tile + stride;
-        const bool more = next_tile < n_work;
-        RowsRow nxt;
-        float m_next = -INFINITY;
-        if (MODE == 2) {
-            for (int k0 = 0; k0 < K8; k0 += kRowsBlock) {
-                float l[kRowsBlock];
-                like_block(cur, k0, m, l);
+        for (int k0 = 0; k0 < K8; k0 += kRowsBlock) {
+            float l[kRowsBlock];
+            like_block(cur, k0, m, l);
 #pragma unroll
-                for (int j = 0; j < kRowsBlock; ++j) {
-                    t -= l[j];
-                    steps += t > 0.f ? 1 : 0;
-                }
-                if (!__any(cur.live && t > 0.f)) break;
+            for (int j = 0; j < kRowsBlock; ++j) {
+                t -= l[j];
+                steps += t > 0.f ? 1 : 0;
             }
-        } else if (MODE == 0 && more) {
-            // the scan of this tile inside the max pass of the next one: a
-            // run's loads are requested, two blocks are scored, then the run
-            // is consumed
-            load_row(next_tile, nxt);
-            for (int k0 = 0; k0 < K16; k0 += kRowsScan) {
-                float l[kRowsScan];
-                load_run(k0, l);
-                __builtin_amdgcn_sched_barrier(0);   // requests stay up here
-                max_block(nxt, k0, m_next);
-                if (k0 + kRowsBlock < K8)
-                    max_block(nxt, k0 + kRowsBlock, m_next);
-                __builtin_amdgcn_sched_barrier(0);
-                scan_run(l, t, steps);
-            }
-        } else {
-            // two runs in flight: the next is requested before the current
-            // one is consumed (requests past the last run fall into the
-            // block's padding rows and are never used)
-            float la[kRowsScan], lb[kRowsScan];
-            load_run(0, la);
-            for (int k0 = 0; k0 < K; k0 += 2 * kRowsScan) {
-                load_run(k0 + kRowsScan, lb);
-                __builtin_amdgcn_sched_barrier(0);
-                scan_run(la, t, steps);
-                if (k0 + kRowsScan >= K || !__any(cur.live && t > 0.f)) break;
-                load_run(k0 + 2 * kRowsScan, la);
-                __builtin_amdgcn_sched_barrier(0);
-                scan_run(lb, t, steps);
-                if (!__any(cur.live && t > 0.f)) break;
-            }
+            if (!__any(cur.live && t > 0.f)) break;
         }
         if (cur.live)
             A.new_packed[cur.out] = (uint32_t)(steps < K - 1 ? steps : K - 1);
-        if (!more) break;
-        tile = next_tile;
-        if (MODE == 0) {
-            cur = nxt;
-            m = m_next;
-        } else {
-            load_row(tile, cur);
-            m = -INFINITY;
-            for (int k0 = 0; k0 < K8; k0 += kRowsBlock) max_block(cur, k0, m);
-        }
     }
 }
 
@@ -5020,6 +4915,182 @@ __global__ void k_zero_ordered_stats(SlaveView s, int K) {
     if (k >= K) return;
     s.f0[k] = 0.f;
     if (s.kind == DIST_NICH) { s.i0[k] = 0; s.f1[k] = 0.f; }
+}
+
+// ---------------------------------------------------------------------------
+// The batch's statistic events sorted STABLY by group for the ordered replay
+// (k_replay_sorted): event 2b removes row b from its old group, event 2b + 1
+// adds it to its new one (additions only: one event per row), and every
+// group's events must come out in row order (nich.hpp:125-165, gp.hpp:109-135
+// are order-dependent).  A counting sort on the group key in three launches --
+// histogram, scan, scatter -- that reads the moves directly (no key / value
+// arrays, no segment-bound pass: a group's events are [base[k], base[k + 1]));
+// it replaced a library radix sort (five launches and eight fills).
+// Keys: 0 .. n_keys - 2 the groups, n_keys - 1 the padding rows.
+constexpr int kCsBlock = 256;            // threads per workgroup
+constexpr int kCsEvents = 4096;          // events per workgroup: 1024 per wave
+constexpr int kCsMaxKeys = 7000;         // (the scatter keeps 5 x n_keys in LDS)
+__device__ __forceinline__ uint32_t cs_event_key(
+        const uint32_t * __restrict__ old_packed,
+        const uint32_t * __restrict__ new_packed, size_t e, uint32_t pad_key) {
+    if (old_packed == nullptr) {   // additions only: event e adds row e
+        const uint32_t g = new_packed[e];
+        return g == 0xFFFFFFFFu ? pad_key : g;
+    }
+    const uint32_t g2 = new_packed[e >> 1];
+    if (g2 == 0xFFFFFFFFu) return pad_key;
+    return (e & 1) ? g2 : old_packed[e >> 1];
+}
+__global__ __launch_bounds__(kCsBlock) void k_cs_hist(
+        const uint32_t * __restrict__ old_packed,
+        const uint32_t * __restrict__ new_packed, size_t n_ev, int n_keys,
+        uint32_t * __restrict__ hist) {
+    extern __shared__ uint32_t cs_lds[];   // [n_keys]
+    for (int k = threadIdx.x; k < n_keys; k += kCsBlock) cs_lds[k] = 0;
+    __syncthreads();
+    const size_t begin = (size_t)blockIdx.x * kCsEvents;
+    for (int i = threadIdx.x; i < kCsEvents; i += kCsBlock) {
+        const size_t e = begin + i;
+        if (e < n_ev)
+            atomicAdd(&cs_lds[cs_event_key(old_packed, new_packed, e,
+                                           (uint32_t)n_keys - 1)], 1u);
+    }
+    __syncthreads();
+    uint32_t * row = hist + (size_t)blockIdx.x * n_keys;
+    for (int k = threadIdx.x; k < n_keys; k += kCsBlock) row[k] = cs_lds[k];
+}
+// hist[b][k] becomes the events of key k in workgroups before b, total[k]
+// their number in all: a thread per key walks its column (rows coalesce
+// across the threads)
+__global__ __launch_bounds__(kCsBlock) void k_cs_scan(
+        uint32_t * __restrict__ hist, int blocks, int n_keys,
+        uint32_t * __restrict__ total) {
+    const int k = blockIdx.x * kCsBlock + threadIdx.x;
+    if (k >= n_keys) return;
+    uint32_t run = 0;
+    constexpr int U = 8;   // loads in flight per thread
+    int b = 0;
+    for (; b + U <= blocks; b += U) {
+        uint32_t v[U];
+#pragma unroll
+        for (int q = 0; q < U; ++q) v[q] = hist[(size_t)(b + q) * n_keys + k];
+#pragma unroll
+        for (int q = 0; q < U; ++q) {
+            hist[(size_t)(b + q) * n_keys + k] = run;
+            run += v[q];
+        }
+    }
+    for (; b < blocks; ++b) {
+        const uint32_t v = hist[(size_t)b * n_keys + k];
+        hist[(size_t)b * n_keys + k] = run;
+        run += v;
+    }
+    total[k] = run;
+}
+// every event's id to its place.  base[k] = the events of keys before k
+// (every workgroup scans the totals for itself; workgroup 0 leaves base[] for
+// k_replay_sorted: a group's events are [base[k], base[k + 1])).  A wave
+// walks its 1024 events in order, 64 at a time: a lane takes its place with
+// an LDS atomic on its key's counter; where several lanes of the 64 share a
+// key -- the lane that drew the lowest place sees the counter move by more
+// than one -- that key's lanes take consecutive places in LANE order instead
+// (the sort must be stable: a group's events replay in row order).
+__global__ __launch_bounds__(kCsBlock) void k_cs_scatter(
+        const uint32_t * __restrict__ old_packed,
+        const uint32_t * __restrict__ new_packed, size_t n_ev, int n_keys,
+        const uint32_t * __restrict__ hist,
+        const uint32_t * __restrict__ total, uint32_t * __restrict__ base_out,
+        uint32_t * __restrict__ events_out) {
+    extern __shared__ uint32_t cs_lds[];   // [n_keys] base | [waves][n_keys]
+    __shared__ uint32_t s_part[kCsBlock / 64];
+    __shared__ uint32_t s_carry;
+    constexpr int kWaves = kCsBlock / 64;
+    constexpr int kPerWave = kCsEvents / kWaves;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t pad_key = (uint32_t)n_keys - 1;
+    uint32_t * base = cs_lds;
+    uint32_t * places = cs_lds + n_keys;
+    // base[]: exclusive scan of the totals, a stretch of kCsBlock keys at a time
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (int k0 = 0; k0 < n_keys; k0 += kCsBlock) {
+        const int k = k0 + threadIdx.x;
+        const uint32_t t = k < n_keys ? total[k] : 0u;
+        uint32_t incl = t;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t up = __shfl_up(incl, off);
+            if (lane >= off) incl += up;
+        }
+        if (lane == 63) s_part[wave] = incl;
+        __syncthreads();
+        uint32_t run = s_carry + incl - t;
+        for (int w = 0; w < wave; ++w) run += s_part[w];
+        if (k < n_keys) base[k] = run;
+        __syncthreads();
+        if (threadIdx.x == kCsBlock - 1) s_carry = run + t;
+        __syncthreads();
+    }
+    if (blockIdx.x == 0) {
+        for (int k = threadIdx.x; k < n_keys; k += kCsBlock) base_out[k] = base[k];
+        if (threadIdx.x == 0) base_out[n_keys] = s_carry;
+    }
+    // the waves' own counts, then their first places: the keys before, the
+    // workgroups before, the waves before
+    for (int i = threadIdx.x; i < kWaves * n_keys; i += kCsBlock) places[i] = 0;
+    __syncthreads();
+    const size_t begin = (size_t)blockIdx.x * kCsEvents + (size_t)wave * kPerWave;
+    uint32_t * mine = places + (size_t)wave * n_keys;
+    for (int i = lane; i < kPerWave; i += 64) {
+        const size_t e = begin + i;
+        if (e < n_ev)
+            atomicAdd(&mine[cs_event_key(old_packed, new_packed, e, pad_key)], 1u);
+    }
+    __syncthreads();
+    const uint32_t * row = hist + (size_t)blockIdx.x * n_keys;
+    for (int k = threadIdx.x; k < n_keys; k += kCsBlock) {
+        uint32_t run = base[k] + row[k];
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) {
+            const uint32_t c = places[(size_t)w * n_keys + k];
+            places[(size_t)w * n_keys + k] = run;
+            run += c;
+        }
+    }
+    __syncthreads();
+    for (int i0 = 0; i0 < kPerWave; i0 += 64) {
+        const size_t e = begin + i0 + lane;
+        const bool active = e < n_ev;
+        const uint32_t key =
+            active ? cs_event_key(old_packed, new_packed, e, pad_key) : 0u;
+        // (additions only: the event id of row e is 2 e + 1, k_replay_sorted's
+        // convention)
+        const uint32_t id = old_packed ? (uint32_t)e : (uint32_t)(2 * e + 1);
+        uint32_t place = 0, after = 0;
+        if (active) place = atomicAdd(&mine[key], 1u);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (active) after = mine[key];
+        // keys that several of the 64 lanes hold: their lane of lowest place
+        // sees the counter two or more ahead of it
+        unsigned long long todo =
+            __builtin_amdgcn_ballot_w64(active && after - place >= 2u);
+        while (todo) {
+            const int leader = __builtin_ctzll(todo);
+            const uint32_t kl =
+                (uint32_t)__builtin_amdgcn_readlane((int)key, leader);
+            const bool same = active && key == kl;
+            const unsigned long long group = __builtin_amdgcn_ballot_w64(same);
+            if (same) {
+                const unsigned long long lower = group & ((1ull << lane) - 1ull);
+                place = after - (uint32_t)__popcll(group)
+                        + (uint32_t)__popcll(lower);
+            }
+            todo &= ~group;
+        }
+        if (active) events_out[place] = id;
+        __builtin_amdgcn_wave_barrier();
+    }
 }
 
 // first/one-past-last position of every group's events in the sorted list

@@ -175,17 +175,29 @@ class ShardedGibbs(object):
         self._delta = None
         self._comm = None
         self._n_batches = {}    # batch_rows -> sub-sweeps per pass (all ranks)
-        # order-dependent statistics travel as rows (every replica replays
-        # all of them) unless the backend keeps them as sums
-        # (float_stats = 1: one more all-reduce of a few doubles per group)
-        self.merged = (self.collective and backend.ordered_features() > 0
-                       and getattr(backend, "float_delta_words",
-                                   lambda: 0)() > 0)
-        self.ordered = (self.collective and backend.ordered_features() > 0
-                        and not self.merged)
         self.columns = columns
         self.assign_packed = assign_packed
-        if self.ordered and columns is None:
+        # (a property of the feature list: engines without such statistics
+        # are never asked again -- the question would close an open
+        # device-normalised run)
+        self._has_ordered = backend.ordered_features() > 0
+        self._exchange_mode()
+
+    def _exchange_mode(self):
+        """Order-dependent statistics travel as rows (every replica replays
+        all of them) unless the backend keeps them as sums (float_stats = 1:
+        one more all-reduce of a few doubles per group).  Asked again before
+        every pass: whether the sums fit the backend's LDS pass depends on the
+        group count, which grows."""
+        backend = self.backend
+        if not self._has_ordered:
+            self.merged = self.ordered = False
+            return
+        self.merged = (self.collective
+                       and getattr(backend, "float_delta_words",
+                                   lambda: 0)() > 0)
+        self.ordered = self.collective and not self.merged
+        if self.ordered and self.columns is None:
             raise ValueError("features with order-dependent statistics need "
                              "the local value columns (columns=...)")
 
@@ -329,6 +341,9 @@ class ShardedGibbs(object):
         """One pass over the local shard; all ranks take the same number of
         sub-sweeps (shards are equal up to one batch of padding)."""
         import torch
+        self._exchange_mode()
+        if self.ordered:
+            self._comm = None   # (rows, not sums: the Python loop below)
         n_batches = (self.n_local + batch_rows - 1) // batch_rows
         if self.collective:
             if self._n_batches.get(batch_rows) is None:

@@ -477,9 +477,8 @@ int dist_gibbs_sharded_device_normalise_ok(const dist_gibbs_t * g,
  * rows a tile hands over are sampled by k_vs_apply; 0: k_normalise,
  * k_batch_finish, k_vs_prepare and k_rows_wave as launches of their own;
  * "rows_scratch" (general rows: any feature list the value-sorted kernels do
- * not take) = 3 (default: k_rows_scratch's loops, every pass scores again),
- * 1 (the likelihoods of the total's pass stay in an HBM scratch column for
- * the scan), 2 (the scores of the max pass as well), 0 (round 2's kernels);
+ * not take) = 3 (default: k_rows_scratch) or 0 (k_sweep_program, the kernel
+ * that feature lists beyond k_rows_scratch's parameter table take anyway);
  * "rows_scratch_lds_log" = 1 (default: FastLog's table in LDS) or 0;
  * "rows_scratch_block" = threads per workgroup of that kernel (512);
  * "rows_fold" = 1 (default: the discrete features before the first

@@ -24,7 +24,7 @@ pytestmark = pytest.mark.gpu
 K, BATCH, SWEEPS, SEED = 24, 1500, 2, 4242
 
 
-def worker(rank, port, out, config, mode, N, peek=False):
+def worker(rank, port, out, config, mode, N, peek=False, float_stats=0):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -41,6 +41,7 @@ def worker(rank, port, out, config, mode, N, peek=False):
     gpu = engine.Gibbs(1.0, 0.2, gsh)
     gpu.set_option("value_sorted", mode)
     gpu.set_option("device_normalise", 1)
+    gpu.set_option("float_stats", float_stats)
     gpu.load_rows_torch(cols, packed.clone(), K, 2)
     sharded = engine.ShardedGibbs(gpu.core, N, 0, device=dev,
                                   force_collective=True,
@@ -104,4 +105,32 @@ def test_native_loop_equals_oracle(tmp_path, config, mode, N, peek):
     want = np.stack([np.concatenate([m.get_group(f, g)
                                      for f in range(len(osh))])
                      for g in range(len(m))])
+    assert np.array_equal(np.load(tmp_path / "groups.npy"), want)
+
+
+def test_native_loop_takes_merged_float_statistics(tmp_path):
+    """BASELINE configs[2]'s feature list (GammaPoisson + NormalInverseChiSq)
+    with float_stats = 1: the order-dependent statistics travel as binary64
+    sums (one more all-reduce per sub-sweep), so the library's own loop takes
+    the engine instead of handing it back to the Python loop -- and is the
+    same function of the data as the single engine with the same option."""
+    import workloads
+    from distributions_amd import _core, engine
+    config, N = "gp_nich", 6000
+    mp.spawn(worker, args=(free_port(), str(tmp_path), config, 1, N, False, 1),
+             nprocs=1, join=True)
+    assert bool(np.load(tmp_path / "native.npy")[0])
+    osh, gsh, vals, assign = workloads.make(config, N, K)
+    gpu = engine.Gibbs(1.0, 0.2, gsh)
+    gpu.set_option("value_sorted", 1)
+    gpu.set_option("float_stats", 1)
+    gpu.load_rows(vals, assign, K, 2)
+    for s in range(SWEEPS):
+        gpu.sweep(0, N, BATCH, SEED, draw_base=s * N)
+    assert gpu.core.debug_counts()["merged_batches"] > 0
+    assert np.array_equal(np.load(tmp_path / "assign.npy"), gpu.assignments())
+    assert np.array_equal(np.load(tmp_path / "counts.npy"), gpu.counts())
+    want = np.stack([np.concatenate([gpu.get_group(f, g)
+                                     for f in range(len(gsh))])
+                     for g in range(len(gpu))])
     assert np.array_equal(np.load(tmp_path / "groups.npy"), want)

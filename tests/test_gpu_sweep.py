@@ -101,18 +101,16 @@ def test_batch_sweeps_bit_exact(config, batch, mode):
 
 @pytest.mark.parametrize("config", CONFIGS + ["nich2"])
 @pytest.mark.parametrize("scratch,lds_log,block,fold",
-                         [(0, 1, 512, 0), (1, 1, 512, 0), (1, 0, 256, 2),
-                          (2, 1, 1024, 0), (2, 0, 64, 2), (3, 1, 512, 0),
-                          (3, 1, 256, 2), (1, 1, 64, 2)])
+                         [(0, 1, 512, 0), (3, 0, 256, 2), (3, 1, 1024, 0),
+                          (3, 0, 64, 2), (3, 1, 512, 0), (3, 1, 256, 2),
+                          (3, 1, 64, 2)])
 @pytest.mark.parametrize("k", [31, 40])
 def test_general_rows_scratch_kernel_bit_exact(config, scratch, lds_log, block,
                                                fold, k):
-    """k_rows_scratch against the oracle on every feature list, with group
-    counts on either side of its blocks of 8 and 16 groups.  scratch 1: the
-    likelihoods of the total's pass kept for the scan; 2: the scores of the
-    max pass kept as well; 3: its loops without the scratch; 0: round 2's
-    kernels.  Small workgroups give every wave several row tiles (mode 1: the
-    scan of one tile inside the max pass of the next).  fold 2: the leading
+    """k_rows_scratch (scratch = 3) and k_sweep_program (0) against the oracle
+    on every feature list, with group counts on either side of the blocks of
+    8 groups.  Small workgroups give every wave several row tiles; the table
+    of FastLog in LDS or not.  fold 2: the leading
     discrete features' scores from the per-(joint value, group) table, rows
     sorted by joint value, whenever the joint domain fits the batch."""
     n = 6000
