@@ -833,6 +833,10 @@ struct Gibbs {
         uint32_t n_chunks = 0;
         bool one_chunk_per_value = false;  // every value's rows in ONE chunk
         bool mixed_chunks = false;         // some chunks hold several values
+        // the chunks of the values inside the tables come first, each of one
+        // value, kVsApplyRows rows apart within a value (bands per chunk)
+        bool one_value_chunks = false;
+        uint32_t n_table_chunks = 0;
         DeviceBuf<uint32_t> val_start;    // [nvals + 1] first position per value
         DeviceBuf<uint32_t> chunk_first;  // [nvals + 1] first chunk per value
         // rows handed over per chunk (VsDefer): zero between batches
@@ -1932,6 +1936,8 @@ struct Gibbs {
                 first[x] = ci;   // (the chunk that holds the value's first row)
             }
             c->chunk_first.upload(first.data(), first.size());
+            c->n_table_chunks = first[nv];
+            c->one_value_chunks = !c->mixed_chunks;
         }
         c->def_counts.reserve(std::max<size_t>(chunks.size(), 1), 0);   // zeros
         // rows whose value is outside the table: generic kernel, by position
@@ -2022,7 +2028,7 @@ struct Gibbs {
                 small ? 1 : kVsSampleBlock / 64;   // tiles per workgroup
             // (band tiles first, a whole number of workgroups)
             const uint32_t band_ids =
-                T.band_mode ? (nv + per - 1) / per * per : 0;
+                T.band_mode ? (T.band_count + per - 1) / per * per : 0;
             const dim3 grid((band_ids + c->n_tiles + per - 1) / per);
             if (c->n_tiles && small)
                 hipLaunchKernelGGL((k_vs_sample<KIND, 64>), grid, dim3(64), 0,
@@ -2290,16 +2296,21 @@ struct Gibbs {
         // ... and their workgroups do not push the launch past what is
         // resident at once (two 1024-thread workgroups per CU at 8 waves/SIMD;
         // a band workgroup is gone in about half the time of a regular one)
+        // (fused: a band per apply CHUNK, read from the offsets the chunk's
+        // sort left -- no walk, so values of any size take part; else a band
+        // per value, found by k_vs_prepare's walk over the value's rows)
+        const uint32_t band_count = fused ? c.n_table_chunks : nv;
         const uint32_t per_wg = kVsSampleBlock / 64;
         const uint32_t tile_wgs = (c.n_tiles + per_wg - 1) / per_wg;
-        const uint32_t band_wgs = (nv + per_wg - 1) / per_wg;
+        const uint32_t band_wgs = (band_count + per_wg - 1) / per_wg;
         const uint32_t slots = 2u * (uint32_t)cu_count();
-        const bool bands = large && n / nv <= kVsBandWalkRows
+        const bool bands = large && (fused || n / nv <= kVsBandWalkRows)
+                           && !(fused && !c.one_value_chunks)
                            && (tile_wgs + band_wgs / 2 <= slots
                                || tile_wgs > slots);
         if (bands) {
-            vsBandMode.reserve(nv, 0);
-            vsBandTile.reserve(nv, 0);
+            vsBandMode.reserve(band_count, 0);
+            vsBandTile.reserve(band_count, 0);
         }
         last_bands = bands;
         last_prefix = prefix;
@@ -2331,7 +2342,8 @@ struct Gibbs {
                             bands ? vsBandMode.p : nullptr,
                             bands ? vsBandTile.p : nullptr, c.val_start.p,
                             nv, nullptr, c.chunk_first.p,
-                            fused ? vsOwn.p : nullptr, Kuse}, narrow, fused};
+                            fused ? vsOwn.p : nullptr, Kuse, band_count,
+                            fused ? 1 : 0}, narrow, fused};
         // DIST_VS_STAMPS=<file>: per-wave phase stamps of every launch (the
         // last one stays in the file): tools/vs_stamps.py
         static const char * stamps_path = getenv("DIST_VS_STAMPS");
@@ -2725,7 +2737,7 @@ struct Gibbs {
             // offsets per chunk (bands without a walk, k_vs_tables); any
             // other form clears the stamps of a range that has some
             VsOffsets O{nullptr, c.off_epoch.p, 0};
-            if (sort && async_active && c.one_chunk_per_value) {
+            if (sort && async_active && c.one_value_chunks) {
                 if (c.off_stride < K() + 2) {
                     c.off_stride = (int)grow_capacity((size_t)K() + 2);
                     c.grp_off.release();

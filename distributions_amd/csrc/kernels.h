@@ -2347,6 +2347,13 @@ struct VsTables {
     // the bound on the group count at THIS batch, a multiple of kVsUnroll,
     // <= Kpad (which stays the run's row stride)
     int Kuse;
+    // band_mode / band_tile entries: one per VALUE (k_vs_prepare's walk), or --
+    // band_by_chunk, k_vs_tables -- one per apply CHUNK of the values inside
+    // the tables: a value with more rows than a chunk holds (Zipf's head)
+    // then still gives the arg-max group's rows of every chunk a tile of
+    // their own
+    uint32_t band_count;
+    int band_by_chunk;
 };
 constexpr uint32_t kVsBandWalkRows = 8192;
 
@@ -2941,30 +2948,33 @@ __global__ __launch_bounds__(kTablesBlock) void k_vs_tables(TablesParams A,
             A.scalars->empty_single = empty_single;
         }
     }
-    // ---- the arg-max group's band of rows (VsTables::band_tile), from the
-    // offsets the chunk's last sort left: valid while no group was
-    // swap-removed since (the packed indices mean what they meant)
-    if (T.band_mode && tid == 0) {
+    // ---- the arg-max group's band of rows in each of the value's chunks
+    // (VsTables::band_tile), from the offsets the chunk's last sort left:
+    // valid while no group was swap-removed since (the packed indices mean
+    // what they meant)
+    if (T.band_mode) {
         const uint32_t c0 = T.chunk_first[x], c1 = T.chunk_first[x + 1];
-        const uint32_t rows = T.val_start[x + 1] - T.val_start[x];
-        int mode = rows == 0 ? 1 : 0;
-        VsTile band = VsTile{x, 0u, 0u, 0u};
-        if (rows != 0 && c1 - c0 == 1 && removed == 0 && A.offsets.off
-            && A.offsets.epoch[c0] == epoch0 && epoch0 != 0u) {
-            const int * off = A.offsets.off + (size_t)c0 * A.offsets.stride;
-            const int k_then = off[A.offsets.stride - 1];
-            uint32_t lo = 0u, hi = 0u;   // (a group younger than the sort)
-            if (amax < k_then) {
-                lo = (uint32_t)off[amax];
-                hi = (uint32_t)off[amax + 1];
+        for (uint32_t c = c0 + tid; c < c1; c += kTablesBlock) {
+            const uint32_t pos = T.val_start[x] + (c - c0) * (uint32_t)kVsApplyRows;
+            int mode = 0;
+            VsTile band = VsTile{x, 0u, 0u, c};
+            if (removed == 0 && A.offsets.off && A.offsets.epoch[c] == epoch0
+                && epoch0 != 0u) {
+                const int * off = A.offsets.off + (size_t)c * A.offsets.stride;
+                const int k_then = off[A.offsets.stride - 1];
+                uint32_t lo = 0u, hi = 0u;   // (a group younger than the sort)
+                if (amax < k_then) {
+                    lo = (uint32_t)off[amax];
+                    hi = (uint32_t)off[amax + 1];
+                }
+                if (hi - lo <= 64u * kVsR) {
+                    mode = 1;
+                    band = VsTile{x, pos + lo, hi - lo, c};
+                }
             }
-            if (hi - lo <= 64u * kVsR) {
-                mode = 1;
-                band = VsTile{x, T.val_start[x] + lo, hi - lo, c0};
-            }
+            T.band_mode[c] = mode;
+            T.band_tile[c] = band;
         }
-        T.band_mode[x] = mode;
-        T.band_tile[x] = band;
     }
     // ---- the running sums at the chunk boundaries (see k_vs_prepare): two
     // lanes walk the copies in LDS
@@ -3216,13 +3226,15 @@ void k_vs_sample(
 #endif
     const bool band = id < n_band_ids;
     const VsTile * mine = band ? T.band_tile + id : tiles + (id - n_band_ids);
-    if (band ? id >= T.n_values : id - n_band_ids >= n_tiles) return;
+    if (band ? id >= T.band_count : id - n_band_ids >= n_tiles) return;
     const uint32_t x = __builtin_amdgcn_readfirstlane(mine->x);
     const uint32_t pos = __builtin_amdgcn_readfirstlane(mine->pos);
     const uint32_t n = __builtin_amdgcn_readfirstlane(mine->n);
     if (n == 0) return;
     const bool skip_a = band;
-    const bool skip_b = !band && n_band_ids != 0 && T.band_mode[x] != 0;
+    const bool skip_b =
+        !band && n_band_ids != 0
+        && T.band_mode[T.band_by_chunk ? mine->chunk : x] != 0;
     SlaveView v = P.feat[0];
     v.kind = KIND;
     const int K = sweep_K(P);
@@ -3274,9 +3286,10 @@ void k_vs_sample(
                 // (a band tile's rows may straddle two chunks of its value)
                 const uint32_t chunk =
                     !D.chunk_counts ? 0u
-                    : band ? T.chunk_first[x]
-                                 + (at - T.val_start[x]) / (uint32_t)kVsApplyRows
-                           : mine->chunk;
+                    : (band && !T.band_by_chunk)
+                        ? T.chunk_first[x]
+                              + (at - T.val_start[x]) / (uint32_t)kVsApplyRows
+                        : mine->chunk;
                 vs_hand_over(D, chunk, at);
                 valid[r] = false;
             } else {
