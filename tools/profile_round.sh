@@ -16,24 +16,34 @@ SQ="SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_S
 
 # one configuration: trace (+ timeline of a sub-sweep), SQ / FETCH / WRITE
 # passes; $1 = name, $2 = kernel that starts a sub-sweep, rest = bench args
+# STEPS / WARMUP: the c2 line is profiled over the very run the driver times
+# (20 + 5 sweeps: the group count creeps up through it, and with it the
+# kernels' durations); the other configurations over 3 + 2
 profile() {
   name=$1; anchor=$2; shift 2
-  rocprofv3 --kernel-trace --stats --output-format csv -d $out/t_$name -- python3 $B --steps 3 --warmup 2 "$@" > $out/bench_${name}_under_rocprof.json 2> $out/t_$name.log
+  steps=${STEPS:-3}; warm=${WARMUP:-2}
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out/t_$name -- python3 $B --steps $steps --warmup $warm "$@" > $out/bench_${name}_under_rocprof.json 2> $out/t_$name.log
   cp $(ls $out/t_$name/*/*kernel_stats.csv | head -1) $out/kernel_stats_$name.csv
   rm -rf $out/t_$name
   # (the sequence of one sub-sweep from a trace of its own: --stats perturbs)
-  rocprofv3 --kernel-trace --output-format csv -d $out/t_$name -- python3 $B --steps 3 --warmup 2 "$@" > /dev/null 2>&1
+  rocprofv3 --kernel-trace --output-format csv -d $out/t_$name -- python3 $B --steps $steps --warmup $warm "$@" > /dev/null 2>&1
   python3 tools/batch_timeline.py $out/t_$name "$anchor" > $out/timeline_$name.txt 2>/dev/null
+  # ... and every launch of the sub-sweep's kernels over the run (what drifts)
+  : > $out/series_$name.txt
+  for k in k_vs_tables k_vs_sample k_vs_narrow k_vs_stream k_vs_apply k_vs_reduce k_rows_scratch k_replay_sorted k_cs_; do
+    python3 tools/kernel_series.py $out/t_$name $k >> $out/series_$name.txt 2>/dev/null
+  done
   for pass in SQ FETCH_SIZE WRITE_SIZE; do
     ctr=$pass; [ $pass = SQ ] && ctr="$SQ"
-    rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out/p_${name}_$pass -- python3 $B --steps 3 --warmup 2 "$@" > /dev/null 2> $out/p.log
+    rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out/p_${name}_$pass -- python3 $B --steps $steps --warmup $warm "$@" > /dev/null 2> $out/p.log
     python3 tools/pmc_summary.py $out/p_${name}_$pass k_ > $out/pmc_${name}_$pass.txt 2>/dev/null
   done
   rm -rf $out/t_$name $out/t_$name.log
 }
-profile c2 k_vs_prepare
-profile c2_b65536 k_vs_prepare --batch 65536
-profile c2_zipf k_vs_prepare --values zipf
+STEPS=20 WARMUP=5 profile c2 k_vs_tables
+profile c2_b65536 k_vs_tables --batch 65536
+profile c2_zipf k_vs_tables --values zipf
+profile c2_unfused k_vs_prepare --opt fused_tables=0
 profile c2_scan k_vs_scan_prepare --opt sampling=1
 profile c3 k_rows_scratch --config gp_nich
 profile c3_scan k_rows_scratch --config gp_nich --opt sampling=1 --opt float_stats=1
@@ -44,10 +54,16 @@ python3 tools/counters.py $out/counters.json \
     "k_vs_sample<dd>=k_vs_sample<0, 1024>:1000000:100000" \
     "k_vs_narrow<dd>=k_vs_narrow<0, 8>:65536:60000" \
     "k_vs_stream<dpd>=k_vs_stream<4>:1000000:100000" \
-    "k_rows_scratch<gp_nich>=k_rows_scratch<2, true, 3>:1000000:100000" \
+    "k_rows_scratch<gp_nich>=k_rows_scratch<false, true, 3>:1000000:100000" \
+    "k_rows_scratch<gp_nich, scan>=k_rows_scratch<true, true, 3>:1000000:100000" \
+    "k_vs_scan_rows<dd>=k_vs_scan_rows<0>:1000000:100000" \
+    "k_vs_scan_rows<dpd>=k_vs_scan_rows<4>:1000000:100000" \
     -- $out/p_c2_SQ $out/p_c2_FETCH_SIZE $out/p_c2_WRITE_SIZE \
        $out/p_c2_b65536_SQ $out/p_c5_SQ $out/p_c5_FETCH_SIZE $out/p_c5_WRITE_SIZE \
-       $out/p_c3_SQ $out/p_c3_FETCH_SIZE $out/p_c3_WRITE_SIZE > $out/counters.log 2>&1
+       $out/p_c3_SQ $out/p_c3_FETCH_SIZE $out/p_c3_WRITE_SIZE \
+       $out/p_c3_scan_SQ $out/p_c3_scan_FETCH_SIZE $out/p_c3_scan_WRITE_SIZE \
+       $out/p_c2_scan_SQ $out/p_c2_scan_FETCH_SIZE $out/p_c2_scan_WRITE_SIZE \
+       $out/p_c5_scan_SQ $out/p_c5_scan_FETCH_SIZE $out/p_c5_scan_WRITE_SIZE > $out/counters.log 2>&1
 rm -rf $out/p_* $out/p.log
 # bench.py looks the counters up under profiles/ (keyed by the sources' hash)
 cp $out/counters.json profiles/${tag}_counters.json
