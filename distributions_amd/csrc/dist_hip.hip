@@ -892,6 +892,7 @@ struct Gibbs {
     std::vector<std::pair<size_t, size_t>> vs_ranges;   // [r0, r1) of each
     size_t vs_last = 0;   // where the last look-up found its range
     DeviceBuf<float> vsLA, vsLB, vsM, vsmB, vsPA, vsPB, vsOwn;
+    DeviceBuf<int> remap_log;   // the batches' swap-removals (kernels.h)
     // the removal epoch (DevState::pad) the groups' recorded offsets are
     // stamped with (VsOffsets): carried from one device-normalised run to the
     // next as long as the host did not re-pack the groups in between
@@ -2092,6 +2093,8 @@ struct Gibbs {
         A.n_empty = py.n_empty;
         A.sample_size = py.sample_size;
         A.offsets = VsOffsets{c.grp_off.p, c.off_epoch.p, c.off_stride};
+        remap_log.reserve((size_t)kRemapEpochs * kRemapEntry, 0);   // zeros
+        A.remap_log = remap_log.p;
         A.k_limit = T.Kuse;
         const size_t lds = ((size_t)T.Kpad * 4 + 2) * 4;
         int device = 0;

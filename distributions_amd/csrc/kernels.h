@@ -2598,6 +2598,17 @@ struct VsOffsets {
     uint32_t * epoch;   // [chunks]; 0 = no offsets
     int stride;
 };
+// A batch that swap-removes groups changes what packed indices mean
+// (Packed_::packed_remove, vector.hpp:47-51: the last group moves into the
+// vacated slot).  Offsets recorded under an older epoch stay usable through
+// the log of those moves: one entry per epoch -- {epoch, groups left after the
+// removals, moves, (dst, src) pairs} -- in a ring; a reader walks it backwards
+// from the current index to the index the group had when the chunk was
+// sorted.  More epochs back than the ring holds, or more moves in one batch
+// than an entry does: no band for that chunk this time.
+constexpr int kRemapEpochs = 64;
+constexpr int kRemapPairs = 4;
+constexpr int kRemapEntry = 4 + 2 * kRemapPairs;   // ints per entry
 struct TablesParams {
     SlaveView feat;              // i0 / i1: the OUT buffers
     const int32_t * i0_in;
@@ -2618,6 +2629,7 @@ struct TablesParams {
     int n_empty;                 // invariant of the chain
     long long sample_size;       // rows in the mixture (invariant)
     VsOffsets offsets;           // (off == nullptr: none recorded)
+    int * remap_log;             // [kRemapEpochs][kRemapEntry]
     // what the group count can be at most at THIS launch (the run's bound,
     // T.Kpad, sizes the buffers; a run that stays open for many sweeps would
     // otherwise have every launch walk the whole bound)
@@ -2638,6 +2650,7 @@ __global__ __launch_bounds__(kTablesBlock) void k_vs_tables(TablesParams A,
     __shared__ int r_i1[kWaves];
     __shared__ int s_sum[2][kWaves];
     __shared__ float sh_so;
+    __shared__ int s_log[kRemapEpochs * kRemapEntry];
     const int Kpad = T.Kpad;
     const uint32_t x = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -2660,6 +2673,10 @@ __global__ __launch_bounds__(kTablesBlock) void k_vs_tables(TablesParams A,
             if (is_cat(KIND)) cell[e] = v.cnt[(size_t)k * v.dim + x];
         }
     }
+    // (the log of earlier batches' moves, for the bands at the end)
+    if (T.band_mode)
+        for (int i = tid; i < kRemapEpochs * kRemapEntry; i += kTablesBlock)
+            s_log[i] = A.remap_log[i];
     const float prior_x = is_cat(KIND) ? v.prior[x] : 0.f;
     const int K0 = A.dev_in->K;
     const uint32_t global_size0 = A.dev_in->global_size;
@@ -2932,6 +2949,27 @@ __global__ __launch_bounds__(kTablesBlock) void k_vs_tables(TablesParams A,
             A.p2g[k] = gid;
             A.g2p[gid] = k;
         }
+        if (removed > 0) {
+            // this batch's moves into the log, under the epoch it begins
+            int * entry = A.remap_log
+                          + (size_t)((epoch0 + 1u) % kRemapEpochs) * kRemapEntry;
+            if (tid == 0) s_sum[1][0] = 0;
+            __syncthreads();
+            for (int k = tid; k < size; k += kTablesBlock)
+                if (src_of[k] != k) {
+                    const int j = atomicAdd(&s_sum[1][0], 1);
+                    if (j < kRemapPairs) {
+                        entry[4 + 2 * j] = k;
+                        entry[5 + 2 * j] = src_of[k];
+                    }
+                }
+            __syncthreads();
+            if (tid == 0) {
+                entry[0] = (int)(epoch0 + 1u);
+                entry[1] = size;
+                entry[2] = s_sum[1][0];
+            }
+        }
         if (tid == 0) {
             DevState st;
             st.K = K1;
@@ -2949,27 +2987,50 @@ __global__ __launch_bounds__(kTablesBlock) void k_vs_tables(TablesParams A,
         }
     }
     // ---- the arg-max group's band of rows in each of the value's chunks
-    // (VsTables::band_tile), from the offsets the chunk's last sort left:
-    // valid while no group was swap-removed since (the packed indices mean
-    // what they meant)
+    // (VsTables::band_tile), from the offsets the chunk's last sort left,
+    // under the index the group had then (the moves since: this batch's plan,
+    // then the log, newest first)
     if (T.band_mode) {
+        __syncthreads();   // (s_log)
         const uint32_t c0 = T.chunk_first[x], c1 = T.chunk_first[x + 1];
         for (uint32_t c = c0 + tid; c < c1; c += kTablesBlock) {
             const uint32_t pos = T.val_start[x] + (c - c0) * (uint32_t)kVsApplyRows;
             int mode = 0;
             VsTile band = VsTile{x, 0u, 0u, c};
-            if (removed == 0 && A.offsets.off && A.offsets.epoch[c] == epoch0
-                && epoch0 != 0u) {
-                const int * off = A.offsets.off + (size_t)c * A.offsets.stride;
-                const int k_then = off[A.offsets.stride - 1];
-                uint32_t lo = 0u, hi = 0u;   // (a group younger than the sort)
-                if (amax < k_then) {
-                    lo = (uint32_t)off[amax];
-                    hi = (uint32_t)off[amax + 1];
+            const uint32_t then = A.offsets.off ? A.offsets.epoch[c] : 0u;
+            if (then != 0u && epoch0 - then < (uint32_t)kRemapEpochs) {
+                // the arg-max group's index when the chunk was sorted; -1: it
+                // did not exist then (no rows of it here)
+                bool known = true;
+                int a = amax;
+                if (removed > 0)
+                    a = a < size ? src_of[a] : -1;   // (>= size: appended now)
+                for (uint32_t e = epoch0; known && a >= 0 && e != then; --e) {
+                    const int * entry = s_log + (e % kRemapEpochs) * kRemapEntry;
+                    if ((uint32_t)entry[0] != e || entry[2] > kRemapPairs) {
+                        known = false;
+                    } else if (a >= entry[1]) {
+                        a = -1;   // appended by that batch, or later
+                    } else {
+                        for (int j = 0; j < entry[2]; ++j)
+                            if (a == entry[4 + 2 * j]) {
+                                a = entry[5 + 2 * j];
+                                break;
+                            }
+                    }
                 }
-                if (hi - lo <= 64u * kVsR) {
-                    mode = 1;
-                    band = VsTile{x, pos + lo, hi - lo, c};
+                if (known) {
+                    const int * off = A.offsets.off + (size_t)c * A.offsets.stride;
+                    const int k_then = off[A.offsets.stride - 1];
+                    uint32_t lo = 0u, hi = 0u;
+                    if (a >= 0 && a < k_then) {
+                        lo = (uint32_t)off[a];
+                        hi = (uint32_t)off[a + 1];
+                    }
+                    if (hi - lo <= 64u * kVsR) {
+                        mode = 1;
+                        band = VsTile{x, pos + lo, hi - lo, c};
+                    }
                 }
             }
             T.band_mode[c] = mode;
