@@ -2300,8 +2300,8 @@ struct Gibbs {
         // resident at once (two 1024-thread workgroups per CU at 8 waves/SIMD;
         // a band workgroup is gone in about half the time of a regular one)
         // (fused: a band per apply CHUNK, read from the offsets the chunk's
-        // sort left -- no walk, so values of any size take part; else a band
-        // per value, found by k_vs_prepare's walk over the value's rows)
+        // sort left -- no walk; else a band per value, found by
+        // k_vs_prepare's walk over the value's rows)
         const uint32_t band_count = fused ? c.n_table_chunks : nv;
         const uint32_t per_wg = kVsSampleBlock / 64;
         const uint32_t tile_wgs = (c.n_tiles + per_wg - 1) / per_wg;
@@ -3286,7 +3286,10 @@ struct Gibbs {
         const int K0 = K();
         const size_t ne = (size_t)py.n_empty;
         size_t n_batches = kAsyncSweeps * n_first;
-        if (fused_tables_mode && (size_t)K0 + n_first * ne + 64 <= kTablesMaxK) {
+        // (only where the fused launch will run: every other path sizes its
+        // work by the run's bound -- the scan mode's prefix tables, for one)
+        if (fused_tables_mode && sampling_mode == 0
+            && (size_t)K0 + n_first * ne + 64 <= kTablesMaxK) {
             const size_t room = ((size_t)kTablesMaxK - 64 - (size_t)K0) / ne;
             const size_t sweeps =
                 std::min(room, kAsyncMaxBatches) / std::max<size_t>(n_first, 1);

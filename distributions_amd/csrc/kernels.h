@@ -2349,9 +2349,7 @@ struct VsTables {
     int Kuse;
     // band_mode / band_tile entries: one per VALUE (k_vs_prepare's walk), or --
     // band_by_chunk, k_vs_tables -- one per apply CHUNK of the values inside
-    // the tables: a value with more rows than a chunk holds (Zipf's head)
-    // then still gives the arg-max group's rows of every chunk a tile of
-    // their own
+    // the tables (used by the values whose rows fit ONE chunk)
     uint32_t band_count;
     int band_by_chunk;
 };
@@ -2998,7 +2996,13 @@ __global__ __launch_bounds__(kTablesBlock) void k_vs_tables(TablesParams A,
             int mode = 0;
             VsTile band = VsTile{x, 0u, 0u, c};
             const uint32_t then = A.offsets.off ? A.offsets.epoch[c] : 0u;
-            if (then != 0u && epoch0 - then < (uint32_t)kRemapEpochs) {
+            // (values of several chunks -- Zipf's head -- keep to their
+            // regular tiles: a band tile per chunk of theirs was measured,
+            // k_vs_sample 105 against 86 us on Zipf(1.1) values: forty more
+            // tiles of full chain length for a handful of rows each, ahead
+            // of everything else in the launch)
+            if (then != 0u && epoch0 - then < (uint32_t)kRemapEpochs
+                && c1 - c0 == 1) {
                 // the arg-max group's index when the chunk was sorted; -1: it
                 // did not exist then (no rows of it here)
                 bool known = true;
