@@ -963,7 +963,12 @@ struct Gibbs {
         count.reserve(1, 0);   // zero-filled
         LAUNCH(k_fold_tiles, n, codes_sorted.p, n, c->tiles.p, count.p);
         count.download(&c->n_tiles, 1);   // (also drains the stream)
-        if (fold_cache.size() >= 64) fold_cache.erase(fold_cache.begin());
+        // (room for every range of a pass at this batch size: a pass that
+        // evicts its own ranges would sort and host-sync on every batch)
+        const size_t keep = std::min<size_t>(
+            std::max<size_t>(64, (n_rows + n - 1) / std::max<size_t>(n, 1) + 2),
+            4096);
+        if (fold_cache.size() >= keep) fold_cache.erase(fold_cache.begin());
         fold_cache.push_back(std::move(c));
         return *fold_cache.back();
     }
@@ -3626,6 +3631,8 @@ struct Gibbs {
 
     void get_row_scores(size_t row, float * out, size_t * size_out) {
         DIST_REQUIRE(row < n_rows, "bad row");
+        DIST_REQUIRE(row < assigned_rows,
+                     "row without a group yet: init_sequential first");
         DIST_REQUIRE(!batch_open, "batch open");
         flush_assign_pos();
         upload_maps();
@@ -3643,6 +3650,8 @@ struct Gibbs {
     void score_rows(size_t r0, size_t r1, float * out_dev, size_t ld) {
         DIST_REQUIRE(r0 <= r1 && r1 <= n_rows && ld >= (size_t)K(),
                      "bad row range or leading dimension");
+        DIST_REQUIRE(r1 <= assigned_rows || r0 == r1,
+                     "rows without a group yet: init_sequential first");
         if (r0 == r1) return;
         flush_assign_pos();
         SweepParams P = params(r0, r1, 0, 0);

@@ -362,7 +362,7 @@ int dist_gibbs_batch_apply_local(dist_gibbs_t * g);
  * between dist_gibbs_batch_apply_delta_dev and dist_gibbs_batch_finish a
  * multi-rank caller takes its open batch's image, all-reduces it and hands it
  * back; dist_gibbs_sweep_sharded does so itself.  After every rank loaded
- * ITS rows: export (which zeroes the rank's own), all-reduce, import. */
+ * ITS rows: export, all-reduce, import (the import replaces the rank's own). */
 size_t dist_gibbs_float_delta_words(const dist_gibbs_t * g);
 int dist_gibbs_batch_float_delta_dev(dist_gibbs_t * g, double * delta_dev);
 int dist_gibbs_batch_apply_float_delta_dev(dist_gibbs_t * g,
@@ -435,8 +435,10 @@ int dist_gibbs_global_to_packed(const dist_gibbs_t * g, uint32_t global,
 /* MixtureIdTracker::global_size (mixture.hpp:517): ids handed out so far */
 size_t dist_gibbs_global_size(const dist_gibbs_t * g);
 /* whether THIS rank could run a sharded pass of n_batches batches of
- * batch_rows rows with the group set normalised on the device; the option
- * "sharded_device_normalise" may be set to 1 only when every rank says yes */
+ * batch_rows rows with the group set normalised on the device (a diagnostic:
+ * dist_gibbs_sweep_sharded asks every rank itself and takes the device path
+ * only when all of them can; "sharded_device_normalise", default 1, set to 0
+ * on a rank keeps all of them on the host-normalised loop) */
 int dist_gibbs_sharded_device_normalise_ok(const dist_gibbs_t * g,
                                            size_t n_batches,
                                            size_t batch_rows, int * ok_out);
