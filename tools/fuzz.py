@@ -108,6 +108,7 @@ def trial(seed, large=False):
     gpu.set_option("narrow_read_ahead", int(rng.choice([0, 4, 8])))
     gpu.set_option("stream_scratch", int(rng.choice([0, 1])))
     gpu.set_option("device_normalise", int(rng.choice([0, 1, 2])))
+    gpu.set_option("fused_tables", int(rng.choice([0, 1, 1, 1])))
     # the general-row kernels: round 2's, k_rows_scratch with the likelihoods
     # / scores as well in its scratch, without a scratch; LDS or global
     # FastLog table; workgroup size; folded leading features; staged apply
@@ -181,6 +182,7 @@ def trial_collective(seed):
     gpu.set_option("narrow_tiles", int(rng.choice([0, 1, 2])))
     gpu.set_option("narrow_read_ahead", int(rng.choice([0, 4, 8])))
     gpu.set_option("stream_scratch", int(rng.choice([0, 1])))
+    gpu.set_option("fused_tables", int(rng.choice([0, 1, 1])))
     gpu.set_option("rows_scratch", int(rng.choice([0, 3])))
     gpu.set_option("rows_fold", int(rng.choice([0, 1, 2])))
     gpu.set_option("apply_stage", int(rng.choice([0, 1])))
