@@ -904,6 +904,7 @@ struct Gibbs {
     DeviceBuf<unsigned long long> vsStamps;   // diagnostics, see VsTables
     DeviceBuf<float> vsScratch;    // k_vs_stream: [tiles][K] likelihoods
     int stream_scratch_mode = 1;   // 0: recompute them in the scan instead
+    int stream_lds_pad = 0;        // bytes of unused LDS per workgroup: caps residency
     DeviceBuf<ChainResult> chain_result;
     DeviceBuf<int32_t> delta_image;         // dist_gibbs_sweep_sharded
     DeviceBuf<float> own_score;             // k_row_prepass
@@ -1874,12 +1875,20 @@ struct Gibbs {
         // the back -- was measured: 70.9 against 69.7 us per launch on C2.
         // Consecutive tiles of one value share their scalar-cache lines.)
         std::vector<VsTile> tiles;
-        for (uint32_t x = 0; x < nv; ++x)
-            for (uint32_t off = 0; off < h[x]; off += 64 * kVsR)
-                tiles.push_back(VsTile{x, start[x] + off,
-                                       std::min<uint32_t>(64 * kVsR,
-                                                          h[x] - off)});
-        c->n_tiles = (uint32_t)tiles.size();
+        auto cut_tiles = [&](uint32_t rows) {
+            tiles.clear();
+            for (uint32_t x = 0; x < nv; ++x)
+                for (uint32_t off = 0; off < h[x]; off += rows)
+                    tiles.push_back(VsTile{x, start[x] + off,
+                                           std::min<uint32_t>(rows,
+                                                              h[x] - off)});
+            c->n_tiles = (uint32_t)tiles.size();
+        };
+        cut_tiles(64 * kVsR);
+        for (uint32_t x = 0; x < nv; ++x) c->n_values_present += h[x] != 0;
+        // (k_vs_stream deals a tile's rows to lanes of one class each: a
+        // spare lane keeps a full tile from handing a row over)
+        if (use_stream(*c)) cut_tiles(64 * kVsR - kVsR);
         std::vector<VsTile> narrow;
         if (c->n_tiles < kVsNarrowBelowTiles || narrow_mode == 2) {
             for (uint32_t x = 0; x < nv; ++x)
@@ -1888,7 +1897,6 @@ struct Gibbs {
                                             std::min<uint32_t>(64, h[x] - off)});
             c->n_narrow_tiles = (uint32_t)narrow.size();
         }
-        for (uint32_t x = 0; x < nv; ++x) c->n_values_present += h[x] != 0;
         // apply work items: up to kVsApplyRows rows of one value -- or, where
         // values have few rows each (the table-free kernel's case) and the
         // kind is categorical, of several WHOLE values (k_vs_apply_mixed)
@@ -2147,21 +2155,22 @@ struct Gibbs {
             hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, stream(),
                                self->deferred_count.p, c->n_other);
             self->mark(self->ev0);
-            // a row of K likelihoods per tile between the total's pass and
-            // the scan (up to 2 GiB of scratch; beyond that they are computed
+            // two rows of K likelihoods per tile (either class's vector)
+            // between the total's pass and the scan (up to 2 GiB of scratch; beyond that they are computed
             // again, as before)
             const size_t stride = ((size_t)self->K() + 63) & ~(size_t)63;
             float * scratch = nullptr;
             if (self->stream_scratch_mode
-                && (size_t)c->n_tiles * stride <= ((size_t)1 << 29)) {
+                && (size_t)c->n_tiles * 2 * stride <= ((size_t)1 << 29)) {
                 self->vsScratch.reserve(
-                    grow_capacity((size_t)c->n_tiles * stride), 0);
+                    grow_capacity((size_t)c->n_tiles * 2 * stride), 0);
                 scratch = self->vsScratch.p;
             }
             if (c->n_tiles)
                 hipLaunchKernelGGL((k_vs_stream<KIND>),
                                    dim3((c->n_tiles + per - 1) / per),
-                                   dim3(kVsStreamBlock), 0, stream(), *P,
+                                   dim3(kVsStreamBlock),
+                                   (size_t)self->stream_lds_pad, stream(), *P,
                                    c->tiles.p, c->n_tiles, c->sorted_rows.p,
                                    self->deferred.p, self->deferred_count.p,
                                    scratch, (uint32_t)stride);
@@ -4847,6 +4856,9 @@ int dist_gibbs_set_option(dist_gibbs_t * g, const char * name, int value) {
             g->impl->narrow_mode = value;
             // (cached ranges carry their tile lists)
             g->impl->drop_overlapping_caches(0, g->impl->n_rows, false);
+        } else if (key == "stream_lds_pad") {
+            DIST_REQUIRE(value >= 0 && value <= 65536, "stream_lds_pad: bytes");
+            g->impl->stream_lds_pad = value;
         } else if (key == "stream_scratch") {
             // k_vs_stream keeps the first pass's likelihoods for the second
             // in a scratch row per tile (1, default) or computes them again

@@ -3902,9 +3902,10 @@ __global__ __launch_bounds__(64) void k_vs_narrow(
 // at a time into the wave's strip of LDS, consumed from there by uniform
 // ds_read_b128 exactly as vs_sum_and_scan consumes its scalar loads (same
 // float operations in the same order: bit-identical to k_vs_sample).  Rows of
-// the arg-max group (shift mB instead of M) take a second round of the same
-// loop; rows the shortcut does not cover are handed over as before.
-constexpr int kVsStreamChunk = 512;
+// the arg-max group (shift mB instead of M) sit in lanes of their own and read
+// a second strip in the same loop; rows the shortcut does not cover are handed
+// over as before.
+constexpr int kVsStreamChunk = 256;
 constexpr int kVsStreamBlock = 256;
 
 __global__ void k_set_u32(uint32_t * p, uint32_t value) { *p = value; }
@@ -3951,16 +3952,22 @@ __device__ __forceinline__ float vs_stream_score(const SweepParams & P,
     return accumulate(KIND, P.base[k], load_entry(v, k, x), x, lf, v.p);
 }
 
+// (five waves to a SIMD: 96 registers hold the prefetched inputs without
+// spilling; measured 1.00 ms per C5 launch against 1.10 at six and 1.12 at
+// four -- profiles/r4_stream_occupancy.txt)
+#ifndef VS_STREAM_WAVES
+#define VS_STREAM_WAVES 5
+#endif
 template <int KIND>
 __global__ __launch_bounds__(kVsStreamBlock)
-__attribute__((amdgpu_waves_per_eu(8, 8)))
+__attribute__((amdgpu_waves_per_eu(VS_STREAM_WAVES, VS_STREAM_WAVES)))
 void k_vs_stream(
         SweepParams P, const VsTile * __restrict__ tiles, uint32_t n_tiles,
         const uint32_t * __restrict__ sorted_rows,
         uint32_t * __restrict__ deferred, uint32_t * deferred_count,
         float * __restrict__ scratch, uint32_t scratch_stride) {
     __shared__ uint32_t s_exp[1024];
-    __shared__ float s_strip[kVsStreamBlock / 64][kVsStreamChunk];
+    __shared__ float s_strip[kVsStreamBlock / 64][2][kVsStreamChunk];
     for (int i = threadIdx.x; i < 1024; i += kVsStreamBlock)
         s_exp[i] = g_tables_dev.exp_table[i];
     __syncthreads();
@@ -3968,7 +3975,8 @@ void k_vs_stream(
     const float eb = u2f(g_tables_dev.exp_ab[1]);
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    float * strip = s_strip[wave];
+    float * stripA = s_strip[wave][0];
+    float * stripB = s_strip[wave][1];
     const uint32_t id = __builtin_amdgcn_readfirstlane(
         blockIdx.x * (kVsStreamBlock / 64) + wave);
     if (id >= n_tiles) return;
@@ -3976,23 +3984,83 @@ void k_vs_stream(
     const uint32_t pos = __builtin_amdgcn_readfirstlane(tiles[id].pos);
     const uint32_t n = __builtin_amdgcn_readfirstlane(tiles[id].n);
     if (n == 0) return;
-    SlaveView v = P.feat[0];
-    v.kind = KIND;
+    const SlaveView & v = P.feat[0];   // (read in place: the argument block)
     const int K = sweep_K(P);
     const float shift = P.scalars->shift;
     const float lf = KIND == DIST_GP ? fast_log_factorial(x) : 0.f;
     // the tile's row of the scratch (null: none): the total's pass leaves
     // its likelihoods there, the scan and the replay read them back instead
     // of evaluating score and exponential a second and a third time
-    float * keep = scratch ? scratch + (size_t)id * scratch_stride : nullptr;
+    float * keep =
+        scratch ? scratch + (size_t)id * 2 * scratch_stride : nullptr;
 
+    // A wave on its own is a chain of dependent steps, and seven neighbours do
+    // not hide a memory round trip per step: every loop below has the inputs
+    // of its NEXT step in flight while it works on this one.
+    constexpr int J = kVsStreamChunk / 64;   // entries per lane and chunk
+    struct Raw { float base[J]; Entry e[J]; };
+    // (load_entry, spelled out on plain pointers: the value is the wave's,
+    // so the row of S -- or OTHER's scalar, dpd.hpp:534-542 -- is chosen once)
+    const float * const par = P.feat[0].p;   // (the launch's argument block)
+    const float * const base_p = P.base;
+    const float * const c0_p = v.c0;
+    const float * const c1_p = v.c1;
+    const float * const c2_p = v.c2;
+    const float * const c3_p = v.c3;
+    const bool is_other = KIND == DIST_DPD && x == DIST_DPD_OTHER;
+    const float other_score = v.other;
+    const float * const s_row =
+        (!is_cat(KIND) || is_other) ? v.c0 : v.S + (size_t)x * v.cap;
+    auto entry_at = [&](int k) {
+        Entry e;
+        e.c0 = c0_p[k];
+        if (is_cat(KIND)) {
+            const float t = s_row[k];
+            e.c1 = is_other ? other_score : t;
+            e.c2 = 0.f;
+            e.c3 = 0.f;
+        } else {
+            e.c1 = c1_p[k];
+            e.c2 = c2_p[k];
+            e.c3 = c3_p[k];
+        }
+        return e;
+    };
+    auto fetch = [&](Raw & r, int k0) {
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const int k = min(k0 + lane + 64 * j, K - 1);
+            r.base[j] = base_p[k];
+            r.e[j] = entry_at(k);
+        }
+    };
     // pass 0: (max, first arg-max, max of the rest) of the value's scores
     float m1 = -INFINITY, m2 = -INFINITY;
     int i1 = 0x7fffffff;
-    for (int k = lane; k < K; k += 64) {
-        const float s = vs_stream_score<KIND>(P, v, k, x, lf);
-        if (s > m1) { m2 = m1; m1 = s; i1 = k; }
-        else if (s > m2) m2 = s;
+    {
+        Raw even, odd;
+        auto fold = [&](const Raw & r, int k0) {
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                const int k = k0 + lane + 64 * j;
+                const float sc = accumulate(KIND, r.base[j], r.e[j], x, lf, par);
+                if (k < K) {
+                    if (sc > m1) { m2 = m1; m1 = sc; i1 = k; }
+                    else if (sc > m2) m2 = sc;
+                }
+            }
+        };
+        fetch(even, 0);
+        for (int k0 = 0; k0 < K; k0 += 2 * kVsStreamChunk) {
+            fetch(odd, k0 + kVsStreamChunk);
+            __builtin_amdgcn_sched_barrier(0);
+            fold(even, k0);
+            __builtin_amdgcn_sched_barrier(0);
+            fetch(even, k0 + 2 * kVsStreamChunk);
+            __builtin_amdgcn_sched_barrier(0);
+            fold(odd, k0 + kVsStreamChunk);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -4009,182 +4077,297 @@ void k_vs_stream(
     const float M = m1, M2 = m2;
     const int amax = i1;
 
-    bool valid[kVsR], classB[kVsR];
+    // Rows of the value's arg-max group (class B) want the other shift and
+    // have ONE vector between them (own slot included: the same group).  The
+    // tile's rows are dealt to the lanes anew -- the others in tile order
+    // from lane 0, the arg-max group's from the next free lane -- so that a
+    // lane holds rows of one class, and each lane reads its operands from its
+    // class's strip: both classes run the recurrences in the same loop.
+    uint32_t * order = reinterpret_cast<uint32_t *>(stripA);   // [128], before the loop
+    int slot_of[kVsR];
+    {
+        bool nat_valid[kVsR], nat_b[kVsR];
+#pragma unroll
+        for (int r = 0; r < kVsR; ++r) {
+            order[kVsR * lane + r] = 0xFFu;
+            nat_valid[r] = (uint32_t)(kVsR * lane + r) < n;
+            nat_b[r] = false;
+            if (nat_valid[r]) {
+                const uint32_t at = pos + kVsR * lane + r;
+                nat_b[r] = (int)P.g2p[P.assign_pos[at]] == amax;
+            }
+        }
+        const unsigned long long below = (1ull << lane) - 1ull;
+        const unsigned long long a0 =
+            __builtin_amdgcn_ballot_w64(nat_valid[0] && !nat_b[0]);
+        const unsigned long long a1 =
+            __builtin_amdgcn_ballot_w64(nat_valid[1] && !nat_b[1]);
+        const unsigned long long b0 =
+            __builtin_amdgcn_ballot_w64(nat_valid[0] && nat_b[0]);
+        const unsigned long long b1 =
+            __builtin_amdgcn_ballot_w64(nat_valid[1] && nat_b[1]);
+        const int n_a = __builtin_popcountll(a0) + __builtin_popcountll(a1);
+        const int b_first = (n_a + kVsR - 1) / kVsR * kVsR;
+        const int rank_a = __builtin_popcountll(a0 & below)
+                           + __builtin_popcountll(a1 & below);
+        const int rank_b = __builtin_popcountll(b0 & below)
+                           + __builtin_popcountll(b1 & below);
+        slot_of[0] = nat_b[0] ? b_first + rank_b : rank_a;
+        slot_of[1] = nat_b[1] ? b_first + rank_b + (nat_b[0] ? 1 : 0)
+                              : rank_a + ((nat_valid[0] && !nat_b[0]) ? 1 : 0);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < kVsR; ++r) {
+            if (!nat_valid[r]) continue;
+            if (slot_of[r] < kVsR * 64)
+                order[slot_of[r]] = kVsR * lane + r;
+            else   // (a full tile whose split costs a slot: one row goes on)
+                deferred[atomicAdd(deferred_count, 1u)] =
+                    pos + kVsR * lane + r;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        slot_of[0] = b_first;   // (kept: where class B begins)
+    }
+    const bool lane_b = kVsR * lane >= slot_of[0];
+    bool valid[kVsR];
+    uint32_t at_of[kVsR];
     size_t row[kVsR];
     int g[kVsR], g2[kVsR];
-    float l_own[kVsR], u[kVsR], m_row[kVsR];
+    float l_own[kVsR], u[kVsR];
+    float s_own_b = 0.f;
 #pragma unroll
     for (int r = 0; r < kVsR; ++r) {
-        valid[r] = (uint32_t)(kVsR * lane + r) < n;
+        const uint32_t idx = order[kVsR * lane + r];
+        valid[r] = idx != 0xFFu;
+        at_of[r] = pos + idx;
         row[r] = 0;
         g[r] = -1;
         g2[r] = 0;
         l_own[r] = 0.f;
         u[r] = 0.f;
-        m_row[r] = M;
-        classB[r] = false;
         if (valid[r]) {
-            const uint32_t at = pos + kVsR * lane + r;
+            const uint32_t at = at_of[r];
             row[r] = P.row_begin + sorted_rows[at];
             g[r] = P.g2p[P.assign_pos[at]];
-            classB[r] = (g[r] == amax);
             const int n_g = P.counts[g[r]];
             float s_own = 0.f;
             bool defer = (n_g == 1);
             if (!defer) {
-                s_own = vs_own_score(P, v, g[r], n_g, x, lf, shift);
-                defer = !classB[r] && s_own > M;   // table rounding lifted it
+                s_own = accumulate(KIND, cluster_own_score(P, n_g - 1, shift),
+                                   entry_after_remove(v, g[r], x, KIND), x, lf,
+                                   par);
+                defer = !lane_b && s_own > M;   // table rounding lifted it
             }
             if (defer) {
                 deferred[atomicAdd(deferred_count, 1u)] = at;
                 valid[r] = false;
             } else {
-                m_row[r] = classB[r] ? fmaxf(s_own, M2) : M;
-                l_own[r] = fast_exp_nonpos(s_own - m_row[r], s_exp, ea, eb);
+                if (lane_b) s_own_b = s_own;
+                else l_own[r] = fast_exp_nonpos(s_own - M, s_exp, ea, eb);
                 u[r] = batch_row_unif01(P, row[r]);
             }
         }
     }
+    __builtin_amdgcn_wave_barrier();   // `order` is read: the strip is free
+    // class B's shift and own-slot likelihood: one row's, the same for all
+    const unsigned long long who_b =
+        __builtin_amdgcn_ballot_w64(lane_b && (valid[0] || valid[1]));
+    const bool has_b = who_b != 0;
+    float mB = M, l_own_b = 0.f;
+    if (has_b) {
+        const int src = __builtin_ctzll(who_b);
+        const float so = u2f((uint32_t)__builtin_amdgcn_readlane(
+            (int)f2u(s_own_b), src));
+        mB = fmaxf(so, M2);
+        l_own_b = fast_exp_nonpos(so - mB, s_exp, ea, eb);
+#pragma unroll
+        for (int r = 0; r < kVsR; ++r)
+            if (lane_b && valid[r]) l_own[r] = l_own_b;
+    }
+    const float m_mine = lane_b ? mB : M;
+    const float * mine = lane_b ? stripB : stripA;
+    float * keepB = keep ? keep + scratch_stride : nullptr;
+    const float * keep_mine = lane_b ? keepB : keep;
     const int nchunks32 = (K + kVsUnroll - 1) / kVsUnroll;
-    // round 0: the rows outside the arg-max group (shift M); round 1: the
-    // rows inside it (shift mB, the same for all of them)
-    for (int round = 0; round < 2; ++round) {
-        bool active[kVsR];
-        bool any_active = false;
-        float m = M;
+    // own slots: class B's sits in its strip already
+    int gchunk[kVsR], gpiece[kVsR];
 #pragma unroll
-        for (int r = 0; r < kVsR; ++r) {
-            active[r] = valid[r] && (classB[r] == (round == 1));
-            any_active = any_active || active[r];
-            if (active[r] && round == 1) m = m_row[r];
+    for (int r = 0; r < kVsR; ++r) {
+        const bool own = valid[r] && !lane_b;
+        gchunk[r] = own ? (g[r] / kVsUnroll) : -1;
+        gpiece[r] = own ? (g[r] >> 3) : -1;
+    }
+    v2f acc = {0.f, 0.f};              // the total, then t
+    float t_start[kVsR] = {0.f, 0.f};
+    int npos[kVsR] = {0, 0};
+    const float4 * src = reinterpret_cast<const float4 *>(mine);
+    auto run_pass = [&](auto pass_tag) {
+        constexpr int pass = decltype(pass_tag)::value;
+        if (pass == 1) {
+            acc = acc * (v2f){u[0], u[1]};
+            t_start[0] = acc.x;
+            t_start[1] = acc.y;
         }
-        if (!__any(any_active)) continue;
-        if (round == 1) {   // wave-uniform: every such row has the same own score
-            const unsigned long long who =
-                __builtin_amdgcn_ballot_w64(any_active);
-            const int src = __builtin_ctzll(who);
-            m = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(m), src));
-        }
-        int gchunk[kVsR], gpiece[kVsR];
+        const bool kept = pass == 1 && keep;
+        // the chunk's inputs: the cache entries, or what the total's pass kept
+        Raw raw;
+        float ka[J], kb[J];
+        auto fetch_chunk = [&](int k0) {
+            if (!kept) return fetch(raw, k0);
 #pragma unroll
-        for (int r = 0; r < kVsR; ++r) {
-            gchunk[r] = active[r] ? (g[r] / kVsUnroll) : -1;
-            gpiece[r] = active[r] ? (g[r] >> 3) : -1;
-        }
-        v2f acc = {0.f, 0.f};              // the total, then t
-        float t_start[kVsR] = {0.f, 0.f};
-        int npos[kVsR] = {0, 0};
-        auto run_pass = [&](auto pass_tag) {
-            constexpr int pass = decltype(pass_tag)::value;
-            if (pass == 1) {
-                acc = acc * (v2f){u[0], u[1]};
-                t_start[0] = acc.x;
-                t_start[1] = acc.y;
-            }
-            bool done = false;
-            for (int k0 = 0; k0 < K && !done; k0 += kVsStreamChunk) {
-                // the chunk's likelihoods, 64 at a time, into the strip
-#pragma unroll
-                for (int j = 0; j < kVsStreamChunk / 64; ++j) {
-                    const int k = k0 + lane + 64 * j;
-                    float l = 0.f;
-                    if (pass == 1 && keep) {
-                        if (k < K) l = keep[k];
-                    } else if (k < K) {
-                        l = fast_exp_nonpos(
-                            vs_stream_score<KIND>(P, v, k, x, lf) - m, s_exp,
-                            ea, eb);
-                        if (keep) keep[k] = l;
-                    }
-                    strip[lane + 64 * j] = l;
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                const int sub_end = min(kVsStreamChunk, K - k0);
-                for (int off = 0; off < sub_end; off += kVsUnroll) {
-                    const int c = (k0 + off) / kVsUnroll;
-                    const int kk = k0 + off;
-                    float4 w[kVsUnroll / 4];
-                    const float4 * src =
-                        reinterpret_cast<const float4 *>(strip + off);
-#pragma unroll
-                    for (int q = 0; q < kVsUnroll / 4; ++q) w[q] = src[q];
-                    const bool own_here =
-                        __any(gchunk[0] == c || gchunk[1] == c);
-#pragma unroll
-                    for (int b = 0; b < kVsUnroll / 8; ++b) {
-                        const int piece = (kk >> 3) + b;
-                        if (own_here && __any(gpiece[0] == piece
-                                              || gpiece[1] == piece)) {
-                            // an own slot in these eight entries: per-lane
-                            // select (vs_sum_and_scan's form)
-                            const float l[8] = {
-                                w[2 * b].x, w[2 * b].y, w[2 * b].z, w[2 * b].w,
-                                w[2 * b + 1].x, w[2 * b + 1].y,
-                                w[2 * b + 1].z, w[2 * b + 1].w};
-                            vs_own_piece<pass == 1>(acc, l, kk + 8 * b, g,
-                                                    l_own);
-                        } else {
-                            vs_pk_chain4<pass == 1>(acc, w[2 * b]);
-                            vs_pk_chain4<pass == 1>(acc, w[2 * b + 1]);
-                        }
-                    }
-                    if (pass == 1) {
-                        const float tr[kVsR] = {acc.x, acc.y};
-                        bool more = false;
-#pragma unroll
-                        for (int r = 0; r < kVsR; ++r) {
-                            const bool p = tr[r] > 0.f;
-                            t_start[r] = p ? tr[r] : t_start[r];
-                            npos[r] += p ? 1 : 0;
-                            more = more || (active[r] && p);
-                        }
-                        if (__builtin_amdgcn_ballot_w64(more) == 0) {
-                            done = true;
-                            break;
-                        }
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();   // before the strip is refilled
+            for (int j = 0; j < J; ++j) {
+                const int k = min(k0 + lane + 64 * j, (int)scratch_stride - 1);
+                ka[j] = keep[k];
+                kb[j] = has_b ? keepB[k] : 0.f;
             }
         };
-        run_pass(std::integral_constant<int, 0>{});   // the total
-        run_pass(std::integral_constant<int, 1>{});   // the scan
-        // replay the chunk in which a row crosses zero (random.hpp:326-329);
-        // its likelihoods are recomputed -- the same operations as above
+        // sixteen entries of the lane's strip; acc (+/-)= them in order
+        auto load16 = [&](float4 (&w)[4], int off) {
 #pragma unroll
-        for (int r = 0; r < kVsR; ++r) {
-            if (!active[r]) continue;
-            int f = K - 1;
-            if (npos[r] < nchunks32) {
-                const int base_k = npos[r] * kVsUnroll;
-                float tt = t_start[r];
-                int steps = 0;
+            for (int q = 0; q < 4; ++q) w[q] = src[off / 4 + q];
+        };
+        auto chain16 = [&](const float4 (&w)[4], int kk, bool own_here) {
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int piece = (kk >> 3) + b;
+                if (own_here && __any(gpiece[0] == piece
+                                      || gpiece[1] == piece)) {
+                    // an own slot in these eight entries: per-lane select
+                    // (vs_sum_and_scan's form)
+                    const float l[8] = {
+                        w[2 * b].x, w[2 * b].y, w[2 * b].z, w[2 * b].w,
+                        w[2 * b + 1].x, w[2 * b + 1].y,
+                        w[2 * b + 1].z, w[2 * b + 1].w};
+                    vs_own_piece<pass == 1>(acc, l, kk + 8 * b, g, l_own);
+                } else {
+                    vs_pk_chain4<pass == 1>(acc, w[2 * b]);
+                    vs_pk_chain4<pass == 1>(acc, w[2 * b + 1]);
+                }
+            }
+        };
+        fetch_chunk(0);
+        bool done = false;
+        for (int k0 = 0; k0 < K && !done; k0 += kVsStreamChunk) {
+            // the chunk's likelihoods, 64 at a time, into the strips
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                const int k = k0 + lane + 64 * j;
+                float la = 0.f, lb = 0.f;
+                if (kept) {
+                    la = k < (int)scratch_stride ? ka[j] : 0.f;   // (zeros
+                    lb = k < (int)scratch_stride ? kb[j] : 0.f;   // beyond K)
+                } else {
+                    if (k < K) {
+                        const float sc = accumulate(KIND, raw.base[j],
+                                                    raw.e[j], x, lf, par);
+                        la = fast_exp_nonpos(sc - M, s_exp, ea, eb);
+                        if (has_b)
+                            lb = k == amax ? l_own_b
+                                           : fast_exp_nonpos(sc - mB, s_exp,
+                                                             ea, eb);
+                    }
+                    if (keep && k < (int)scratch_stride) {
+                        keep[k] = la;
+                        if (has_b) keepB[k] = lb;
+                    }
+                }
+                stripA[lane + 64 * j] = la;
+                if (has_b) stripB[lane + 64 * j] = lb;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (k0 + kVsStreamChunk < K) fetch_chunk(k0 + kVsStreamChunk);
+            const int sub_end = min(kVsStreamChunk, K - k0);
+            float4 w0[4], w1[4];
+            load16(w0, 0);
+            for (int off = 0; off < sub_end; off += kVsUnroll) {
+                const int c = (k0 + off) / kVsUnroll;
+                const bool own_here =
+                    __any(gchunk[0] == c || gchunk[1] == c);
+                load16(w1, off + 16);
+                __builtin_amdgcn_sched_barrier(0);
+                chain16(w0, k0 + off, own_here);
+                __builtin_amdgcn_sched_barrier(0);
+                // (the last one stays inside the strip and is not used)
+                load16(w0, off + kVsUnroll < kVsStreamChunk ? off + kVsUnroll
+                                                            : off);
+                __builtin_amdgcn_sched_barrier(0);
+                chain16(w1, k0 + off + 16, own_here);
+                __builtin_amdgcn_sched_barrier(0);
+                if (pass == 1) {
+                    const float tr[kVsR] = {acc.x, acc.y};
+                    bool more = false;
+#pragma unroll
+                    for (int r = 0; r < kVsR; ++r) {
+                        const bool p = tr[r] > 0.f;
+                        t_start[r] = p ? tr[r] : t_start[r];
+                        npos[r] += p ? 1 : 0;
+                        more = more || (valid[r] && p);
+                    }
+                    if (__builtin_amdgcn_ballot_w64(more) == 0) {
+                        done = true;
+                        break;
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();   // before the strips are refilled
+        }
+    };
+    run_pass(std::integral_constant<int, 0>{});   // the total
+    run_pass(std::integral_constant<int, 1>{});   // the scan
+    // replay the chunk in which a row crosses zero (random.hpp:326-329): its
+    // likelihoods from what the total's pass kept, or computed once more --
+    // the same operations as above
+#pragma unroll
+    for (int r = 0; r < kVsR; ++r) {
+        if (!valid[r]) continue;
+        int f = K - 1;
+        if (npos[r] < nchunks32) {
+            const int base_k = npos[r] * kVsUnroll;
+            float tt = t_start[r];
+            int steps = 0;
+            if (keep) {   // (rows of the scratch are 256-byte aligned)
+                const float4 * kept4 =
+                    reinterpret_cast<const float4 *>(keep_mine + base_k);
+                float4 l4[kVsUnroll / 4];
+#pragma unroll
+                for (int q = 0; q < kVsUnroll / 4; ++q) l4[q] = kept4[q];
+#pragma unroll
+                for (int q = 0; q < kVsUnroll / 4; ++q) {
+                    const float l[4] = {l4[q].x, l4[q].y, l4[q].z, l4[q].w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        tt -= (base_k + 4 * q + i == g[r]) ? l_own[r] : l[i];
+                        steps += (tt > 0.f) ? 1 : 0;
+                    }
+                }
+            } else {
                 for (int j = 0; j < kVsUnroll; ++j) {
                     const int k = base_k + j;
                     float l = 0.f;
                     if (k == g[r])
                         l = l_own[r];
                     else if (k < K)
-                        l = keep ? keep[k]
-                                 : fast_exp_nonpos(
-                                       vs_stream_score<KIND>(P, v, k, x, lf)
-                                           - m, s_exp, ea, eb);
+                        l = fast_exp_nonpos(
+                            accumulate(KIND, base_p[k], entry_at(k), x, lf,
+                                       par) - m_mine, s_exp, ea, eb);
                     tt -= l;
                     steps += (tt > 0.f) ? 1 : 0;
                 }
-                f = base_k + steps;
             }
-            g2[r] = f < K - 1 ? f : K - 1;
+            f = base_k + steps;
         }
+        g2[r] = f < K - 1 ? f : K - 1;
     }
 #pragma unroll
     for (int r = 0; r < kVsR; ++r) {
         if (valid[r]) {
-            const uint32_t at = pos + kVsR * lane + r;
-            P.old_packed[at] = (uint32_t)g[r];
-            P.new_packed[at] = (uint32_t)g2[r];
+            P.old_packed[at_of[r]] = (uint32_t)g[r];
+            P.new_packed[at_of[r]] = (uint32_t)g2[r];
         }
     }
 }

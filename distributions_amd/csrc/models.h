@@ -303,11 +303,14 @@ DIST_HD Entry load_entry(const SlaveView & s, int k, uint32_t value) {
 // the entry group g would have after remove_value(value): what
 // MixtureSlave::remove_value leaves in the cache (mixture.hpp:386-398;
 // dd.hpp:390-397,458-467; gp.hpp:275-282; nich.hpp:335-342; bb.hpp:267-274)
-DIST_HD Entry entry_after_remove(const SlaveView & s, int g, uint32_t value) {
+// (`kind`: the view's kind, for callers that know it at compile time and read
+// the view in place)
+DIST_HD Entry entry_after_remove(const SlaveView & s, int g, uint32_t value,
+                                 int kind) {
     Entry e = {0.f, 0.f, 0.f, 0.f};
-    if (is_cat(s.kind)) {
+    if (is_cat(kind)) {
         e.c0 = fast_log(s.alpha_sum + (float)(s.i0[g] - 1));
-        if (s.kind == DIST_DPD && value == DIST_DPD_OTHER) {
+        if (kind == DIST_DPD && value == DIST_DPD_OTHER) {
             e.c1 = s.other;
         } else {
             e.c1 = fast_log(
@@ -317,8 +320,11 @@ DIST_HD Entry entry_after_remove(const SlaveView & s, int g, uint32_t value) {
         return e;
     }
     Stats st = load_stats(s, g);
-    stats_remove(s.kind, st, value);
-    return scorer_init(s.kind, s.p, st);
+    stats_remove(kind, st, value);
+    return scorer_init(kind, s.p, st);
+}
+DIST_HD Entry entry_after_remove(const SlaveView & s, int g, uint32_t value) {
+    return entry_after_remove(s, g, value, s.kind);
 }
 
 // MixtureValueScorer::update_group for one (group, value) cell of a
