@@ -3945,6 +3945,20 @@ __device__ __forceinline__ void vs_pk_chain4(v2f & acc, const float4 & w) {
     }
 }
 
+// four entries (k0 .. k0+3) into which own slots fall: vs_own_piece's select
+template <bool SUB>
+__device__ __forceinline__ void vs_own_quad(
+        v2f & acc, const float4 & w, int k0, const int (&g)[kVsR],
+        const float (&l_own)[kVsR]) {
+    const float l[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const v2f e = {(k0 + j == g[0]) ? l_own[0] : l[j],
+                       (k0 + j == g[1]) ? l_own[1] : l[j]};
+        acc = SUB ? acc - e : acc + e;
+    }
+}
+
 template <int KIND>
 __device__ __forceinline__ float vs_stream_score(const SweepParams & P,
                                                  const SlaveView & v, int k,
@@ -4235,13 +4249,22 @@ void k_vs_stream(
                 const int piece = (kk >> 3) + b;
                 if (own_here && __any(gpiece[0] == piece
                                       || gpiece[1] == piece)) {
-                    // an own slot in these eight entries: per-lane select
-                    // (vs_sum_and_scan's form)
-                    const float l[8] = {
-                        w[2 * b].x, w[2 * b].y, w[2 * b].z, w[2 * b].w,
-                        w[2 * b + 1].x, w[2 * b + 1].y,
-                        w[2 * b + 1].z, w[2 * b + 1].w};
-                    vs_own_piece<pass == 1>(acc, l, kk + 8 * b, g, l_own);
+                    // own slots in these eight entries: the quad that holds
+                    // one by per-lane select (vs_sum_and_scan's form), the
+                    // other as it is
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const bool mine0 = gpiece[0] == piece
+                                           && ((g[0] >> 2) & 1) == h;
+                        const bool mine1 = gpiece[1] == piece
+                                           && ((g[1] >> 2) & 1) == h;
+                        if (__any(mine0 || mine1))
+                            vs_own_quad<pass == 1>(acc, w[2 * b + h],
+                                                   kk + 8 * b + 4 * h, g,
+                                                   l_own);
+                        else
+                            vs_pk_chain4<pass == 1>(acc, w[2 * b + h]);
+                    }
                 } else {
                     vs_pk_chain4<pass == 1>(acc, w[2 * b]);
                     vs_pk_chain4<pass == 1>(acc, w[2 * b + 1]);
@@ -4587,19 +4610,47 @@ __global__ __launch_bounds__(kVsApplyBlock) void k_vs_apply_mixed(
     const uint32_t n = chunks[blockIdx.x].n;
     const int dim = P.feat[0].dim;
     for (int k = threadIdx.x; k < K; k += kVsApplyBlock) delta[k] = 0;
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < n; i += kVsApplyBlock) {
-        const uint32_t go = P.old_packed[pos + i], gn = P.new_packed[pos + i];
-        assign_pos[pos + i] = p2g[gn];
-        if (go == gn) continue;
-        atomicAdd(&delta[go], -1);
-        atomicAdd(&delta[gn], 1);
-        const uint32_t x = P.values[0][P.row_begin + sorted_rows[pos + i]];
-        atomicAdd(&img.cnt[0][(size_t)go * dim + x], -1);
-        atomicAdd(&img.cnt[0][(size_t)gn * dim + x], 1);
+    // a thread's rows side by side: every step below is a round trip to a
+    // matrix far larger than the caches, and the steps of one row depend on
+    // each other -- the rows' do not
+    constexpr int R = kVsApplyRows / kVsApplyBlock;
+    uint32_t go[R], gn[R], x[R];
+    bool moved[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const uint32_t i = threadIdx.x + r * kVsApplyBlock;
+        moved[r] = false;
+        go[r] = gn[r] = x[r] = 0;
+        if (i < n) {
+            go[r] = P.old_packed[pos + i];
+            gn[r] = P.new_packed[pos + i];
+            x[r] = sorted_rows[pos + i];
+            moved[r] = go[r] != gn[r];
+        }
     }
-    __threadfence();     // the cell updates are complete before the refresh
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        if (moved[r]) x[r] = P.values[0][P.row_begin + x[r]];
     __syncthreads();
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const uint32_t i = threadIdx.x + r * kVsApplyBlock;
+        if (i < n) assign_pos[pos + i] = p2g[gn[r]];
+        if (!moved[r]) continue;
+        atomicAdd(&delta[go[r]], -1);
+        atomicAdd(&delta[gn[r]], 1);
+        // (workgroup scope: no other workgroup touches these cells in this
+        // launch, and an agent-scope atomic is performed at the memory side
+        // of the eight XCDs' L2s -- measured 208 us per launch against ...)
+        __hip_atomic_fetch_add(&img.cnt[0][(size_t)go[r] * dim + x[r]], -1,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(&img.cnt[0][(size_t)gn[r] * dim + x[r]], 1,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    // the cell updates are complete before the refresh
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     for (int k = threadIdx.x; k < K; k += kVsApplyBlock) {
         const int dlt = delta[k];
         if (stage) {
@@ -4613,19 +4664,26 @@ __global__ __launch_bounds__(kVsApplyBlock) void k_vs_apply_mixed(
     // dd.hpp:458-467 for every touched cell, from the counts as they now stand
     // (a cell moved by several rows is rewritten by each of them, alike)
     const SlaveView & s = P.feat[0];
-    for (uint32_t i = threadIdx.x; i < n; i += kVsApplyBlock) {
-        const uint32_t go = P.old_packed[pos + i], gn = P.new_packed[pos + i];
-        if (go == gn) continue;
-        const uint32_t x = P.values[0][P.row_begin + sorted_rows[pos + i]];
-        const float prior = s.prior[x];
-        const int c_old = __hip_atomic_load(
-            &img.cnt[0][(size_t)go * dim + x], __ATOMIC_RELAXED,
-            __HIP_MEMORY_SCOPE_AGENT);
-        const int c_new = __hip_atomic_load(
-            &img.cnt[0][(size_t)gn * dim + x], __ATOMIC_RELAXED,
-            __HIP_MEMORY_SCOPE_AGENT);
-        s.S[(size_t)x * s.cap + go] = fast_log(prior + (float)c_old);
-        s.S[(size_t)x * s.cap + gn] = fast_log(prior + (float)c_new);
+    int c_old[R], c_new[R];
+    float prior[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        c_old[r] = c_new[r] = 0;
+        prior[r] = 0.f;
+        if (!moved[r]) continue;
+        prior[r] = s.prior[x[r]];
+        c_old[r] = __hip_atomic_load(
+            &img.cnt[0][(size_t)go[r] * dim + x[r]], __ATOMIC_RELAXED,
+            __HIP_MEMORY_SCOPE_WORKGROUP);
+        c_new[r] = __hip_atomic_load(
+            &img.cnt[0][(size_t)gn[r] * dim + x[r]], __ATOMIC_RELAXED,
+            __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        if (!moved[r]) continue;
+        s.S[(size_t)x[r] * s.cap + go[r]] = fast_log(prior[r] + (float)c_old[r]);
+        s.S[(size_t)x[r] * s.cap + gn[r]] = fast_log(prior[r] + (float)c_new[r]);
     }
 }
 
