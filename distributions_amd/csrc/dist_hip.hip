@@ -904,7 +904,6 @@ struct Gibbs {
     DeviceBuf<unsigned long long> vsStamps;   // diagnostics, see VsTables
     DeviceBuf<float> vsScratch;    // k_vs_stream: [tiles][K] likelihoods
     int stream_scratch_mode = 1;   // 0: recompute them in the scan instead
-    int stream_lds_pad = 0;        // bytes of unused LDS per workgroup: caps residency
     DeviceBuf<ChainResult> chain_result;
     DeviceBuf<int32_t> delta_image;         // dist_gibbs_sweep_sharded
     DeviceBuf<float> own_score;             // k_row_prepass
@@ -2169,8 +2168,7 @@ struct Gibbs {
             if (c->n_tiles)
                 hipLaunchKernelGGL((k_vs_stream<KIND>),
                                    dim3((c->n_tiles + per - 1) / per),
-                                   dim3(kVsStreamBlock),
-                                   (size_t)self->stream_lds_pad, stream(), *P,
+                                   dim3(kVsStreamBlock), 0, stream(), *P,
                                    c->tiles.p, c->n_tiles, c->sorted_rows.p,
                                    self->deferred.p, self->deferred_count.p,
                                    scratch, (uint32_t)stride);
@@ -4856,9 +4854,6 @@ int dist_gibbs_set_option(dist_gibbs_t * g, const char * name, int value) {
             g->impl->narrow_mode = value;
             // (cached ranges carry their tile lists)
             g->impl->drop_overlapping_caches(0, g->impl->n_rows, false);
-        } else if (key == "stream_lds_pad") {
-            DIST_REQUIRE(value >= 0 && value <= 65536, "stream_lds_pad: bytes");
-            g->impl->stream_lds_pad = value;
         } else if (key == "stream_scratch") {
             // k_vs_stream keeps the first pass's likelihoods for the second
             // in a scratch row per tile (1, default) or computes them again

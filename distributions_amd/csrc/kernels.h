@@ -3967,14 +3967,11 @@ __device__ __forceinline__ float vs_stream_score(const SweepParams & P,
 }
 
 // (five waves to a SIMD: 96 registers hold the prefetched inputs without
-// spilling; measured 1.00 ms per C5 launch against 1.10 at six and 1.12 at
-// four -- profiles/r4_stream_occupancy.txt)
-#ifndef VS_STREAM_WAVES
-#define VS_STREAM_WAVES 5
-#endif
+// spilling; measured 1.00 ms per C5 launch against 1.10 at six, 1.12 at four
+// and 1.97 at eight -- profiles/r4_experiments.txt)
 template <int KIND>
 __global__ __launch_bounds__(kVsStreamBlock)
-__attribute__((amdgpu_waves_per_eu(VS_STREAM_WAVES, VS_STREAM_WAVES)))
+__attribute__((amdgpu_waves_per_eu(5, 5)))
 void k_vs_stream(
         SweepParams P, const VsTile * __restrict__ tiles, uint32_t n_tiles,
         const uint32_t * __restrict__ sorted_rows,
