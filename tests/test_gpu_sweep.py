@@ -99,6 +99,25 @@ def test_batch_sweeps_bit_exact(config, batch, mode):
     assert counts["narrow_batches"] == (vs if mode in (4, 5) else 0)
 
 
+@pytest.mark.parametrize("config,dim", [("dd", 4), ("dpd", 6), ("bb", None)])
+def test_stream_kernel_on_full_tiles(config, dim):
+    """k_vs_stream deals a tile's rows to lanes of one class each, which can
+    cost a full tile one slot: the host cuts tiles of 126 rows for it, but a
+    range sorted while the tables were in use keeps its tiles of 128 -- the
+    row without a lane is handed over.  Few values, so every tile is full."""
+    n, k = 4096, 12
+    orc, gpu = both(config, n, k, 1.0, 0.2, dim=dim, mode=2)
+    st = ol.oracle().orc_rng_seed(99)
+    for sweep in range(4):
+        if sweep == 1:
+            gpu.set_option("value_stream", 2)   # (the range is sorted already)
+        base = sweep * n
+        orc.gibbs_batch(0, n, st, base)
+        gpu.sweep(0, n, n, 99, draw_base=base)
+        assert_same_state(orc, gpu, "%s sweep %d" % (config, sweep))
+    assert gpu.core.debug_counts()["stream_batches"] == 3
+
+
 @pytest.mark.parametrize("config", CONFIGS + ["nich2"])
 @pytest.mark.parametrize("scratch,lds_log,block,fold",
                          [(0, 1, 512, 0), (3, 0, 256, 2), (3, 1, 1024, 0),
