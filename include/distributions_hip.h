@@ -454,7 +454,8 @@ int dist_gibbs_sharded_device_normalise_ok(const dist_gibbs_t * g,
  * the vectors fit); "narrow_read_ahead" = 0 (by launch size), 4 or 8 (that
  * kernel's instance);
  * "stream_scratch" = 1 (default: the table-free kernel keeps a tile's
- * likelihoods between its two passes in a scratch row) or 0;
+ * likelihoods -- one vector for the rows of the value's arg-max group, one
+ * for the others -- between its two passes in two scratch rows) or 0;
  * "kernel_timing" = n: HIP events around the score+sample kernel of every
  * n-th batch feed dist_gibbs_kernel_stats (1, the default: every batch; 0:
  * none; two events cost a batch some 8 us);
