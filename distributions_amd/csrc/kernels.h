@@ -3627,8 +3627,8 @@ __global__ __launch_bounds__(kBlock) void k_vs_scan_rows(
 // the waves; a plain dependent v_add_f32 comes back after 8.5 cycles); the
 // tile's vector(s) copied into LDS once, by coalesced loads issued before the
 // rows' gathers, and read from there a chunk AHEAD of its use into registers
-// (a wave alone has hundreds); rows of the arg-max group take their entries
-// from the second vector by a per-lane select in the same pass.  The float
+// (a wave alone has hundreds); rows of the arg-max group read the second
+// vector, through the lane's own base address, in the same pass.  The float
 // operations per row and their order are k_vs_sample's: bit-identical.
 constexpr int kVsNarrowMaxK = 4096;   // two vectors of Kpad + 64 floats in LDS
 // (Handing a tile's few rows of the arg-max group to the wave-per-row kernel
@@ -3637,19 +3637,17 @@ constexpr int kVsNarrowMaxK = 4096;   // two vectors of Kpad + 64 floats in LDS
 // costs the wave-per-row kernel what a tile costs here.)
 
 // 4 * HQ entries (a chunk, or half of one) of the recurrences, one row per lane
-template <bool DUAL, bool SCAN, int HQ>
+template <bool SCAN, int HQ>
 __device__ __forceinline__ void vs_narrow_part(
-        float & acc, const float4 (&a)[HQ], const float4 (&b)[HQ],
-        bool is_b, bool own, int k0, int g, float l_own) {
+        float & acc, const float4 (&a)[HQ], bool own, int k0, int g,
+        float l_own) {
     if (own) {   // (wave-uniform) a lane's own slot falls into this chunk
 #pragma unroll
         for (int q = 0; q < HQ; ++q) {
             const float ea[4] = {a[q].x, a[q].y, a[q].z, a[q].w};
-            const float eb[4] = {b[q].x, b[q].y, b[q].z, b[q].w};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                float e = (DUAL && is_b) ? eb[i] : ea[i];
-                e = (k0 + 4 * q + i == g) ? l_own : e;
+                const float e = (k0 + 4 * q + i == g) ? l_own : ea[i];
                 acc = SCAN ? acc - e : acc + e;
             }
         }
@@ -3657,22 +3655,22 @@ __device__ __forceinline__ void vs_narrow_part(
 #pragma unroll
         for (int q = 0; q < HQ; ++q) {
             const float ea[4] = {a[q].x, a[q].y, a[q].z, a[q].w};
-            const float eb[4] = {b[q].x, b[q].y, b[q].z, b[q].w};
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float e = (DUAL && is_b) ? eb[i] : ea[i];
-                acc = SCAN ? acc - e : acc + e;
-            }
+            for (int i = 0; i < 4; ++i) acc = SCAN ? acc - ea[i] : acc + ea[i];
         }
     }
 }
 
 // the two recurrences of vs_sum_and_scan for one row per lane; va / vb: the
-// vectors in LDS (vb only read when DUAL), slack behind each.  The vector is
-// read one part ahead of the part in use: a whole chunk (HQ = 8: 32 registers
-// per vector and buffer, two such waves per SIMD -- a wave alone needs that
-// distance to hide the read) or half of one (HQ = 4: four waves per SIMD).
-template <bool DUAL, int HQ>
+// vectors in LDS, slack behind each.  A lane holds ONE row, so it reads the
+// vector of its row's class through its own base address (the rows of the
+// arg-max group vb, the others va): one LDS read serves both classes and no
+// entry is selected per lane -- a tile that holds both costs what any tile
+// costs (it used to read both vectors and select: 45 k against 32 k cycles,
+// and such tiles ended the launch).  The vector is read one part ahead of the
+// part in use: a whole chunk (HQ = 8: 32 registers per buffer -- a wave alone
+// needs that distance to hide the read) or half of one (HQ = 4).
+template <int HQ>
 __device__ __forceinline__ int vs_narrow_row(
         const float * va, const float * vb, bool is_b, int K, int g,
         float l_own, float u, bool active) {
@@ -3680,29 +3678,25 @@ __device__ __forceinline__ int vs_narrow_row(
     const int nchunks = (K + kVsUnroll - 1) / kVsUnroll;
     const int nsteps = nchunks * parts;
     const int gchunk = active ? g / kVsUnroll : -1;
-    const float4 * a4 = reinterpret_cast<const float4 *>(va);
-    const float4 * b4 = reinterpret_cast<const float4 *>(vb);
-    float4 a0[HQ], a1[HQ], b0[HQ], b1[HQ];
-    auto fetch = [&](int s, float4 (&a)[HQ], float4 (&b)[HQ]) {
+    const float * mine = is_b ? vb : va;
+    const float4 * m4 = reinterpret_cast<const float4 *>(mine);
+    float4 a0[HQ], a1[HQ];
+    auto fetch = [&](int s, float4 (&a)[HQ]) {
 #pragma unroll
-        for (int q = 0; q < HQ; ++q) {
-            a[q] = a4[s * HQ + q];
-            b[q] = DUAL ? b4[s * HQ + q] : a[q];
-        }
+        for (int q = 0; q < HQ; ++q) a[q] = m4[s * HQ + q];
     };
     // total = ((l_0 + l_1) + l_2) + ...                  random.cc:100-103
     float acc = 0.f;
-    fetch(0, a0, b0);
+    fetch(0, a0);
     for (int s = 0; s < nsteps; s += 2) {
-        fetch(s + 1, a1, b1);
-        vs_narrow_part<DUAL, false, HQ>(acc, a0, b0, is_b,
-                                        __any(gchunk == s / parts),
-                                        s * 4 * HQ, g, l_own);
-        fetch(s + 2, a0, b0);
+        fetch(s + 1, a1);
+        vs_narrow_part<false, HQ>(acc, a0, __any(gchunk == s / parts),
+                                  s * 4 * HQ, g, l_own);
+        fetch(s + 2, a0);
         if (s + 1 < nsteps)
-            vs_narrow_part<DUAL, false, HQ>(acc, a1, b1, is_b,
-                                            __any(gchunk == (s + 1) / parts),
-                                            (s + 1) * 4 * HQ, g, l_own);
+            vs_narrow_part<false, HQ>(acc, a1,
+                                      __any(gchunk == (s + 1) / parts),
+                                      (s + 1) * 4 * HQ, g, l_own);
     }
     // t = total*u; t -= l_k until t <= 0                 random.hpp:323-330
     float t = acc * u;
@@ -3714,26 +3708,24 @@ __device__ __forceinline__ int vs_narrow_row(
         npos += pos ? 1 : 0;
         return __builtin_amdgcn_ballot_w64(active && pos) != 0;
     };
-    fetch(0, a0, b0);
+    fetch(0, a0);
     for (int s = 0; s < nsteps; s += 2) {
-        fetch(s + 1, a1, b1);
-        vs_narrow_part<DUAL, true, HQ>(t, a0, b0, is_b,
-                                       __any(gchunk == s / parts), s * 4 * HQ,
-                                       g, l_own);
+        fetch(s + 1, a1);
+        vs_narrow_part<true, HQ>(t, a0, __any(gchunk == s / parts),
+                                 s * 4 * HQ, g, l_own);
         if (parts == 1 && !book()) break;
-        fetch(s + 2, a0, b0);
+        fetch(s + 2, a0);
         if (s + 1 < nsteps) {
-            vs_narrow_part<DUAL, true, HQ>(t, a1, b1, is_b,
-                                           __any(gchunk == (s + 1) / parts),
-                                           (s + 1) * 4 * HQ, g, l_own);
+            vs_narrow_part<true, HQ>(t, a1, __any(gchunk == (s + 1) / parts),
+                                     (s + 1) * 4 * HQ, g, l_own);
             if (!book()) break;
         }
     }
     int f = K - 1;
     if (active && npos < nchunks) {
         // replay the crossing chunk (as vs_sum_and_scan does)
-        const float4 * chunk = reinterpret_cast<const float4 *>(
-            ((DUAL && is_b) ? vb : va) + npos * kVsUnroll);
+        const float4 * chunk =
+            reinterpret_cast<const float4 *>(mine + npos * kVsUnroll);
         const int own = g - npos * kVsUnroll;   // in 0..31 or not
         float tt = t_start;
         int steps = 0;
@@ -3862,12 +3854,9 @@ __global__ __launch_bounds__(64) void k_vs_narrow(
 #endif
     const float * fa = reinterpret_cast<const float *>(sa);
     const float * fb = reinterpret_cast<const float *>(sb);
-    int g2;
-    if (any_a && any_b)
-        g2 = vs_narrow_row<true, HQ>(fa, fb, is_b, K, g, l_own, u, valid);
-    else
-        g2 = vs_narrow_row<false, HQ>(any_b ? fb : fa, fb, false, K, g, l_own,
-                                      u, valid);
+    // (lanes without a row read va: is_b is false there)
+    const int g2 = vs_narrow_row<HQ>(fa, fb, is_b && valid, K, g, l_own, u,
+                                     valid);
 #ifdef DIST_VS_STAMPS
     if (T.stamps) st3 = __builtin_amdgcn_s_memtime();
 #endif
