@@ -987,11 +987,17 @@ struct Gibbs {
     int narrow_mode = 1;
     int narrow_read_ahead = 0;   // float4s per vector: 0 auto, 4 or 8
     uint64_t narrow_batches = 0;
-    static constexpr uint32_t kVsNarrowBelowTiles = 4100;   // (measured)
+    // (measured, round 4, K = 1024, rows per launch: 400 k 49.5 us against
+    // k_vs_sample's 51.3, 524 k 61.2 / 68.5, 655 k 66.7 / 69.0, 786 k 77.1 /
+    // 68.9, 10^6 93.8 / 67.6; Zipf values 524 k 63.4 / 101.9, 786 k 77.7 /
+    // 92.1, 10^6 97.5 / 88.2.  At larger K the vectors leave fewer waves a
+    // place in LDS: round 2's bound stays there.)
+    static constexpr uint32_t kVsNarrowBelowTiles = 5600;
     bool use_narrow(const VsCache & c, int Kpad) const {
         if (narrow_mode == 0 || Kpad > kVsNarrowMaxK || !c.n_narrow_tiles)
             return false;
-        return narrow_mode == 2 || c.n_tiles < kVsNarrowBelowTiles;
+        return narrow_mode == 2
+               || c.n_tiles < (Kpad <= 1152 ? kVsNarrowBelowTiles : 4100u);
     }
     int running_sums_min_tiles = 2048;   // see sample_value_sorted
     int cu_count_cached = 0;
