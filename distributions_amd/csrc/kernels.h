@@ -539,10 +539,6 @@ __global__ void k_py_move_groups(int32_t * counts, float * shifted,
     counts[moves[i].x] = counts[moves[i].y];
     shifted[moves[i].x] = shifted[moves[i].y];
 }
-__global__ void k_py_zero_range(int32_t * counts, int k0, int k1) {
-    const int k = k0 + blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < k1) counts[k] = 0;
-}
 
 // MixtureSlave::score_value (accumulates) and score_value_group
 __global__ void k_slave_score_value(SlaveView s, uint32_t value,
@@ -597,11 +593,6 @@ __device__ __forceinline__ double score_data_cell(const SlaveView & s,
         for (int j = 0; j < nt; ++j) acc += (double)t[j];
     }
     return acc;
-}
-
-__global__ void k_score_data(SlaveView s, double * out) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    block_sum_to(score_data_cell(s, i), out);
 }
 
 // score_data_grid (mixture.hpp:238-247, dd.hpp:259-284): blockIdx.y = the
@@ -3265,11 +3256,16 @@ __device__ __forceinline__ void vs_sum_and_scan(
     }
 }
 
-// BLOCK = kVsSampleBlock for launches that fill the chip (16 tiles per
+// BLOCK = kVsSampleBlock for launches that fill the chip (8 tiles per
 // workgroup, mostly of one value: they share their scalar-cache lines); 64
 // for small ones -- a 65 536-row batch is 512 tiles, which 1024-thread
 // workgroups would pile onto 32 of the 256 CUs, four waves to a SIMD.
-constexpr int kVsSampleBlock = 1024;
+// (512: eight tiles per workgroup.  Measured round 4 against 1024, one box:
+// DD-256 9.18 against 9.05 G row-updates/s, Zipf values 7.62 / 7.37, GP 2.71 /
+// 2.67, K = 512 12.2 / 11.8, 786 k rows per launch 7.21 / 7.08; BB 9.09 /
+// 9.22 and DD-16 8.36 / 8.43 -- few values, whose tiles share more of the
+// scalar cache in the larger workgroup.  128: DD-16 8.18, BB 8.65.)
+constexpr int kVsSampleBlock = 512;
 template <int KIND, int BLOCK>
 __global__ __launch_bounds__(BLOCK)
 __attribute__((amdgpu_waves_per_eu(8, 8)))

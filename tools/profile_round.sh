@@ -51,7 +51,7 @@ profile mixed k_rows_scratch --config mixed
 profile c5 k_vs_stream --config dpd --groups 8192 --dim 10000
 profile c5_scan k_vs_scan_prepare --config dpd --groups 8192 --dim 10000 --opt sampling=1
 python3 tools/counters.py $out/counters.json \
-    "k_vs_sample<dd>=k_vs_sample<0, 1024>:1000000:100000" \
+    "k_vs_sample<dd>=k_vs_sample<0, 512>:1000000:100000" \
     "k_vs_narrow<dd>=k_vs_narrow<0, 8>:65536:60000" \
     "k_vs_stream<dpd>=k_vs_stream<4>:1000000:100000" \
     "k_rows_scratch<gp_nich>=k_rows_scratch<false, true, 3>:1000000:100000" \
