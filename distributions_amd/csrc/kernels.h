@@ -492,6 +492,15 @@ __global__ __launch_bounds__(kNormaliseBlock) void k_normalise(
         P.dev->first_new_global = P.dev->global_size;
         P.dev->global_size += (uint32_t)n_created;
         P.dev->nonempty = size + n_created - P.n_empty;
+        // packed indices mean something else now: the removal epoch moves on
+        // (VsOffsets).  No entry goes into k_vs_tables' log of moves for it,
+        // so offsets recorded before this launch are not translated across
+        // it -- the chunks they belong to go without a band until their next
+        // sort.  (Without this a fused batch whose group set was closed HERE,
+        // on the host's demand, left the next run trusting offsets under
+        // indices that no longer held: rows in neither tile nor band, moves
+        // applied twice -- tools/fuzz.py seed 501609.)
+        if (removed > 0) P.dev->pad += 1;
     }
 }
 

@@ -18,3 +18,13 @@ def test_differential_fuzz(first):
     failures = [err for err in (fuzz.trial(seed)
                                 for seed in range(first, first + 40)) if err]
     assert not failures, failures
+
+
+@pytest.mark.parametrize("seed", [501609])
+def test_fuzz_seeds_that_once_failed(seed):
+    """501609: a fused batch whose group set was closed by k_normalise (the
+    host asked for the state) with groups vanishing; the next run trusted the
+    offsets k_vs_apply had recorded under the old packed indices -- rows in
+    neither tile nor band, moves applied twice, negative group sizes."""
+    import fuzz
+    assert fuzz.trial(seed) is None
