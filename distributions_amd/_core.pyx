@@ -123,6 +123,10 @@ cdef extern from "distributions_hip.h" nogil:
     int dist_group_score_value(const dist_shared_t *, const uint32_t *,
                                uint32_t, float *)
     int dist_group_score_data(const dist_shared_t *, const uint32_t *, float *)
+    size_t dist_scorer_words(const dist_shared_t *)
+    int dist_scorer_init(const dist_shared_t *, const uint32_t *, float *)
+    int dist_scorer_eval(const dist_shared_t *, const float *, uint32_t,
+                         float *)
     int dist_group_protobuf_dump(const dist_shared_t *, const uint32_t *,
                                  const uint32_t *, uint8_t *, size_t, size_t *)
     int dist_group_protobuf_load(const dist_shared_t *, const uint32_t *,
@@ -342,6 +346,21 @@ cdef class SharedParams:
     def group_score_data(self, cnp.ndarray[cnp.uint32_t, ndim=1] g):
         cdef float out = 0
         check(dist_group_score_data(&self.c, <const uint32_t *> g.data, &out))
+        return out
+
+    # Model::Scorer (dd.hpp:222-245 and the other models'): init -> state
+    def scorer_init(self, cnp.ndarray[cnp.uint32_t, ndim=1] g):
+        cdef cnp.ndarray[cnp.float32_t, ndim=1] state = np.zeros(
+            dist_scorer_words(&self.c), np.float32)
+        check(dist_scorer_init(&self.c, <const uint32_t *> g.data,
+                               <float *> state.data))
+        return state
+
+    def scorer_eval(self, cnp.ndarray[cnp.float32_t, ndim=1] state,
+                    uint32_t value):
+        cdef float out = 0
+        check(dist_scorer_eval(&self.c, <const float *> state.data, value,
+                               &out))
         return out
 
     # protobuf wire bytes (schema.proto messages) without libprotobuf
