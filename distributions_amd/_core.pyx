@@ -123,6 +123,27 @@ cdef extern from "distributions_hip.h" nogil:
     int dist_group_score_value(const dist_shared_t *, const uint32_t *,
                                uint32_t, float *)
     int dist_group_score_data(const dist_shared_t *, const uint32_t *, float *)
+    ctypedef struct dist_dpd_shared_t:
+        pass
+    dist_dpd_shared_t * dist_dpd_shared_create()
+    void dist_dpd_shared_destroy(dist_dpd_shared_t *)
+    int dist_dpd_shared_load(dist_dpd_shared_t *, float, float,
+                             const uint32_t *, const float *, const int *,
+                             size_t)
+    int dist_dpd_shared_add_value(dist_dpd_shared_t *, uint32_t, uint32_t *)
+    int dist_dpd_shared_remove_value(dist_dpd_shared_t *, uint32_t)
+    int dist_dpd_shared_realize(dist_dpd_shared_t *, uint32_t *)
+    size_t dist_dpd_shared_slots(const dist_dpd_shared_t *)
+    size_t dist_dpd_shared_size(const dist_dpd_shared_t *)
+    uint64_t dist_dpd_shared_version(const dist_dpd_shared_t *)
+    int dist_dpd_shared_params(const dist_dpd_shared_t *, float *, float *,
+                               float *)
+    int dist_dpd_shared_view(const dist_dpd_shared_t *, dist_shared_t *)
+    int dist_dpd_shared_slot(const dist_dpd_shared_t *, uint32_t, uint32_t *)
+    int dist_dpd_shared_dump(const dist_dpd_shared_t *, uint32_t *, float *,
+                             int *)
+    int dist_sample_gamma(uint32_t *, float, float, float *)
+    int dist_sample_beta_safe(uint32_t *, float, float, float, float *)
     size_t dist_scorer_words(const dist_shared_t *)
     int dist_scorer_init(const dist_shared_t *, const uint32_t *, float *)
     int dist_scorer_eval(const dist_shared_t *, const float *, uint32_t,
@@ -412,6 +433,102 @@ cdef class SharedParams:
 
 # ---------------------------------------------------------------------------
 # entropy and sampling
+
+cdef class DpdShared:
+    """DirichletProcessDiscrete::Shared's stick-breaking state
+    (dist_dpd_shared_t; dpd.hpp:59-124)"""
+    cdef dist_dpd_shared_t * h
+
+    def __cinit__(self):
+        self.h = dist_dpd_shared_create()
+        if self.h == NULL:
+            raise MemoryError()
+
+    def __dealloc__(self):
+        if self.h != NULL:
+            dist_dpd_shared_destroy(self.h)
+            self.h = NULL
+
+    def load(self, float gamma, float alpha, values, betas, counts):
+        cdef cnp.ndarray[cnp.uint32_t, ndim=1] v = np.ascontiguousarray(
+            values, dtype=np.uint32)
+        cdef cnp.ndarray[cnp.float32_t, ndim=1] b = np.ascontiguousarray(
+            betas, dtype=np.float32)
+        cdef cnp.ndarray[cnp.int32_t, ndim=1] c = np.ascontiguousarray(
+            counts, dtype=np.int32)
+        if not (v.shape[0] == b.shape[0] == c.shape[0]):
+            raise RuntimeError("invalid message")
+        check(dist_dpd_shared_load(self.h, gamma, alpha,
+                                   <const uint32_t *> v.data,
+                                   <const float *> b.data,
+                                   <const int *> c.data, v.shape[0]))
+
+    def add_value(self, uint32_t value, uint32_t rng_state):
+        check(dist_dpd_shared_add_value(self.h, value, &rng_state))
+        return rng_state
+
+    def remove_value(self, uint32_t value):
+        check(dist_dpd_shared_remove_value(self.h, value))
+
+    def realize(self, uint32_t rng_state):
+        check(dist_dpd_shared_realize(self.h, &rng_state))
+        return rng_state
+
+    def slot(self, uint32_t value):
+        cdef uint32_t out = 0
+        check(dist_dpd_shared_slot(self.h, value, &out))
+        return out
+
+    def __len__(self):
+        return dist_dpd_shared_size(self.h)
+
+    property slots:
+        def __get__(self):
+            return dist_dpd_shared_slots(self.h)
+
+    property version:
+        def __get__(self):
+            return dist_dpd_shared_version(self.h)
+
+    def scalars(self):
+        """(gamma, alpha, beta0)"""
+        cdef float g = 0, a = 0, b = 0
+        check(dist_dpd_shared_params(self.h, &g, &a, &b))
+        return g, a, b
+
+    def dump(self):
+        """by dense slot: values (0xFFFFFFFF = free), betas, counts"""
+        cdef size_t n = dist_dpd_shared_slots(self.h)
+        cdef cnp.ndarray[cnp.uint32_t, ndim=1] v = np.zeros(n, np.uint32)
+        cdef cnp.ndarray[cnp.float32_t, ndim=1] b = np.zeros(n, np.float32)
+        cdef cnp.ndarray[cnp.int32_t, ndim=1] c = np.zeros(n, np.int32)
+        check(dist_dpd_shared_dump(self.h, <uint32_t *> v.data,
+                                   <float *> b.data, <int *> c.data))
+        return v, b, c
+
+    def params(self):
+        """the SharedParams (dist_shared_t) mixtures and groups take: a
+        snapshot (betas copied) of the dense view"""
+        cdef dist_shared_t view
+        check(dist_dpd_shared_view(self.h, &view))
+        v, b, c = self.dump()
+        return SharedParams.make(DIST_DPD, p=(view.p[0], view.p[1]), betas=b)
+
+
+def sample_gamma(uint32_t rng_state, float alpha, float beta=1.0):
+    """random.hpp:87-97 -> (draw, engine state after)"""
+    cdef float out = 0
+    check(dist_sample_gamma(&rng_state, alpha, beta, &out))
+    return out, rng_state
+
+
+def sample_beta_safe(uint32_t rng_state, float alpha, float beta,
+                     float min_value):
+    """random.hpp:110-119 -> (draw, engine state after)"""
+    cdef float out = 0
+    check(dist_sample_beta_safe(&rng_state, alpha, beta, min_value, &out))
+    return out, rng_state
+
 
 def rng_seed(seed):
     return dist_rng_seed(<uint64_t> seed)

@@ -1,14 +1,15 @@
 """DirichletProcessDiscrete -- mirror of distributions/lp/models/dpd.pyx.
 
-Values are kept in a dense remap: the Shared's `betas` dict {value: beta}
-fixes an order value -> 0..V-1; OTHER is 0xFFFFFFFF (dpd.hpp:56).  The
-stick-breaking side of Shared (add_value creating new values, realize;
-dpd.hpp:66-101) is outside the row-update path.
+Values are kept in a dense remap: every value the Shared knows owns a dense
+slot 0..V-1 for life (dist_dpd_shared_t); OTHER is 0xFFFFFFFF (dpd.hpp:56).
+Shared.add_value / remove_value / realize are the reference's stick-breaking
+(dpd.hpp:66-101): a new value appends a slot (or takes a freed one), groups
+and mixtures built before it are widened when they next meet the Shared.
 """
 import numpy as np
 
 from ... import _core
-from ._base import SharedBase, GroupBase, MixtureBase
+from ._base import SharedBase, GroupBase, MixtureBase, get_rng
 
 NAME = 'DirichletProcessDiscrete'
 EXAMPLES = [
@@ -26,26 +27,92 @@ OTHER = 0xFFFFFFFF
 
 
 class Shared(SharedBase):
-    def load(self, raw):
-        self.gamma = float(raw.get('gamma', 1.0))
-        self.alpha = float(raw['alpha'])
-        self.values = sorted(int(v) for v in raw['betas'])
-        self.index = {v: i for i, v in enumerate(self.values)}
-        betas = [float(raw['betas'][v] if v in raw['betas']
-                       else raw['betas'][str(v)]) for v in self.values]
-        self.counts = dict(raw.get('counts', {}))
-        self.beta0 = max(0.0, 1.0 - float(np.sum(betas, dtype=np.float64)))
-        self._params = _core.SharedParams.make(
-            _core.KIND_DPD, p=(self.alpha, self.beta0), betas=betas)
+    """dpd.hpp:59-153 through dist_dpd_shared_t: the stick-breaking state
+    (which values exist, their betas and row counts, beta0) lives in the
+    library; `params` is the dense view the groups and mixtures take."""
 
-    def dump(self):
-        betas = self.params.betas
-        return {'gamma': self.gamma, 'alpha': self.alpha,
-                'betas': {v: float(betas[i]) for v, i in self.index.items()},
-                'counts': dict(self.counts)}
+    def __init__(self):
+        SharedBase.__init__(self)
+        self._core = _core.DpdShared()
+        self._seen = None
+
+    # --- the dense view -----------------------------------------------------
+    @property
+    def params(self):
+        if self._seen != self._core.version:
+            self._params = self._core.params()
+            slot_values, _, _ = self._core.dump()
+            self._values = [None if v == OTHER else int(v)
+                            for v in slot_values]
+            self._seen = self._core.version
+        return self._params
+
+    @property
+    def version(self):
+        return self._core.version
+
+    @property
+    def values(self):
+        """dense slot -> value (None: a slot whose value is gone)"""
+        self.params
+        return self._values
+
+    @property
+    def index(self):
+        return {v: i for i, v in enumerate(self.values) if v is not None}
+
+    @property
+    def gamma(self):
+        return self._core.scalars()[0]
+
+    @property
+    def alpha(self):
+        return self._core.scalars()[1]
+
+    @property
+    def beta0(self):
+        return self._core.scalars()[2]
+
+    @property
+    def counts(self):
+        values, _, counts = self._core.dump()
+        return {int(v): int(c) for v, c in zip(values, counts) if v != OTHER}
 
     def remap(self, value):
-        return OTHER if value == OTHER else self.index[int(value)]
+        return self._core.slot(int(value))
+
+    # --- Shared's own interface (dpd.pyx:69-134, _dpd.pyx:31-45) ------------
+    def load(self, raw):
+        betas = {int(v): float(b) for v, b in raw['betas'].items()}
+        counts = {int(v): int(c) for v, c in raw.get('counts', {}).items()}
+        values = sorted(betas)
+        self._core.load(float(raw.get('gamma', 1.0)), float(raw['alpha']),
+                        values, [betas[v] for v in values],
+                        [counts.get(v, 0) for v in values])
+
+    def dump(self):
+        values, betas, counts = self._core.dump()
+        live = values != OTHER
+        return {'gamma': self.gamma, 'alpha': self.alpha,
+                'betas': {int(v): float(b)
+                          for v, b in zip(values[live], betas[live])},
+                'counts': {int(v): int(c)
+                           for v, c in zip(values[live], counts[live])}}
+
+    def add_value(self, value):
+        """dpd.hpp:66-74: the first row of a new value breaks a piece off the
+        stick, with the global engine (lp/models/_dpd.pyx:38-39)"""
+        rng = get_rng()
+        rng.state = self._core.add_value(int(value), rng.state)
+
+    def remove_value(self, value):
+        """dpd.hpp:76-83"""
+        self._core.remove_value(int(value))
+
+    def realize(self):
+        """dpd.hpp:85-101"""
+        rng = get_rng()
+        rng.state = self._core.realize(rng.state)
 
     def protobuf_load(self, message):          # dpd.pyx:105-120
         values = [int(v) for v in message.values]
@@ -59,11 +126,23 @@ class Shared(SharedBase):
         message.Clear()
         message.gamma = self.gamma
         message.alpha = self.alpha
-        betas = self.params.betas
-        for value in self.values:
+        raw = self.dump()
+        for value in sorted(raw['betas']):
             message.values.append(value)
-            message.betas.append(float(betas[self.index[value]]))
-            message.counts.append(int(self.counts.get(value, 0)))
+            message.betas.append(raw['betas'][value])
+            message.counts.append(raw['counts'][value])
+
+
+def _widen(words, shared):
+    """a group's counts in the Shared's CURRENT dense layout: values that
+    appeared after the group was built get a zero (dpd.hpp:66-74 grows the
+    Shared, never re-orders it)"""
+    need = 1 + shared.params.dim
+    if len(words) >= need:
+        return words
+    out = np.zeros(need, np.uint32)
+    out[:len(words)] = words
+    return out
 
 
 class Group(GroupBase):
@@ -84,10 +163,12 @@ class Group(GroupBase):
         if self._sparse is not None:
             words = shared.params.group_init()
             for value, count in self._sparse.items():
-                words[1 + shared.index[int(value)]] = int(count)
+                words[1 + shared.remap(value)] = int(count)
                 words[0] += int(count)
             self.words = words
             self._sparse = None
+        elif self.words is not None:
+            self.words = _widen(self.words, shared)
 
     def init(self, shared):
         self._sparse = None
@@ -151,11 +232,29 @@ class Mixture(MixtureBase):
             MixtureBase.append(self, group)
 
     def _handle(self, shared):
+        """the device mixture of the Shared's current dense view: rebuilt
+        (counts carried over, caches re-initialised) when the Shared gained
+        or lost a value since -- the reference creates and destroys
+        per-value score vectors as values come and go (dpd.hpp:430-469)"""
         for i, item in enumerate(self._pending):
             if isinstance(item, Group):
                 item._bind(shared)
                 self._pending[i] = np.array(item.words, np.uint32)
-        return MixtureBase._handle(self, shared)
+        key = (id(shared), shared.version)
+        if self._core is None or key != self._key:
+            fresh = self._core is None
+            groups = self._pending if fresh else [
+                self._core.get_group(i) for i in range(len(self._core))]
+            self._core = _core.SlaveMixture(shared.params)
+            for words in groups:
+                self._core.append(_widen(
+                    np.ascontiguousarray(words, np.uint32), shared))
+            if not fresh:
+                self._core.init()
+            self._pending = []
+            self._key = key
+            self._values_of_shared = shared.values
+        return self._core
 
     _values_of_shared = None
 

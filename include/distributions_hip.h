@@ -244,6 +244,54 @@ int dist_scorer_init(const dist_shared_t * shared, const uint32_t * group,
 int dist_scorer_eval(const dist_shared_t * shared, const float * state,
                      uint32_t value, float * out);
 
+/* ---- DirichletProcessDiscrete::Shared, the stick-breaking side -------------
+ * (dpd.hpp:59-101; lp/models/_dpd.pyx:31-45).  Host side like the reference's:
+ * gamma, alpha, beta0, the betas of the values that exist and how many rows
+ * carry each.  A value owns a DENSE SLOT for life (the index groups and the
+ * kernels count it under); a value whose last row leaves gives its beta back
+ * to beta0 and its slot to the next new value.
+ *   add_value     dpd.hpp:66-74  a first row of a new value breaks
+ *                 beta0 * sample_beta_safe(rng, 1, gamma, MIN_BETA) off the stick
+ *   remove_value  dpd.hpp:76-83
+ *   realize       dpd.hpp:85-101 new values until beta0 <= 1e-4 or 9 999 exist,
+ *                 the rest of the stick to one last value; beta0 = 0
+ *   load          protobuf_load dpd.hpp:103-124 (beta0 = max(0, 1 - sum betas))
+ *   view          the dist_shared_t the mixtures take: dim = slots, betas by
+ *                 slot (0 for a free slot); the pointer is the object's own
+ *                 storage, valid until its next mutation (`version` moves)
+ *   slot          value -> dense slot (OTHER -> OTHER); unknown values fail
+ *   dump          by slot: value (0xFFFFFFFF = free), beta, count
+ * Entropy: rng_t's one word of state, advanced as libstdc++'s
+ * std::gamma_distribution<double> over std::default_random_engine advances it
+ * (random.hpp:87-119). */
+typedef struct dist_dpd_shared dist_dpd_shared_t;
+dist_dpd_shared_t * dist_dpd_shared_create(void);
+void dist_dpd_shared_destroy(dist_dpd_shared_t * s);
+int dist_dpd_shared_copy(dist_dpd_shared_t * dst,
+                         const dist_dpd_shared_t * src);  /* Shared's copy  */
+int dist_dpd_shared_load(dist_dpd_shared_t * s, float gamma, float alpha,
+                         const uint32_t * values, const float * betas,
+                         const int * counts, size_t n);
+int dist_dpd_shared_add_value(dist_dpd_shared_t * s, uint32_t value,
+                              uint32_t * rng_state);
+int dist_dpd_shared_remove_value(dist_dpd_shared_t * s, uint32_t value);
+int dist_dpd_shared_realize(dist_dpd_shared_t * s, uint32_t * rng_state);
+size_t dist_dpd_shared_slots(const dist_dpd_shared_t * s);
+size_t dist_dpd_shared_size(const dist_dpd_shared_t * s);
+uint64_t dist_dpd_shared_version(const dist_dpd_shared_t * s);
+int dist_dpd_shared_params(const dist_dpd_shared_t * s, float * gamma,
+                           float * alpha, float * beta0);
+int dist_dpd_shared_view(const dist_dpd_shared_t * s, dist_shared_t * out);
+int dist_dpd_shared_slot(const dist_dpd_shared_t * s, uint32_t value,
+                         uint32_t * slot_out);
+int dist_dpd_shared_dump(const dist_dpd_shared_t * s, uint32_t * values,
+                         float * betas, int * counts);
+/* sample_gamma / sample_beta_safe (random.hpp:87-97,110-119) over rng_t */
+int dist_sample_gamma(uint32_t * rng_state, float alpha, float beta,
+                      float * out);
+int dist_sample_beta_safe(uint32_t * rng_state, float alpha, float beta,
+                          float min_value, float * out);
+
 /* ---- protobuf wire format of Shared / Group -------------------------------
  * The messages of distributions/io/schema.proto (package
  * protobuf.distributions) as bytes, what Group::protobuf_dump / protobuf_load

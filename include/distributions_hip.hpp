@@ -393,34 +393,98 @@ typedef Model<DIST_NICH, float> NormalInverseChiSq;      // models/nich.hpp
 // remap; dist_shared_t carries a pointer to them)
 struct DirichletProcessDiscrete : Model<DIST_DPD, uint32_t> {
     typedef Model<DIST_DPD, uint32_t> Base;
+    // dpd.hpp:59-153.  The members a mixture reads (dim, betas by DENSE SLOT,
+    // p[0] = alpha, p[1] = beta0) are the base's; the stick-breaking state
+    // behind them -- which value owns which slot, the row counts, gamma --
+    // is a dist_dpd_shared_t.  Groups and mixtures count values under their
+    // slot: pass shared.slot(value) where the reference passes the value
+    // (for values 0..V-1 loaded in order, e.g. EXAMPLE(), the two coincide).
     struct Shared : Base::Shared {
-        std::vector<float> storage;
-        Shared() {}
-        Shared(const Shared & other) : Base::Shared(other), storage(other.storage) {
-            repoint();
+        Shared() : handle(dist_dpd_shared_create()) {
+            if (!handle) throw std::runtime_error(dist_last_error());
+            refresh();
+        }
+        Shared(const Shared & other) : Base::Shared(other),
+                                       handle(dist_dpd_shared_create()) {
+            if (!handle) throw std::runtime_error(dist_last_error());
+            copy_state(other);
         }
         Shared & operator=(const Shared & other) {
-            static_cast<Base::Shared &>(*this) = other;
-            storage = other.storage;
-            repoint();
+            if (this != &other) copy_state(other);
             return *this;
         }
+        ~Shared() { dist_dpd_shared_destroy(handle); }
+
+        float gamma() const { return scalar(0); }
+        float alpha() const { return scalar(1); }
+        float beta0() const { return scalar(2); }
+        size_t size() const { return dist_dpd_shared_size(handle); }
+
+        // protobuf_load's content (dpd.hpp:103-124)
+        void load(float gamma_value, float alpha_value,
+                  const std::vector<uint32_t> & values,
+                  const std::vector<float> & betas_by_value,
+                  const std::vector<int> & counts) {
+            check(dist_dpd_shared_load(handle, gamma_value, alpha_value,
+                                       values.data(), betas_by_value.data(),
+                                       counts.empty() ? nullptr : counts.data(),
+                                       values.size()));
+            refresh();
+        }
+        // values 0 .. n-1 with these betas (the dense layout itself)
         void set_betas(const std::vector<float> & values) {
-            storage = values;
-            this->dim = (int)storage.size();
-            repoint();
+            std::vector<uint32_t> keys(values.size());
+            for (size_t i = 0; i < keys.size(); ++i) keys[i] = (uint32_t)i;
+            const float a = this->p[0];
+            load(gamma(), a, keys, values, std::vector<int>(values.size(), 1));
+        }
+        void add_value(const Value & value, rng_t & rng) {   // dpd.hpp:66-74
+            check(dist_dpd_shared_add_value(handle, value, &rng.state));
+            refresh();
+        }
+        void remove_value(const Value & value, rng_t &) {    // dpd.hpp:76-83
+            check(dist_dpd_shared_remove_value(handle, value));
+            refresh();
+        }
+        void realize(rng_t & rng) {                          // dpd.hpp:85-101
+            check(dist_dpd_shared_realize(handle, &rng.state));
+            refresh();
+        }
+        // the dense slot a value is counted under (OTHER stays OTHER)
+        uint32_t slot(const Value & value) const {
+            uint32_t out = 0;
+            check(dist_dpd_shared_slot(handle, value, &out));
+            return out;
         }
         // dpd.hpp:141-152: alpha 0.5, beta0 0, a hundred values of 1/100
         static Shared EXAMPLE() {
             Shared shared;
-            shared.p[0] = 0.5f;
-            shared.p[1] = 0.0f;
-            shared.set_betas(std::vector<float>(100, (float)(1.0 / 100)));
+            std::vector<uint32_t> keys(100);
+            for (size_t i = 0; i < keys.size(); ++i) keys[i] = (uint32_t)i;
+            shared.load((float)(1.0 / 100), 0.5f, keys,
+                        std::vector<float>(100, (float)(1.0 / 100)),
+                        std::vector<int>(100, 1));
+            shared.p[1] = 0.0f;     // "must be zero for testing"
             return shared;
         }
 
       private:
-        void repoint() { this->betas = storage.empty() ? nullptr : storage.data(); }
+        dist_dpd_shared_t * handle;
+        float scalar(int which) const {
+            float v[3];
+            check(dist_dpd_shared_params(handle, &v[0], &v[1], &v[2]));
+            return v[which];
+        }
+        void refresh() {
+            dist_shared_t view;
+            check(dist_dpd_shared_view(handle, &view));
+            static_cast<dist_shared_t &>(*this) = view;
+        }
+        void copy_state(const Shared & other) {
+            check(dist_dpd_shared_copy(handle, other.handle));
+            refresh();
+            this->p[1] = other.p[1];
+        }
     };
 };
 typedef Model<DIST_BNB, uint32_t> BetaNegativeBinomial;      // models/bnb.hpp

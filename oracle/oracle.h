@@ -19,7 +19,15 @@
  * test_models.py:498-594, test_clustering.py:242-327, test_random.py:183-247)
  * and an independent float64/scipy evaluation.  PARITY UNPINNED at the bit
  * level for those: every "bit-exact" claim of the GPU path about them is
- * "bit-exact against this restatement".
+ * "bit-exact against this restatement".  "dbg (TOL)" = held, at the
+ * tolerance the reference's own cross-flavour test uses (TOL = 1e-3,
+ * distributions/tests/test_model_flavors.py:61-116, tests/util.py:42), to
+ * the answers of the reference's OWN pure-Python flavour
+ * (distributions/dbg/models/*.py, dbg/clustering.py), run where it lies by
+ * tests/golden/make_dbg_goldens.py (lib2to3 in memory) and committed as
+ * tests/golden/dbg_*.json.gz; tests/test_dbg_goldens.py (this file) and
+ * tests/test_gpu_dbg_goldens.py (the HIP library).  Not a bit-level pin:
+ * nothing in this image can give one for these functions.
  *
  *   function(s) here                      reference                 pinned to
  *   orc_fast_log/exp/lgamma/lgamma_nu/    special.hpp:53-273,       _ref
@@ -43,14 +51,13 @@
  *     shifted-score cache, orc_py_score_  clustering.cc:37-63,      score_counts
  *     counts, orc_py_sample_assignments   152-183                   {5,3,1,0},
  *                                                                   one draw)
- *   orc_le_* (LowEntropy)                 clustering.hpp:245-331,   UNPINNED
- *                                         clustering.cc:185-238     (table: own
- *                                                                   derivation)
- *   orc_mix_slave_* / orc_group_* :       dd.hpp:89-472, bb.hpp:    UNPINNED
- *     Group add/remove, Scorer::init,     79-325, gp.hpp:84-334 +
- *     score_value(_group), score_data     gp.cc:32-67, nich.hpp:98-
- *     for DD, BB, GP, NICH, DPD, BNB      385 + nich.cc:33-66,
- *                                         dpd.hpp:157-578, bnb.hpp
+ *   orc_le_* (LowEntropy)                 clustering.hpp:245-331,   dbg (TOL);
+ *                                         clustering.cc:185-238     bits UNPINNED
+ *   orc_mix_slave_* / orc_group_* :       dd.hpp:89-472, bb.hpp:    dbg (TOL):
+ *     Group add/remove, Scorer::init,     79-325, gp.hpp:84-334 +   statistics
+ *     score_value(_group), score_data     gp.cc:32-67, nich.hpp:98- after every
+ *     for DD, BB, GP, NICH, DPD, BNB      385 + nich.cc:33-66,      step, scores;
+ *                                         dpd.hpp:157-578, bnb.hpp  bits UNPINNED
  *   orc_mix_gibbs_sequential              examples/mixture/main.py: composition
  *                                         236-244      of the above
  *   orc_mix_batch_sample/apply_moves/     none: the batch semantics of

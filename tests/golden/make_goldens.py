@@ -165,6 +165,38 @@ def driver_tracker(R):
     np.savez_compressed(os.path.join(HERE, "driver_tracker.npz"), **out)
 
 
+def variates_libstdcxx():
+    """sample_gamma / sample_beta_safe (random.hpp:87-119) from libstdc++
+    itself: oracle/check_libstdcxx.cc variates"""
+    import json
+    exe = os.path.join(ROOT, "oracle", "_ref", "check_libstdcxx")
+    cases = []
+    for alpha, beta in [(1.0, 0.5), (1.0, 2.0), (1.0, 5.0), (0.3, 0.01),
+                        (7.5, 1.0), (1.0, 0.01)]:
+        seeds = [1, 7, 12345, 987654321]
+        txt = subprocess.check_output(
+            [exe, "variates", "40", repr(alpha), repr(beta)]
+            + [str(s) for s in seeds], text=True)
+        cur = None
+        for line in txt.splitlines():
+            if line.startswith("seed"):
+                cur = {"alpha": alpha, "beta": beta,
+                       "seed": int(line.split()[1]), "gamma_bits": [],
+                       "gamma_next": [], "beta_safe_bits": [],
+                       "beta_safe_next": []}
+                cases.append(cur)
+            else:
+                g, gn, b, bn = line.split()
+                cur["gamma_bits"].append(int(g, 16))
+                cur["gamma_next"].append(int(gn))
+                cur["beta_safe_bits"].append(int(b, 16))
+                cur["beta_safe_next"].append(int(bn))
+    with open(os.path.join(HERE, "variates_libstdcxx.json"), "w") as f:
+        json.dump({"min_value": 1e-6, "cases": cases}, f,
+                  separators=(",", ":"))
+    print("variates_libstdcxx.json: %d cases" % len(cases))
+
+
 def rng_libstdcxx():
     exe = os.path.join(ROOT, "oracle", "_ref", "check_libstdcxx")
     seeds = [1, 0, 12345, 2147483647, 2147483646, 987654321]
@@ -297,6 +329,9 @@ def low_entropy_table():
 if __name__ == "__main__":
     protobuf_schema()
     low_entropy_table()
+    if "--variates-only" in sys.argv:
+        variates_libstdcxx()
+        sys.exit(0)
     if "--schema-only" in sys.argv:
         sys.exit(0)
     if "--vector-sum-only" in sys.argv:
@@ -310,5 +345,6 @@ if __name__ == "__main__":
     vector_math(R)
     driver_tracker(R)
     rng_libstdcxx()
+    variates_libstdcxx()
     for f in sorted(os.listdir(HERE)):
         print(f, os.path.getsize(os.path.join(HERE, f)))

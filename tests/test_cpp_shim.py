@@ -161,3 +161,42 @@ def test_shim_example_reproduces_the_sequential_chain():
         st = m.gibbs_sequential(0, 8, st)
     assert groups == len(m)
     assert got == list(m.assign)
+
+
+def test_dpd_shared_stick_breaking_through_the_shim_equals_the_mirror():
+    """DirichletProcessDiscrete::Shared::add_value / remove_value / realize
+    (dpd.hpp:66-101) called as the reference's C++ callers call them
+    (examples/dpd_shared_check.cc) == the same calls through
+    distributions_amd.lp.models.dpd: one implementation behind both
+    (dist_dpd_shared_*), one engine.  Host-side: no GPU needed."""
+    exe = os.path.join(ROOT, "examples", "dpd_shared_check")
+    subprocess.check_call(
+        ["g++", "-std=c++11", "-Wall", "-Werror",
+         "-I" + os.path.join(ROOT, "include", "compat"),
+         os.path.join(ROOT, "examples", "dpd_shared_check.cc"),
+         "-L" + os.path.join(ROOT, "distributions_amd"),
+         "-ldistributions_hip",
+         "-Wl,-rpath," + os.path.join(ROOT, "distributions_amd"),
+         "-o", exe])
+    lines = subprocess.check_output([exe], text=True).splitlines()
+    from distributions_amd.lp import random as lprandom
+    from distributions_amd.lp.models import dpd
+    lprandom.seed(7)
+    shared = dpd.Shared.from_dict({'gamma': 2.0, 'alpha': 2.0, 'betas': {},
+                                   'counts': {}})
+    for value in [5, 4, 3, 2, 1, 0, 3, 2, 1]:
+        shared.add_value(value)
+    shared.remove_value(5)
+    shared.add_value(77)
+    size, beta0, slot77, slot4 = lines[1].split()
+    assert int(size) == len(shared.dump()['betas'])
+    assert np.float32(float(beta0)) == np.float32(shared.beta0)
+    assert (int(slot77), int(slot4)) == (shared.remap(77), shared.remap(4))
+    got = np.array([float(x) for x in lines[2].split()], np.float32)
+    assert np.array_equal(got, shared.params.betas)
+    shared.realize()
+    size, beta0, state, dim = lines[0].split()
+    assert int(size) == len(shared.dump()['betas']) and float(beta0) == 0.0
+    assert int(state) == lprandom.get_rng().state
+    assert int(dim) == shared.params.dim
+    assert lines[3].split() == ["100", "0.5", "0", "42"]
