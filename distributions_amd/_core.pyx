@@ -114,6 +114,7 @@ cdef extern from "distributions_hip.h" nogil:
     int dist_mixture_score_value(const dist_mixture_t *, uint32_t, float *,
                                  size_t)
     int dist_mixture_score_data(const dist_mixture_t *, float *)
+    int dist_mixture_validate(const dist_mixture_t *)
     int dist_mixture_score_data_grid(const dist_mixture_t *,
                                      const dist_shared_t *, size_t, float *)
 
@@ -224,6 +225,16 @@ cdef extern from "distributions_hip.h" nogil:
     int dist_gibbs_global_to_packed(const dist_gibbs_t *, uint32_t, uint32_t *)
     size_t dist_gibbs_global_size(const dist_gibbs_t *)
     int dist_gibbs_debug_counts(dist_gibbs_t *, uint64_t *, size_t)
+    ctypedef struct dist_validate_report_t:
+        int code
+        int feature
+        long long group
+        long long detail
+        long long expected
+        long long found
+        long long rows_assigned
+        char what[96]
+    int dist_gibbs_validate(dist_gibbs_t *, dist_validate_report_t *)
     int dist_gibbs_comm_stats(dist_gibbs_t *, double *, uint64_t *, int)
     int dist_gibbs_phase_stats(dist_gibbs_t *, double *, uint64_t *, int)
     size_t dist_gibbs_float_delta_words(const dist_gibbs_t *)
@@ -895,6 +906,10 @@ cdef class SlaveMixture:
         check(dist_mixture_score_data(self.ptr, &out))
         return out
 
+    def validate(self):
+        """Mixture::validate (mixture.hpp:440-444): raises RuntimeError"""
+        check(dist_mixture_validate(self.ptr))
+
     def score_data_grid(self, shareds):
         """shareds: SharedParams candidates -> float32 scores, one each"""
         cdef size_t n = len(shareds)
@@ -1247,6 +1262,19 @@ cdef class GibbsEngine:
         check(dist_gibbs_sharded_device_normalise_ok(self.ptr, n_batches,
                                                      batch_rows, &ok))
         return bool(ok)
+
+    def validate(self, raise_on_failure=True):
+        """dist_gibbs_validate: the statistics against a recount from the rows
+        (mixture.hpp:152-163,440-444).  Returns the report as a dict; raises
+        RuntimeError on an inconsistency unless raise_on_failure is False."""
+        cdef dist_validate_report_t rep
+        cdef int rc = dist_gibbs_validate(self.ptr, &rep)
+        if rc == 1 or (rc and raise_on_failure):
+            check(rc)
+        return {"code": rep.code, "feature": rep.feature, "group": rep.group,
+                "detail": rep.detail, "expected": rep.expected,
+                "found": rep.found, "rows_assigned": rep.rows_assigned,
+                "what": (<bytes> rep.what).decode()}
 
     def debug_counts(self):
         """dict of the engine's path diagnostics (dist_gibbs_debug_counts)"""

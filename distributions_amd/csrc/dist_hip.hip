@@ -473,6 +473,51 @@ struct Slave {
         }
     }
 
+    // MixtureSlave::validate (mixture.hpp:440-444): the groups and both
+    // scorers agree on the group count (dd.hpp:447-455 ...), and -- what those
+    // size checks stand for -- the value scorer's cache IS Scorer::init of
+    // the statistics: recomputed in place and compared bit for bit.
+    void validate() {
+        DIST_REQUIRE(K >= 0 && K <= cap, "validate: group count beyond capacity");
+        const size_t width = is_cat(sh.kind) ? (size_t)sh.dim : 0;
+        auto grab = [&](const DeviceBuf<float> & b, size_t n) {
+            std::vector<float> v(b.p ? n : 0);
+            if (b.p && n) b.download(v.data(), n);
+            return v;
+        };
+        const size_t Kn = (size_t)K;
+        std::vector<float> before[5] = {grab(c0, Kn), grab(c1, Kn), grab(c2, Kn),
+                                        grab(c3, Kn), grab(S, width * cap)};
+        std::vector<int32_t> sizes(Kn);
+        if (Kn) i0.download(sizes.data(), Kn);
+        if (is_cat(sh.kind) && Kn) {
+            std::vector<int32_t> cells(Kn * width);
+            cnt.download(cells.data(), cells.size());
+            for (size_t k = 0; k < Kn; ++k) {
+                long long sum = 0;
+                for (size_t v = 0; v < width; ++v) sum += cells[k * width + v];
+                DIST_REQUIRE(sum == sizes[k],
+                             "validate: count_sum != sum of counts in group "
+                                 + std::to_string(k));
+            }
+        }
+        init();
+        std::vector<float> after[5] = {grab(c0, Kn), grab(c1, Kn), grab(c2, Kn),
+                                       grab(c3, Kn), grab(S, width * cap)};
+        static const char * names[5] = {"c0", "c1", "c2", "c3", "S"};
+        for (int b = 0; b < 5; ++b)
+            for (size_t i = 0; i < before[b].size(); ++i) {
+                if (b == 4 && i % cap >= Kn) continue;   // slots beyond K
+                uint32_t x, y;
+                memcpy(&x, &before[b][i], 4);
+                memcpy(&y, &after[b][i], 4);
+                DIST_REQUIRE(x == y,
+                             std::string("validate: the value scorer's cache ")
+                                 + names[b] + " is stale at "
+                                 + std::to_string(b == 4 ? i % cap : i));
+            }
+    }
+
     void update(int k0, int k1) {
         if (k1 <= k0) return;
         const size_t width = is_cat(sh.kind) ? sh.dim : 1;
@@ -1242,6 +1287,139 @@ struct Gibbs {
         }
         return img;
     }
+    // Mixture::validate / MixtureDriver::_validate (mixture.hpp:152-163,
+    // 440-442) and what the reference's asserts stand for: every row's group
+    // is live, the group sizes and every integer statistic equal a recount
+    // from the rows, the host's mirror of the group set equals the device's,
+    // there is an empty group, sizes sum to the rows assigned.
+    void validate(dist_validate_report_t * rep) {
+        DIST_REQUIRE(!batch_open, "validate: a batch is open");
+        memset(rep, 0, sizeof(*rep));
+        rep->feature = -1;
+        flush_assign_pos();
+        upload_maps();
+        const size_t Kn = (size_t)K();
+        // the host's mirror (MixtureDriver::_validate)
+        std::vector<int> dev(Kn);
+        py.d_counts.download(dev.data(), Kn);
+        long long total = 0;
+        int empties = 0;
+        auto host_bad = [&](long long group, long long expected,
+                            long long found, const char * what) {
+            rep->code = VALIDATE_HOST;
+            rep->group = group;
+            rep->expected = expected;
+            rep->found = found;
+            snprintf(rep->what, sizeof(rep->what), "%s", what);
+        };
+        for (size_t k = 0; k < Kn && !rep->code; ++k) {
+            if (dev[k] != py.counts[k])
+                host_bad((long long)k, dev[k], py.counts[k],
+                         "host mirror of a group size differs from the device");
+            else if (dev[k] < 0)
+                host_bad((long long)k, 0, dev[k], "negative group size");
+            total += dev[k];
+            empties += dev[k] == 0;
+        }
+        if (!rep->code && empties < 1)
+            host_bad(-1, 1, 0, "missing empty groups");
+        if (!rep->code && empties != py.n_empty)
+            host_bad(-1, empties, py.n_empty, "empty-group count");
+        if (!rep->code && total != py.sample_size)
+            host_bad(-1, total, py.sample_size, "sample_size");
+        if (!rep->code && tracker.p2g.size() != Kn)
+            host_bad(-1, (long long)Kn, (long long)tracker.p2g.size(),
+                     "id tracker's packed size");
+        for (size_t k = 0; k < Kn && !rep->code; ++k) {
+            const uint32_t id = tracker.p2g[k];
+            if (id >= tracker.g2p.size() || tracker.g2p[id] != (int32_t)k)
+                host_bad((long long)k, (long long)k,
+                         id < tracker.g2p.size() ? tracker.g2p[id] : -2,
+                         "id tracker's maps are not inverse");
+        }
+        for (auto & s : feats)
+            if (!rep->code && (size_t)s->K != Kn)
+                host_bad(-1, (long long)Kn, s->K, "a feature's group count");
+        if (rep->code) return;
+        // the recount on the device
+        DeviceBuf<int32_t> words;
+        words.reserve(std::max<size_t>(stat_words(), 1), 0);
+        HIP_CHECK(hipMemsetAsync(words.p, 0, stat_words() * sizeof(int32_t),
+                                 stream()));
+        DeviceBuf<uint32_t> packed;
+        packed.reserve(std::max<size_t>(n_rows, 1), 0);
+        DeviceBuf<unsigned long long> out;
+        out.reserve(2, 0);
+        const unsigned long long init[2] = {~0ull, 0ull};
+        out.upload(init, 2);
+        SweepParams P = params(0, n_rows, 1, 0);
+        StatImage recount = word_image(words.p);
+        if (n_rows)
+            LAUNCH(k_validate_rows, n_rows, P, recount, d_g2p_ptr,
+                   (uint32_t)tracker.g2p.size(), n_rows, packed.p, out.p,
+                   out.p + 1);
+        StatImage live = live_image();
+        if (Kn) LAUNCH(k_validate_compare, Kn, P, live, recount, -1, Kn, out.p);
+        for (int f = 0; f < F(); ++f) {
+            const size_t width = 2 + (size_t)feats[f]->dim();
+            LAUNCH(k_validate_compare, Kn * width, P, live, recount, f,
+                   Kn * width, out.p);
+        }
+        unsigned long long got[2];
+        out.download(got, 2);
+        rep->rows_assigned = (long long)got[1];
+        if (got[0] == ~0ull) {
+            if ((long long)got[1] != total)
+                host_bad(-1, (long long)got[1], total,
+                         "group sizes do not sum to the rows assigned");
+            return;
+        }
+        rep->code = (int)(got[0] >> 60);
+        rep->feature = (int)((got[0] >> 56) & 15);
+        rep->group = (long long)((got[0] >> 28) & 0xFFFFFFFull);
+        rep->detail = (long long)(got[0] & 0xFFFFFFFull);
+        static const char * names[] = {
+            "", "a row carries a group id that is not live",
+            "a row's value is outside the feature's domain",
+            "group size != rows assigned to the group",
+            "statistic 0 (count_sum / heads / count) != recount",
+            "statistic 1 (tails / sum) != recount",
+            "categorical count cell != recount", ""};
+        snprintf(rep->what, sizeof(rep->what), "%s", names[rep->code & 7]);
+        // expected (recount) and found (live) for the report
+        auto word_at = [&](const int32_t * p) {
+            int32_t v = 0;
+            HIP_CHECK(hipMemcpyAsync(&v, p, 4, hipMemcpyDeviceToHost, stream()));
+            sync();
+            return (long long)v;
+        };
+        const size_t k = (size_t)rep->group;
+        const int f = rep->feature;
+        switch (rep->code) {
+        case VALIDATE_GROUP_SIZE:
+            rep->feature = -1;
+            rep->expected = word_at(recount.counts + k);
+            rep->found = word_at(live.counts + k);
+            break;
+        case VALIDATE_STAT0:
+            rep->expected = word_at(recount.i0[f] + k);
+            rep->found = word_at(live.i0[f] + k);
+            break;
+        case VALIDATE_STAT1:
+            rep->expected = word_at(recount.i1[f] + k);
+            rep->found = word_at(live.i1[f] + k);
+            break;
+        case VALIDATE_CELL: {
+            const size_t cell = k * feats[f]->dim() + (size_t)rep->detail;
+            rep->expected = word_at(recount.cnt[f] + cell);
+            rep->found = word_at(live.cnt[f] + cell);
+            break;
+        }
+        default:
+            break;
+        }
+    }
+
     size_t stat_words() const {
         size_t n = (size_t)K();
         for (auto & s : feats)
@@ -4833,6 +5011,23 @@ size_t dist_gibbs_global_size(const dist_gibbs_t * g) {
     size_t n = (size_t)-1;
     (void)guarded([&] { n = g->impl->tracker.g2p.size(); });
     return n;
+}
+int dist_gibbs_validate(dist_gibbs_t * g, dist_validate_report_t * report) {
+    dist_validate_report_t local;
+    dist_validate_report_t * rep = report ? report : &local;
+    const int rc = guarded([&] { g->impl->validate(rep); });
+    if (rc) return rc;
+    if (rep->code == 0) return 0;
+    char msg[256];
+    snprintf(msg, sizeof(msg),
+             "validate: %s (code %d, feature %d, group/row %lld, detail %lld, "
+             "expected %lld, found %lld)", rep->what, rep->code, rep->feature,
+             rep->group, rep->detail, rep->expected, rep->found);
+    set_last_error(msg);
+    return 2;
+}
+int dist_mixture_validate(const dist_mixture_t * m) {
+    return guarded([&] { m->impl->validate(); });
 }
 int dist_gibbs_sharded_device_normalise_ok(const dist_gibbs_t * g,
                                            size_t n_batches,

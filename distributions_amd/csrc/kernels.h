@@ -5539,4 +5539,112 @@ __global__ void k_packed_to_global(const uint32_t * __restrict__ packed,
     if (i < n) global[i] = p2g[packed[i]];
 }
 
+// ---------------------------------------------------------------------------
+// validate (mixture.hpp:152-163,440-442 and what those asserts stand for):
+// the statistics recounted from the rows' assignments against the live ones.
+// k_validate_rows turns every row's global id into its packed index (an id
+// that is not live is reported, lowest row first) and counts the row into a
+// recount image; k_validate_compare reports the lowest (feature, group, cell)
+// at which the live image differs.
+
+enum ValidateCode {
+    VALIDATE_OK = 0,
+    VALIDATE_DEAD_ID = 1,       // group = row, detail = the id it carries
+    VALIDATE_VALUE_RANGE = 2,   // group = row, detail = the value
+    VALIDATE_GROUP_SIZE = 3,    // counts[k] != rows assigned to k
+    VALIDATE_STAT0 = 4,         // i0[k]: count_sum / heads / count
+    VALIDATE_STAT1 = 5,         // i1[k]: tails / sum
+    VALIDATE_CELL = 6,          // cnt[k][detail]
+    VALIDATE_HOST = 7           // the host's mirror of the group set
+};
+
+// code:4 | feature:4 | group:28 | detail:28 -- the lowest key wins
+__device__ __forceinline__ unsigned long long validate_key(
+        int code, int feature, unsigned long long group,
+        unsigned long long detail) {
+    return ((unsigned long long)code << 60) | ((unsigned long long)feature << 56)
+         | ((group & 0xFFFFFFFull) << 28) | (detail & 0xFFFFFFFull);
+}
+
+__global__ void k_validate_rows(SweepParams P, StatImage img,
+                                const int32_t * __restrict__ g2p,
+                                uint32_t n_global, size_t n_rows,
+                                uint32_t * __restrict__ packed_out,
+                                unsigned long long * __restrict__ first_bad,
+                                unsigned long long * __restrict__ n_assigned) {
+    const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n_rows) return;
+    const uint32_t id = P.assign[row];
+    packed_out[row] = 0xFFFFFFFFu;
+    if (id == 0xFFFFFFFFu) return;          // not assigned yet (init path)
+    const int32_t g = id < n_global ? g2p[id] : -1;
+    if (g < 0 || g >= P.K) {
+        atomicMin(first_bad, validate_key(VALIDATE_DEAD_ID, 0, row, id));
+        return;
+    }
+    packed_out[row] = (uint32_t)g;
+    atomicAdd(n_assigned, 1ull);
+    atomicAdd(&img.counts[g], 1);
+    for (int f = 0; f < P.F; ++f) {
+        const SlaveView & s = P.feat[f];
+        const uint32_t x = P.values[f][row];
+        switch (s.kind) {
+        case DIST_DD:
+        case DIST_DPD:
+            if (x >= (uint32_t)s.dim) {
+                atomicMin(first_bad,
+                          validate_key(VALIDATE_VALUE_RANGE, f, row, x));
+                break;
+            }
+            atomicAdd(&img.i0[f][g], 1);
+            atomicAdd(&img.cnt[f][(size_t)g * s.dim + x], 1);
+            break;
+        case DIST_BB:
+            atomicAdd(x ? &img.i0[f][g] : &img.i1[f][g], 1);
+            break;
+        case DIST_GP:
+        case DIST_BNB:
+            atomicAdd(&img.i0[f][g], 1);
+            atomicAdd(&img.i1[f][g], (int32_t)x);
+            break;
+        default:    // NormalInverseChiSq: its count is the group's size
+            atomicAdd(&img.i0[f][g], 1);
+            break;
+        }
+    }
+}
+
+// item i: group i / width, column i % width of [size | i0 | i1 | cnt[dim]]
+// of feature f (f = -1: the group sizes)
+__global__ void k_validate_compare(SweepParams P, StatImage live,
+                                   StatImage recount, int f, size_t items,
+                                   unsigned long long * __restrict__ first_bad) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= items) return;
+    if (f < 0) {
+        if (live.counts[i] != recount.counts[i])
+            atomicMin(first_bad, validate_key(VALIDATE_GROUP_SIZE, 0, i,
+                                              (uint32_t)recount.counts[i]));
+        return;
+    }
+    const SlaveView & s = P.feat[f];
+    const bool cat = s.kind == DIST_DD || s.kind == DIST_DPD;
+    const size_t width = cat ? 2 + (size_t)s.dim : 2;
+    const size_t k = i / width, c = i % width;
+    if (c == 0) {
+        if (live.i0[f][k] != recount.i0[f][k])
+            atomicMin(first_bad, validate_key(VALIDATE_STAT0, f, k,
+                                              (uint32_t)recount.i0[f][k]));
+    } else if (c == 1) {
+        if (s.kind != DIST_NICH && !cat
+            && live.i1[f][k] != recount.i1[f][k])
+            atomicMin(first_bad, validate_key(VALIDATE_STAT1, f, k,
+                                              (uint32_t)recount.i1[f][k]));
+    } else {
+        const size_t cell = k * s.dim + (c - 2);
+        if (live.cnt[f][cell] != recount.cnt[f][cell])
+            atomicMin(first_bad, validate_key(VALIDATE_CELL, f, k, c - 2));
+    }
+}
+
 }  // namespace dist

@@ -124,6 +124,13 @@ class Gibbs(object):
     def get_group(self, feature, groupid):
         return self.core.get_group(feature, groupid)
 
+    def validate(self, raise_on_failure=True):
+        """Mixture::validate for the whole engine (mixture.hpp:152-163,
+        440-444): statistics against a recount from the rows, on the device
+        (dist_gibbs_validate).  Returns the report; raises RuntimeError on
+        the first inconsistency."""
+        return self.core.validate(raise_on_failure)
+
     def row_scores(self, row):
         return self.core.row_scores(row)
 

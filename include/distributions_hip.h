@@ -218,6 +218,12 @@ int dist_mixture_score_data_grid(const dist_mixture_t * m,
                                  const dist_shared_t * shareds, size_t n,
                                  float * scores_out);
 
+/* Mixture::validate (mixture.hpp:440-444; dd.hpp:447-455 and the other value
+ * scorers'): group counts agree, count_sum == sum of counts, and the value
+ * scorer's cache equals Scorer::init of the statistics bit for bit
+ * (recomputed on the device).  Non-zero + dist_last_error() otherwise. */
+int dist_mixture_validate(const dist_mixture_t * m);
+
 /* ---- Model::Group scalar API (host side, O(1); dd.hpp:113-199 etc.) ------ */
 int dist_group_init(const dist_shared_t * shared, uint32_t * group);
 int dist_group_add_value(const dist_shared_t * shared, uint32_t * group,
@@ -482,6 +488,32 @@ int dist_gibbs_global_to_packed(const dist_gibbs_t * g, uint32_t global,
                                 uint32_t * packed_out);
 /* MixtureIdTracker::global_size (mixture.hpp:517): ids handed out so far */
 size_t dist_gibbs_global_size(const dist_gibbs_t * g);
+/* Mixture::validate for the whole engine (mixture.hpp:152-163 the driver's
+ * _validate, :440-444 the slaves'), as far as the rows themselves can vouch:
+ * every row's group id is live; group sizes, and every integer statistic of
+ * every feature (count_sum and cells, heads/tails, count/sum; the count of a
+ * NormalInverseChiSq group), equal a recount from the rows on the device; the
+ * host's mirror of the group set (sizes, empty groups, id maps) equals the
+ * device's; there is an empty group; sizes sum to the rows assigned.  Closes
+ * an open device-normalised run first; fails while a batch is open.
+ * Returns 0 when consistent; 2 with dist_last_error() and *report (may be
+ * NULL) naming the first inconsistency; 1 when the check itself failed.
+ * Cost: one pass of atomics over the rows + O(K * dim); a diagnostic. */
+typedef struct dist_validate_report {
+    int code;            /* 0 ok | 1 dead id (group = row, detail = id) |
+                            2 value out of range (group = row) | 3 group size |
+                            4 statistic 0 | 5 statistic 1 | 6 count cell
+                            (detail = value) | 7 host mirror               */
+    int feature;         /* -1: the driver                                  */
+    long long group;     /* packed group index (or the row, codes 1-2)      */
+    long long detail;
+    long long expected;  /* the recount                                     */
+    long long found;     /* the live statistic                              */
+    long long rows_assigned;
+    char what[96];
+} dist_validate_report_t;
+int dist_gibbs_validate(dist_gibbs_t * g, dist_validate_report_t * report);
+
 /* whether THIS rank could run a sharded pass of n_batches batches of
  * batch_rows rows with the group set normalised on the device (a diagnostic:
  * dist_gibbs_sweep_sharded asks every rank itself and takes the device path

@@ -15,6 +15,11 @@ from distributions_amd import engine  # noqa: E402
 
 
 def same_state(orc, gpu):
+    # the engine's own consistency first (dist_gibbs_validate: a recount from
+    # the rows on the device): independent of the oracle
+    report = gpu.validate(raise_on_failure=False)
+    if report["code"]:
+        return "validate: %r" % (report,)
     if len(gpu) != len(orc):
         return "group count %d vs %d" % (len(gpu), len(orc))
     if not np.array_equal(gpu.counts(), orc.counts()):

@@ -32,6 +32,10 @@ def main():
                 orc.gibbs_batch(b, min(n, b + batch), st, s * n)
             gpu.sweep(0, n, batch, seed, draw_base=s * n)
             if s == sweeps // 2 or s == sweeps - 1:
+                report = gpu.validate(raise_on_failure=False)
+                if report["code"]:
+                    print("validate:", report, flush=True)
+                    bad += 1
                 same = (len(gpu) == len(orc)
                         and np.array_equal(gpu.counts(), orc.counts())
                         and np.array_equal(gpu.assignments(), orc.assign))
