@@ -115,6 +115,8 @@ cdef extern from "distributions_hip.h" nogil:
                                  size_t)
     int dist_mixture_score_data(const dist_mixture_t *, float *)
     int dist_mixture_validate(const dist_mixture_t *)
+    int dist_mixture_score_values(const dist_mixture_t *, const uint32_t *,
+                                  size_t, float *, size_t)
     int dist_mixture_score_data_grid(const dist_mixture_t *,
                                      const dist_shared_t *, size_t, float *)
 
@@ -905,6 +907,19 @@ cdef class SlaveMixture:
         cdef float out = 0
         check(dist_mixture_score_data(self.ptr, &out))
         return out
+
+    def score_values(self, values,
+                     cnp.ndarray[cnp.float32_t, ndim=2, mode="c"] scores_accum):
+        """score_value for len(values) values in one launch:
+        scores_accum[r, k] accumulates (dist_mixture_score_values)"""
+        cdef cnp.ndarray[cnp.uint32_t, ndim=1] v = np.ascontiguousarray(
+            values, dtype=np.uint32)
+        if scores_accum.shape[0] != v.shape[0]:
+            raise RuntimeError("scores_accum has one row per value")
+        check(dist_mixture_score_values(self.ptr, <const uint32_t *> v.data,
+                                        v.shape[0],
+                                        <float *> scores_accum.data,
+                                        scores_accum.shape[1]))
 
     def validate(self):
         """Mixture::validate (mixture.hpp:440-444): raises RuntimeError"""

@@ -246,6 +246,7 @@ static void check_shared(const dist_shared_t & sh) {
 // a reusable scratch of device floats for the per-call API paths
 struct Scratch {
     DeviceBuf<float> f;
+    DeviceBuf<uint32_t> u;
     DeviceBuf<SampleOut> s;
 };
 static Scratch & scratch() {
@@ -659,6 +660,19 @@ struct Slave {
         }
         out.download(scores_out, n);
     }
+    // score_value for n values at once: acc[r * ld + k] accumulates
+    void score_values(const uint32_t * vals, size_t n, float * acc,
+                      size_t ld) const {
+        DIST_REQUIRE(ld >= (size_t)K, "row stride below len(mixture)");
+        for (size_t r = 0; r < n; ++r) check_value(vals[r]);
+        if (!K || !n) return;
+        Scratch & sc = scratch();
+        sc.u.upload(vals, n);
+        sc.f.upload(acc, n * ld);
+        SlaveView v = view();
+        LAUNCH(k_slave_score_values, n * (size_t)K, v, sc.u.p, n, sc.f.p, ld, K);
+        sc.f.download(acc, n * ld);
+    }
     void score_value(uint32_t value, float * acc, size_t size) const {
         DIST_REQUIRE(size == (size_t)K, "scores_accum != len(mixture)");
         check_value(value);
@@ -884,6 +898,9 @@ struct Gibbs {
         uint32_t n_table_chunks = 0;
         DeviceBuf<uint32_t> val_start;    // [nvals + 1] first position per value
         DeviceBuf<uint32_t> chunk_first;  // [nvals + 1] first chunk per value
+        // {value, first chunk, chunks} of every table value with several
+        DeviceBuf<uint32_t> multi;
+        uint32_t n_multi = 0;
         // rows handed over per chunk (VsDefer): zero between batches
         DeviceBuf<uint32_t> def_counts;
         // where each group's rows begin in each chunk after its last sort
@@ -2103,6 +2120,27 @@ struct Gibbs {
                                                            h[x] - off)});
             if (h[x]) open = false;
         }
+        // (a chunk's `chunk` word: how many chunks its value has -- the
+        // cells of a value with several are k_vs_reduce's in a fused batch)
+        {
+            std::vector<uint32_t> multi;
+            for (size_t i = 0; i < chunks.size();) {
+                size_t j = i + 1;
+                while (j < chunks.size() && chunks[j].x == chunks[i].x
+                       && chunks[i].x != kVsMixedChunk) ++j;
+                const bool in_table = chunks[i].x < nv;
+                for (size_t q = i; q < j; ++q)
+                    chunks[q].chunk = in_table ? (uint32_t)(j - i) : 1u;
+                if (j - i > 1 && in_table) {
+                    multi.push_back(chunks[i].x);
+                    multi.push_back((uint32_t)i);
+                    multi.push_back((uint32_t)(j - i));
+                }
+                i = j;
+            }
+            c->n_multi = (uint32_t)(multi.size() / 3);
+            if (c->n_multi) c->multi.upload(multi.data(), multi.size());
+        }
         c->n_chunks = (uint32_t)chunks.size();
         c->one_chunk_per_value = true;
         c->mixed_chunks = false;
@@ -2250,6 +2288,11 @@ struct Gibbs {
             return false;
         if (Kpad > kTablesMaxK || c.mixed_chunks || any_float_stats())
             return false;
+        // rows beyond the value table bring their own value to the sums,
+        // unstaged (k_vs_apply), while the chunks' handed-over rows read
+        // those sums: not in one launch
+        const int kind0 = feats[0]->sh.kind;
+        if ((kind0 == DIST_BNB || kind0 == DIST_GP) && c.n_other) return false;
         const size_t lds_sort =
             ((size_t)K() * 2 + kVsApplyBlock / 64 + 4 * kVsApplyRows + 4) * 4;
         if (lds_sort > 144 * 1024) return false;
@@ -2973,7 +3016,10 @@ struct Gibbs {
                                        (uint32_t)vs_nvals(), pairs,          \
                                        pairs_seq,                            \
                                        async_active ? dev_ptr() : nullptr,   \
-                                       k_limit());                           \
+                                       k_limit(),                            \
+                                       batch_fused ? c.multi.p : nullptr,    \
+                                       batch_fused ? c.n_multi : 0u,         \
+                                       feats[0]->dim());                     \
             } while (0)
             // chunks of several values first (their rows of the staging
             // matrix must be there when k_vs_reduce runs)
@@ -4370,6 +4416,11 @@ int dist_mixture_score_value(const dist_mixture_t * m, uint32_t value,
     return guarded([&] { m->impl->score_value(value, scores_accum, size); });
 }
 
+int dist_mixture_score_values(const dist_mixture_t * m,
+                              const uint32_t * values, size_t n,
+                              float * scores_accum, size_t ld) {
+    return guarded([&] { m->impl->score_values(values, n, scores_accum, ld); });
+}
 int dist_mixture_score_data(const dist_mixture_t * m, float * out) {
     return guarded([&] { *out = m->impl->score_data(); });
 }

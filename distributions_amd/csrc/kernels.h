@@ -558,6 +558,22 @@ __global__ void k_slave_score_value(SlaveView s, uint32_t value,
     acc[k] = accumulate(s.kind, acc[k], load_entry(s, k, value), value, lf,
                         s.p);
 }
+// the same for a batch of values: acc[r * ld + k] accumulates the score of
+// values[r] in group k (one launch instead of one per value; per element the
+// very operations of k_slave_score_value)
+__global__ void k_slave_score_values(SlaveView s,
+                                     const uint32_t * __restrict__ values,
+                                     size_t n, float * __restrict__ acc,
+                                     size_t ld, int K) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * (size_t)K) return;
+    const size_t r = i / (size_t)K;
+    const int k = (int)(i % (size_t)K);
+    const uint32_t value = values[r];
+    const float lf = s.kind == DIST_GP ? fast_log_factorial(value) : 0.f;
+    float * cell = acc + r * ld + k;
+    *cell = accumulate(s.kind, *cell, load_entry(s, k, value), value, lf, s.p);
+}
 __global__ void k_slave_score_group(SlaveView s, int k, uint32_t value,
                                     float * out) {
     const float lf = s.kind == DIST_GP ? fast_log_factorial(value) : 0.f;
@@ -4496,6 +4512,15 @@ __global__ __launch_bounds__(kVsApplyBlock) void k_vs_apply(
     }
     __syncthreads();
     const int dim = P.feat[0].dim;
+    // A fused batch's chunks sample the rows they were handed while their
+    // siblings are already here: a handed-over row that is NOT alone in its
+    // group reads the cell (its group, x) as the batch found it
+    // (entry_after_remove), so the chunks of a value that has several must
+    // not change that cell under it -- k_vs_reduce adds their staged deltas
+    // to it after this launch (VsTile::chunk of a chunk: how many chunks its
+    // value has).
+    const bool defer_cells = SORT && stage && D.chunk_counts
+                             && chunks[blockIdx.x].chunk > 1u;
     for (int k = threadIdx.x; k < K; k += kVsApplyBlock) {
         const int dlt = delta[k];
         if (stage) stage[(size_t)blockIdx.x * P.K + k] = dlt;
@@ -4510,7 +4535,7 @@ __global__ __launch_bounds__(kVsApplyBlock) void k_vs_apply(
                     atomicAdd(&img.i1[0][k], dlt * (int32_t)x);   // sum
             }
         }
-        if (KIND == DIST_DD || KIND == DIST_DPD) {
+        if ((KIND == DIST_DD || KIND == DIST_DPD) && !defer_cells) {
             int32_t * cell = &img.cnt[0][(size_t)k * dim + x];
             int before;
             if (sole_owner) {   // one chunk per value: nobody else is here
@@ -4688,7 +4713,9 @@ __global__ __launch_bounds__(kVsReduceGroups * kVsReduceSlices)
 void k_vs_reduce(StatImage img, const int32_t * __restrict__ stage,
                  const VsTile * __restrict__ chunks, uint32_t n_chunks, int K,
                  uint32_t nvals, unsigned long long * host_pairs,
-                 unsigned int seq, const DevState * dev, int k_limit) {
+                 unsigned int seq, const DevState * dev, int k_limit,
+                 const uint32_t * __restrict__ multi, uint32_t n_multi,
+                 int dim) {
     // (the rows of the staging matrix are the host's bound apart: their
     // addresses do not wait for the group count of record; k_limit: what
     // that count can be at most at this batch)
@@ -4710,6 +4737,18 @@ void k_vs_reduce(StatImage img, const int32_t * __restrict__ stage,
                 b += x < nvals ? d * (int32_t)x : 0;
         }
     }
+    // the cells k_vs_apply left to this kernel (a fused batch's values with
+    // several chunks; multi[] = {value, first chunk, chunks} each): thread
+    // (k, slice) owns cell (k, x) of the slice's values
+    if ((KIND == DIST_DD || KIND == DIST_DPD) && k < k_limit)
+        for (uint32_t m = slice; m < n_multi; m += kVsReduceSlices) {
+            const uint32_t x = multi[3 * m], c0 = multi[3 * m + 1],
+                           nc = multi[3 * m + 2];
+            int d = 0;
+            for (uint32_t c = c0; c < c0 + nc; ++c)
+                d += stage[(size_t)c * stride + k];
+            if (d) img.cnt[0][(size_t)k * dim + x] += d;
+        }
     s_a[slice][kk] = a;
     s_b[slice][kk] = b;
     __syncthreads();

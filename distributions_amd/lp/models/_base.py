@@ -295,6 +295,19 @@ class MixtureBase(object):
         self._handle(shared).score_value(GroupBase._word(shared, value),
                                          scores_accum)
 
+    def score_values(self, shared, values, scores_accum):
+        """score_value for a batch of values in one launch (extension of
+        mixture.hpp:416-425): scores_accum[r, k] accumulates the score of
+        values[r] in group k; float32 [len(values), len(mixture)]"""
+        assert scores_accum.shape == (len(values), len(self))
+        assert scores_accum.dtype == np.float32
+        words = [self.GROUP._word(shared, value) for value in values]
+        self._handle(shared).score_values(words, scores_accum)
+
+    def validate(self, shared):
+        """mixture.hpp:440-444"""
+        self._handle(shared).validate()
+
     def score_data(self, shared):
         return self._handle(shared).score_data()
 

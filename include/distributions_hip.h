@@ -218,6 +218,15 @@ int dist_mixture_score_data_grid(const dist_mixture_t * m,
                                  const dist_shared_t * shareds, size_t n,
                                  float * scores_out);
 
+/* score_value for n values in ONE launch (extension; mixture.hpp:416-425 per
+ * value): scores_accum[r * ld + k] accumulates the score of values[r] in group
+ * k, bit for bit what n calls of dist_mixture_score_value leave.  The per-value
+ * call costs a launch and a round trip (measured with the reference's own
+ * harness: 0.03 cells/us at every K); this is the member to
+ * use between one value and a whole dist_gibbs_t. */
+int dist_mixture_score_values(const dist_mixture_t * m,
+                              const uint32_t * values, size_t n,
+                              float * scores_accum, size_t ld);
 /* Mixture::validate (mixture.hpp:440-444; dd.hpp:447-455 and the other value
  * scorers'): group counts agree, count_sum == sum of counts, and the value
  * scorer's cache equals Scorer::init of the statistics bit for bit

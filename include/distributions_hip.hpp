@@ -335,6 +335,24 @@ struct Model {
                                            scores_accum.data(),
                                            scores_accum.size()));
         }
+        // score_value for a batch of values in one launch (extension):
+        // scores_accum[r * size() + k] accumulates the score of values[r] in
+        // group k -- what values.size() calls of score_value leave, without a
+        // launch and a round trip per value
+        void score_values(const Shared & shared,
+                          const std::vector<Value> & values,
+                          VectorFloat & scores_accum, rng_t &) {
+            const size_t k = dist_mixture_size(handle(shared));
+            if (scores_accum.size() != values.size() * k)
+                throw std::invalid_argument(
+                    "scores_accum.size() != values.size() * size()");
+            std::vector<uint32_t> words(values.size());
+            for (size_t i = 0; i < values.size(); ++i)
+                words[i] = detail::word(values[i]);
+            check(dist_mixture_score_values(handle(shared), words.data(),
+                                            words.size(), scores_accum.data(),
+                                            k));
+        }
         // mixture.hpp:427-431
         float score_data(const Shared & shared, rng_t &) {
             float out = 0;

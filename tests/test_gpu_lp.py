@@ -662,3 +662,30 @@ def test_dpd_mixture_follows_a_shared_that_gains_and_loses_values():
         members[0].append(v)
     assert shared.params.dim <= 12
     compare()
+
+
+@pytest.mark.parametrize("module,EXAMPLE", examples())
+def test_mixture_score_values_is_score_value_in_one_launch(module, EXAMPLE):
+    """dist_mixture_score_values (extension): a batch of values scored
+    against all groups in one launch == one Mixture.score_value per value
+    (mixture.hpp:416-425), bit for bit, accumulating like it"""
+    rng = np.random.default_rng(3)
+    shared = module.Shared.from_dict(EXAMPLE['shared'])
+    values = EXAMPLE['values']
+    mixture = module.Mixture()
+    for value in values:
+        shared.add_value(value)
+    for value in values:
+        mixture.append(module.Group.from_values(shared, [value]))
+    mixture.init(shared)
+    for g, value in enumerate(values):
+        mixture.add_value(shared, (g + 2) % len(mixture), value)
+    batch = [values[i] for i in rng.integers(0, len(values), 37)]
+    noise = rng.normal(size=(len(batch), len(mixture))).astype(np.float32)
+    got = noise.copy()
+    mixture.score_values(shared, batch, got)
+    for r, value in enumerate(batch):
+        want = noise[r].copy()
+        mixture.score_value(shared, value, want)
+        assert np.array_equal(bits(got[r]), bits(want)), (r, value)
+    mixture.validate(shared)

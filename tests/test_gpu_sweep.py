@@ -742,3 +742,45 @@ def test_sequential_init_bit_exact(config, prior_only, empty):
         orc.gibbs_batch(bb, bb + 2048, s2, 0)
     gpu.sweep(0, n, 2048, seed)
     assert_same_state(orc, gpu, "%s after a sweep" % config)
+
+
+@pytest.mark.parametrize("config,dim,big_values", [
+    ("dd", 2, False), ("dd", 16, False), ("dd_skew", 16, False),
+    ("dpd", 3, False), ("bb", None, False), ("bnb", None, False),
+    ("bnb", None, True), ("gp", None, True)])
+def test_fused_batches_with_values_of_several_apply_chunks(config, dim,
+                                                           big_values):
+    """A fused batch's chunks sample the rows they were handed inside
+    k_vs_apply, in the launch in which sibling chunks add up their moves.  A
+    value with more than 4096 rows has several chunks: their count cells are
+    left to k_vs_reduce (a handed-over row must see the cell as the batch
+    found it), and batches with rows beyond the value table of a count model
+    (BetaNegativeBinomial / GammaPoisson values > 255: sums changed in place)
+    keep the separate launches.  Many small groups and a large alpha: rows
+    alone in their group -- the handed-over kind -- in every batch.  Bit for
+    bit against the oracle, and validate() after every sweep."""
+    from distributions_amd import engine
+    n, k = 30000, 700
+    osh, gsh, vals, assign = workloads.make(config, n, k, dim=dim, seed=11)
+    if big_values:      # rows the 256-entry tables do not cover, > one chunk
+        rs = np.random.default_rng(2)
+        where = rs.choice(n, 5000, replace=False)
+        vals[0][where] = rs.integers(256, 4000, where.size).astype(np.uint32)
+    orc = ol.OracleMixture(25.0, 0.5, osh)
+    orc.init_from_assignments(vals, assign, k, 2)
+    gpu = engine.Gibbs(25.0, 0.5, gsh)
+    gpu.set_option("value_sorted", 2)
+    gpu.set_option("device_normalise", 1)
+    gpu.set_option("fused_tables", 1)
+    gpu.load_rows(vals, assign, k, 2)
+    seed = 777
+    st = ol.oracle().orc_rng_seed(seed)
+    for sweep, batch in enumerate([n, 15000, n]):
+        for b in range(0, n, batch):
+            orc.gibbs_batch(b, min(n, b + batch), st, sweep * n)
+        gpu.sweep(0, n, batch, seed, draw_base=sweep * n)
+        assert gpu.validate()["code"] == 0
+        assert_same_state(orc, gpu, "%s sweep %d" % (config, sweep))
+    counts = gpu.core.debug_counts()
+    assert counts["device_normalised"] > 0
+    assert (counts["fused_batches"] > 0) == (not big_values)
