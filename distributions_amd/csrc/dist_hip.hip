@@ -3575,6 +3575,11 @@ struct Gibbs {
                 if (c->off_epoch.p)
                     HIP_CHECK(hipMemsetAsync(c->off_epoch.p, 0,
                                              c->off_epoch.cap * 4, stream()));
+            // ... nor an old entry of the swap-removal log answer to a new
+            // epoch of the same number
+            if (remap_log.p)
+                HIP_CHECK(hipMemsetAsync(remap_log.p, 0, remap_log.cap * 4,
+                                         stream()));
             run_epoch = 1u << 20;
         }
         st.pad = (int)run_epoch;

@@ -301,3 +301,41 @@ def test_more_groups_than_the_lds_paths_hold():
     state = orc.gibbs_sequential(0, 40, st)
     assert gpu.sweep_sequential(0, 40, st) == state
     assert_same_state(orc, gpu, "K=16000 sequential")
+
+
+def test_c5_stream_kernel_where_the_bench_runs_it():
+    """k_vs_stream in the shape bench.py times for BASELINE configs[4]:
+    K = 8192 groups, a Shared of V = 10 000 values, ~100 rows per value and
+    sub-sweep, tiles re-sorted by group (sweep >= 2).  100 000 rows over
+    1 000 of the values; sweep 1 on the GPU (one sub-sweep, table-free
+    kernel), the oracle adopts the state and follows ALL of sweep 2 -- the
+    stream launch itself, not a generic-kernel stand-in -- bit for bit
+    (dpd.hpp:517-543, mixture.hpp:84-119)."""
+    from distributions_amd import engine
+    n, k, dim = 100_000, 8192, 10_000
+    osh, gsh, vals, assign = workloads.make("dpd", n, k, dim=dim)
+    rs = np.random.default_rng(8)
+    vals = [(rs.integers(0, 1000, n) * 10 + 3).astype(np.uint32)]
+    gpu = engine.Gibbs(ALPHA, D, gsh)
+    gpu.load_rows(vals, assign, k, 1)
+    seed = 31337
+    st = ol.oracle().orc_rng_seed(seed)
+    gpu.sweep(0, n, n, seed, draw_base=0)
+    before = gpu.core.debug_counts()
+    assert before["stream_batches"] == 1 and before["other_batches"] == 0
+    assert gpu.validate()["code"] == 0
+    orc = ol.OracleMixture(ALPHA, D, osh)
+    orc.adopt(gpu, vals)
+    for sweep in (1, 2):
+        orc.gibbs_batch(0, n, st, sweep * n)
+        gpu.sweep(0, n, n, seed, draw_base=sweep * n)
+        after = gpu.core.debug_counts()
+        assert after["stream_batches"] == 1 + sweep
+        assert after["other_batches"] == 0
+        assert len(gpu) == len(orc)
+        np.testing.assert_array_equal(gpu.counts(), orc.counts())
+        np.testing.assert_array_equal(gpu.assignments(), orc.assign)
+    for g in range(0, len(orc), 61):      # (a group is 10 001 words)
+        np.testing.assert_array_equal(gpu.get_group(0, g),
+                                      orc.get_group(0, g))
+    assert gpu.validate()["code"] == 0

@@ -20,6 +20,17 @@ def test_differential_fuzz(first):
     assert not failures, failures
 
 
+@pytest.mark.parametrize("first", [900000])
+def test_differential_fuzz_large(first):
+    """tools/fuzz.py large: 20 000 / 60 000 rows, K up to 8192, DPD tables up
+    to 10 000 values, value_stream on or off (k_vs_stream at BASELINE
+    configs[4]'s group count)"""
+    import fuzz
+    failures = [err for err in (fuzz.trial(seed, large=True)
+                                for seed in range(first, first + 10)) if err]
+    assert not failures, failures
+
+
 @pytest.mark.parametrize("seed", [501609])
 def test_fuzz_seeds_that_once_failed(seed):
     """501609: a fused batch whose group set was closed by k_normalise (the

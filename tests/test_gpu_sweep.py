@@ -782,5 +782,7 @@ def test_fused_batches_with_values_of_several_apply_chunks(config, dim,
         assert gpu.validate()["code"] == 0
         assert_same_state(orc, gpu, "%s sweep %d" % (config, sweep))
     counts = gpu.core.debug_counts()
-    assert counts["device_normalised"] > 0
+    # (GammaPoisson's log-product is a float statistic: replayed in row order
+    # between batches, its runs are not device-normalised at all)
+    assert (counts["device_normalised"] > 0) == (config != "gp")
     assert (counts["fused_batches"] > 0) == (not big_values)

@@ -43,12 +43,16 @@ def trial(seed, large=False):
     k = int(min(n, rng.choice([1, 2, 7, 33, 150])))
     if large:   # group sets that cross the kernels' capacity steps
         n = int(rng.choice([20000, 60000]))
-        k = int(rng.choice([250, 1000, 3000]))
+        k = int(rng.choice([250, 1000, 3000, 8192]))
+        if k == 8192:   # (the oracle does 12 k row-updates/s there)
+            n = 20000
     empty = int(rng.integers(1, 4))
     nf = int(rng.choice([1, 1, 1, 2, 3]))
     feats_o, feats_g, vals, desc = [], [], [], []
     for _ in range(nf):
         kind = rng.choice(["dd", "bb", "gp", "nich", "bnb", "dpd"])
+        if large and rng.random() < 0.4:
+            kind = "dpd"
         desc.append(str(kind))
         if kind == "dd":
             dim = int(rng.choice([1, 2, 16, 256]))
@@ -58,6 +62,8 @@ def trial(seed, large=False):
             vals.append(rng.integers(0, dim, n).astype(np.uint32))
         elif kind == "dpd":
             dim = int(rng.choice([3, 40, 700]))
+            if large:   # BASELINE configs[4]'s table: up to 10 000 values
+                dim = int(rng.choice([40, 700, 3000, 10000]))
             betas = rng.dirichlet(np.ones(dim)).astype(np.float32) * 0.9
             feats_o.append(ol.make_shared(ol.DPD, alpha=0.7, betas=betas,
                                           beta0=0.1))

@@ -1,7 +1,7 @@
 # C5 (DPD, V = 10 000, K = 8192): the bench line, one sub-sweep's launches in
 # order, and three counter passes (SQ issue / LDS + VMEM / scalar + misc) of
 # k_vs_stream; on the GPU box:  bash tools/prof_c5.sh
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?not on a gpurun box}"
 B="bench.py --cpu-rows 0 --other-batches= --other-configs= --no-breakdown --steps 3 --warmup 2 --config dpd --groups 8192 --dim 10000"
 python3 $B 2>/dev/null | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value']/1e9, d['ms_per_step'], d['roofline'].get('avg_launch_ms'))"
 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/t_c5 -- python3 $B > /dev/null 2>&1
