@@ -15,7 +15,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def report(path):
     a = np.fromfile(path, dtype=np.uint64).reshape(-1, 6)
-    a = a[a[:, 4] != 0]
+    nonzero = a[:, 4] != 0
+    a = a[nonzero]
     st = a[:, :5].astype(np.int64)
     hw = a[:, 5]
     simd = ((hw >> 4) & 3).astype(np.int64)
@@ -34,6 +35,8 @@ def report(path):
         recent = m & (st[:, 0] >= st[m, 0].max() - 100_000)
         st[recent] -= st[recent, 0].min()
         keep |= recent
+    keep_rows = np.zeros(len(nonzero), bool)
+    keep_rows[np.nonzero(nonzero)[0][keep]] = True
     st, hw, simd, cu, sh, se, xcc, chunks = (
         v[keep] for v in (st, hw, simd, cu, sh, se, xcc, chunks))
     key = (((xcc * 8 + se) * 2 + sh) * 16 + cu) * 4 + simd
@@ -99,6 +102,21 @@ def report(path):
                   np.percentile(per, 90), np.percentile(per, 99),
                   int((per > 2 * np.median(per)).sum()),
                   100.0 * dur[per > 2 * np.median(per)].sum() / dur.sum()))
+    # which CU a workgroup (8 consecutive tile ids) landed on: the dispatch
+    # pattern a static balance of the tile list would have to know
+    ids = np.nonzero(keep_rows)[0]
+    wg = ids // 8
+    cu_of = key // 4
+    first = {}
+    for w, c in zip(wg.tolist(), cu_of.tolist()):
+        first.setdefault(w, c)
+    order = [first[w] for w in sorted(first)][:48]
+    print("  CU (xcc*256+se*32+sh*16+cu) of workgroups 0..47:", order)
+    by_cu = {}
+    for w in sorted(first):
+        by_cu.setdefault(first[w], []).append(w)
+    some = sorted(by_cu)[:6]
+    print("  workgroups per CU (first 6 CUs):", [by_cu[c] for c in some])
     grid = np.linspace(0, span, 11)
     alive = [(int(((st[:, 0] <= t) & (st[:, 4] > t)).sum())) for t in grid]
     print("  waves alive at 0%..100% of the span:", alive)
