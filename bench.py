@@ -879,10 +879,35 @@ def run_rank(args):
             "other_configs": others,
         }
         if sharded_collective(world, args):
+            import torch.distributed as dist
+            # (the communicator the timed region ran on is the job's: a run
+            # that fell back to fewer ranks is not an N-GPU number)
+            assert dist.get_world_size() == world == max(args.gpus, 1) or \
+                args.force_collective, "communicator size != --gpus"
+            sub_sweeps = -(-n // args.batch)
+            avg_us = 1e3 * comm_ms / comm_count if comm_count else None
+            step_us = 1e6 * dt / args.steps
             out["comm"] = {
                 "ranks": world,
-                "all_reduce_avg_us": (1e3 * comm_ms / comm_count
-                                      if comm_count else None),
+                "all_reduce_avg_us": avg_us,
+                # nothing runs under the collective (every kernel
+                # of the next sub-sweep needs its result), so all of it is
+                # exposed: its share of the step, and what the step would
+                # take without it
+                "sub_sweeps_per_step": sub_sweeps,
+                "all_reduce_us_per_step": (avg_us * sub_sweeps
+                                           if avg_us is not None else None),
+                "exposed_fraction_of_step": (avg_us * sub_sweeps / step_us
+                                             if avg_us is not None else None),
+                "weak_scaling_budget_us": {
+                    # 8 * t / (t + L) >= 6 with t = the sub-sweep without
+                    # the collective
+                    "sub_sweep_without_all_reduce_us": (
+                        (step_us - avg_us * sub_sweeps) / sub_sweeps
+                        if avg_us is not None else None),
+                    "max_all_reduce_us_for_6x_at_8": (
+                        (step_us - avg_us * sub_sweeps) / sub_sweeps / 3.0
+                        if avg_us is not None else None)},
                 "timed": comm_count,
                 "words_per_all_reduce": timed_words,
                 "note": "HIP events around the library's in-place all-reduce "

@@ -12,6 +12,7 @@
 #include <cstring>
 #include <memory>
 #include <atomic>
+#include <chrono>
 #include <map>
 #include <mutex>
 #include <set>
@@ -244,6 +245,53 @@ static void check_shared(const dist_shared_t & sh) {
 }
 
 // a reusable scratch of device floats for the per-call API paths
+// DIST_HOST_PROFILE=1: where the host's time per batch goes (nanoseconds per
+// named section, printed when the process ends).  A diagnostic; off, a probe is
+// one load and a branch.
+struct HostProf {
+    static constexpr int kSlots = 24;
+    const char * name[kSlots] = {nullptr};
+    unsigned long long ns[kSlots] = {0}, hits[kSlots] = {0};
+    bool on = getenv("DIST_HOST_PROFILE") != nullptr;
+    // (the first calls of every section -- the ranges' one-time sorts, the
+    // first allocations -- are left out: DIST_HOST_PROFILE=<calls to skip>)
+    unsigned long long skip =
+        getenv("DIST_HOST_PROFILE") ? strtoull(getenv("DIST_HOST_PROFILE"),
+                                               nullptr, 10) : 0;
+    unsigned long long seen[kSlots] = {0};
+    ~HostProf() {
+        if (!on) return;
+        for (int i = 0; i < kSlots; ++i)
+            if (name[i])
+                fprintf(stderr, "[dist host] %-22s %10.3f ms  %8llu calls  %8.2f us each\n",
+                        name[i], ns[i] * 1e-6, hits[i],
+                        hits[i] ? ns[i] * 1e-3 / hits[i] : 0.0);
+    }
+};
+static HostProf & host_prof() {
+    static HostProf p;
+    return p;
+}
+struct HostProbe {
+    int slot;
+    std::chrono::steady_clock::time_point t0;
+    HostProbe(int s, const char * n) : slot(s) {
+        HostProf & p = host_prof();
+        if (!p.on) { slot = -1; return; }
+        p.name[s] = n;
+        t0 = std::chrono::steady_clock::now();
+    }
+    ~HostProbe() {
+        if (slot < 0) return;
+        HostProf & p = host_prof();
+        if (p.seen[slot]++ < p.skip) return;
+        p.ns[slot] += (unsigned long long)std::chrono::duration_cast<
+            std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+        p.hits[slot] += 1;
+    }
+};
+#define HOST_PROBE(slot, name) HostProbe host_probe_##slot(slot, name)
+
 struct Scratch {
     DeviceBuf<float> f;
     DeviceBuf<uint32_t> u;
@@ -2217,9 +2265,10 @@ struct Gibbs {
         template <int KIND>
         void go() {
             const uint32_t nv = (uint32_t)self->vs_nvals();
-            if (fused)
+            if (fused) {
+                HOST_PROBE(8, "      launch_tables");
                 self->launch_tables<KIND>(*P, T, *c);
-            else
+            } else
                 hipLaunchKernelGGL((k_vs_prepare<KIND>), dim3(nv), dim3(kBlock),
                                    T.PA ? (size_t)T.Kpad * 8 : 0,
                                    stream(), *P, T, self->deferred_count.p,
@@ -2232,7 +2281,11 @@ struct Gibbs {
             const VsDefer D{self->deferred.p, self->deferred_count.p,
                             fused ? c->def_counts.p : nullptr, c->chunks.p};
             self->phase_mark(1);
-            self->mark(self->ev0);
+            {
+                HOST_PROBE(10, "      mark(ev0)");
+                self->mark(self->ev0);
+            }
+            HOST_PROBE(11, "      sample launch+mark");
             // a launch that cannot fill the chip spreads out: a wave per
             // workgroup (no band tiles on such launches)
             if (narrow) {
@@ -2417,12 +2470,15 @@ struct Gibbs {
         last_bands = last_prefix = false;
         stream_batches += 1;
         VsStreamLaunch L{this, &P, &c};
+        {
+        HOST_PROBE(7, "    launches (L.go)");
         switch (feats[0]->sh.kind) {
         case DIST_DD: L.go<DIST_DD>(); break;
         case DIST_DPD: L.go<DIST_DPD>(); break;
         case DIST_GP: L.go<DIST_GP>(); break;
         case DIST_BNB: L.go<DIST_BNB>(); break;
         default: L.go<DIST_BB>(); break;
+        }
         }
         launch_deferred(P);
     }
@@ -2501,7 +2557,12 @@ struct Gibbs {
     }
 
     void sample_value_sorted(SweepParams & P) {
-        VsCache & c = vs_get(P.row_begin, P.row_end);
+        VsCache * cp;
+        {
+            HOST_PROBE(6, "    vs_get");
+            cp = &vs_get(P.row_begin, P.row_end);
+        }
+        VsCache & c = *cp;
         phase_mark(0);
         const int Kpad = (K() + kVsUnroll - 1) / kVsUnroll * kVsUnroll;
         const bool fused = sampling_mode != 1 && !use_stream(c)
@@ -2514,6 +2575,7 @@ struct Gibbs {
         if (use_stream(c)) return sample_value_stream(P, c);
         const size_t n = P.row_end - P.row_begin;
         const uint32_t nv = (uint32_t)vs_nvals();
+        HOST_PROBE(13, "    after vs_get");
         // (headroom: K creeps up by a group per batch; no realloc per step)
         vsLA.reserve(grow_capacity((size_t)nv * Kpad), 0);
         vsLB.reserve(grow_capacity((size_t)nv * Kpad), 0);
@@ -2659,13 +2721,21 @@ struct Gibbs {
         timing_this_batch =
             kernel_timing > 0 && timing_tick++ % (uint64_t)kernel_timing == 0;
         upload_maps();
-        SweepParams P = params(r0, r1, seed, draw_base);
+        SweepParams P;
+        {
+            HOST_PROBE(3, "  params()");
+            P = params(r0, r1, seed, draw_base);
+        }
         batch_value_sorted = use_value_sorted(r1 - r0);
         batch_fused = false;
         if (!batch_value_sorted) run_pending_finish();
-        drop_overlapping_caches(r0, r1, batch_value_sorted);
+        {
+            HOST_PROBE(4, "  drop_overlapping");
+            drop_overlapping_caches(r0, r1, batch_value_sorted);
+        }
         if (!batch_value_sorted) flush_assign_pos();
         if (batch_value_sorted) {
+            HOST_PROBE(5, "  sample_value_sorted");
             sample_value_sorted(P);
             vs_batches += 1;
         } else if (r1 - r0 <= 2048 && wave_rows_fit()) {
@@ -2917,8 +2987,11 @@ struct Gibbs {
         const size_t n = batch_end - batch_begin;
         // (the batch's entropy too: a fused batch's chunks sample the rows
         // they were handed)
-        SweepParams P = params(batch_begin, batch_end, batch_seed,
-                               batch_draw_base);
+        SweepParams P;
+        {
+            HOST_PROBE(9, "  params() in apply");
+            P = params(batch_begin, batch_end, batch_seed, batch_draw_base);
+        }
         const size_t lds_sort =
             ((size_t)K() * 2 + kVsApplyBlock / 64 + 4 * kVsApplyRows + 4) * 4;
         const size_t lds_plain = (size_t)K() * 4;
@@ -3021,6 +3094,7 @@ struct Gibbs {
                                        batch_fused ? c.n_multi : 0u,         \
                                        feats[0]->dim());                     \
             } while (0)
+            HOST_PROBE(12, "  apply launches");
             // chunks of several values first (their rows of the staging
             // matrix must be there when k_vs_reduce runs)
             if (c.mixed_chunks) {   // (categorical kinds only, see vs_get)
@@ -3684,13 +3758,22 @@ struct Gibbs {
         async_peek_collect();
         try {
             for (size_t b = r0; b < r1; b += batch) {
-                async_sample(b, std::min(r1, b + batch), seed, draw_base);
-                apply_ints(live_image());
+                {
+                    HOST_PROBE(0, "async_sample");
+                    async_sample(b, std::min(r1, b + batch), seed, draw_base);
+                }
+                {
+                    HOST_PROBE(1, "apply_ints");
+                    apply_ints(live_image());
+                }
                 phase_mark(4);
                 batch_finish_device();
                 phase_mark(5);
             }
-            async_peek();
+            {
+                HOST_PROBE(2, "async_peek");
+                async_peek();
+            }
         } catch (...) {
             async_end(true);
             throw;
