@@ -526,7 +526,7 @@ def run_rank(args):
         g.set_option("device_normalise", args.device_normalise)
         g.set_option("narrow_tiles", args.narrow_tiles)
         g.set_option("kernel_timing", args.kernel_timing)
-        g.set_option("stream_scratch", args.stream_scratch)
+        g.set_option("debug.stream_scratch", args.stream_scratch)
         for item in args.opt:
             key, _, val = item.partition("=")
             g.set_option(key.strip(), int(val))

@@ -5177,7 +5177,21 @@ int dist_gibbs_sharded_device_normalise_ok(const dist_gibbs_t * g,
 }
 int dist_gibbs_set_option(dist_gibbs_t * g, const char * name, int value) {
     return guarded([&] {
-        const std::string key(name);
+        // The public options first (include/distributions_hip.h lists them);
+        // "debug.<name>" are the tests' hooks: each forces a kernel variant
+        // the library otherwise picks by itself, and none changes a result.
+        std::string key(name);
+        const bool hook = key.compare(0, 6, "debug.") == 0;
+        if (hook) key = key.substr(6);
+        static const char * const hooks[] = {
+            "sequential_chain", "running_sums_min_tiles", "narrow_read_ahead",
+            "stream_scratch", "rows_scratch", "rows_scratch_lds_log",
+            "rows_scratch_block", "rows_fold", "apply_stage", "program_all"};
+        bool is_hook = false;
+        for (const char * h : hooks) is_hook = is_hook || key == h;
+        DIST_REQUIRE(hook == is_hook,
+                     is_hook ? "a test hook: spell it debug." + key
+                             : "unknown option debug." + key);
         if (key == "value_sorted") {
             DIST_REQUIRE(value >= 0 && value <= 2, "value_sorted: 0, 1 or 2");
             g->impl->value_sorted_mode = value;

@@ -12,8 +12,8 @@
 // Entropy: sample_beta_safe (random.hpp:87-119) = two std::gamma_distribution
 // <double> draws over rng_t.  The reference calls libstdc++'s <random>; so
 // does this file, over an engine that IS std::minstd_rand0 (one word of
-// state, random_fwd.hpp:34) -- tests/test_dpd_shared.py compares it with
-// oracle/check_libstdcxx.cc, which uses std::default_random_engine itself.
+// state, random_fwd.hpp:34) -- tests/test_dpd_shared.py compares it with a
+// probe that uses std::default_random_engine itself.
 #include <algorithm>
 #include <cstring>
 #include <random>

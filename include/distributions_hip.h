@@ -531,66 +531,82 @@ int dist_gibbs_validate(dist_gibbs_t * g, dist_validate_report_t * report);
 int dist_gibbs_sharded_device_normalise_ok(const dist_gibbs_t * g,
                                            size_t n_batches,
                                            size_t batch_rows, int * ok_out);
-/* options: "value_sorted" = 0 (generic kernel only), 1 (auto, default),
- * 2 (value-sorted kernel whenever the feature list allows it);
- * "sequential_chain" = 1 (device-resident chain kernel, default) or 0;
- * "running_sums_min_tiles" = launches of at least this many value tiles use
- * the per-value running sums and band tiles (default 2048);
- * "value_stream" = 0 (per-value tables always), 1 (auto: the table-free
- * kernel where a value has about one tile per batch), 2 (always);
- * "narrow_tiles" = 0 (never), 1 (auto, default: launches too small to fill
- * the chip take tiles of 64 rows and their vectors from LDS), 2 (whenever
- * the vectors fit); "narrow_read_ahead" = 0 (by launch size), 4 or 8 (that
- * kernel's instance);
- * "stream_scratch" = 1 (default: the table-free kernel keeps a tile's
- * likelihoods -- one vector for the rows of the value's arg-max group, one
- * for the others -- between its two passes in two scratch rows) or 0;
- * "kernel_timing" = n: HIP events around the score+sample kernel of every
- * n-th batch feed dist_gibbs_kernel_stats (1, the default: every batch; 0:
- * none; two events cost a batch some 8 us);
- * "device_normalise" = 1 or 2 (the same; 2 is the default): sweeps that stay
- * on the value-sorted path with integer statistics normalise the group set on
- * the device and run without a host round trip per batch; such a run stays
- * open when dist_gibbs_sweep / dist_gibbs_sweep_sharded return (the next
- * sweep of the same tiling goes on with it, any other call pulls the host's
- * mirrors first), so they return before the device has finished.  An open run
- * is queued on the stream of the thread that swept; a call from another
- * thread drains that stream before it reads the state.  0: never.
- * "sharded_device_normalise" = 1 (default) lets dist_gibbs_sweep_sharded do
- * the same: the ranks agree among themselves, on EVERY call (one all-reduce
- * of a flag), whether their open runs go on -- a rank whose run was settled
- * in between by any other call makes all of them open a new one -- and, when
- * a run is opened, whether every one of them can; 0 keeps this rank, and so
- * all of them, on the host-normalised loop.  Calls between two passes need
- * not be the same on every rank;
- * "fused_tables" = 1 (default): a device-normalised run of the value-sorted
- * path spends ONE launch between a batch's statistics and the next batch's
- * sampling (k_vs_tables: group set, caches and per-value tables), and the
- * rows a tile hands over are sampled by k_vs_apply; 0: k_normalise,
- * k_batch_finish, k_vs_prepare and k_rows_wave as launches of their own;
- * "rows_scratch" (general rows: any feature list the value-sorted kernels do
- * not take) = 3 (default: k_rows_scratch) or 0 (k_sweep_program, the kernel
- * that feature lists beyond k_rows_scratch's parameter table take anyway);
- * "rows_scratch_lds_log" = 1 (default: FastLog's table in LDS) or 0;
- * "rows_scratch_block" = threads per workgroup of that kernel (512);
- * "rows_fold" = 1 (default: the discrete features before the first
- * real-valued one are folded into a per-(joint value, group) table and the
- * rows sorted by joint value, where at least 128 rows share a value),
- * 2 (whenever the joint domain is no larger than the batch), 0 (never);
- * "program_all" = 1 (default: every batch outside the value-sorted path is
- * scored through the per-batch score program) or 0;
- * "apply_stage" = 1 (default: general rows' integer statistics summed in LDS
- * as one image per workgroup where the image fits) or 0.
- * None of the above changes a result.
- * "float_stats" = 0 (default: the ordered replay) or 1 (merged sums, see
- * dist_gibbs_float_delta_words): tolerance-level.
- * "sampling" = 0 (default, the line of record: the reference's float
- * operations in the reference's order, bit-identical assignments) or 1: SCAN
- * SAMPLING, tolerance-level -- the same scores bit for bit and the same engine
- * step per row, but the softmax and its inverse CDF by a running log-sum-exp
- * and cumulative sums (random.hpp:316-333 in distribution; the index can
- * differ from the exact mode's where u * total falls within float rounding of
- * a boundary between two groups).
+/* Options.  Ten are public; each names the test that exercises it.  None but
+ * the last two changes a result.
+ *
+ *  "value_sorted"  0 generic kernels only | 1 auto (default) | 2 the
+ *      value-sorted kernels whenever the feature list allows (ONE feature with
+ *      a small value domain).  tests/test_gpu_sweep.py::test_batch_sweeps_bit_exact
+ *  "value_stream"  0 per-value tables always | 1 auto (default: the table-free
+ *      kernel k_vs_stream where a value has about one tile per batch -- C5) |
+ *      2 always.  test_gpu_sweep.py::test_stream_kernel_on_full_tiles,
+ *      test_gpu_fullsize.py::test_c5_stream_kernel_where_the_bench_runs_it
+ *  "narrow_tiles"  0 never | 1 auto (default: launches too small to fill the
+ *      chip take tiles of 64 rows, vectors from LDS: k_vs_narrow) | 2 whenever
+ *      the vectors fit.  test_gpu_sweep.py::test_batch_sweeps_bit_exact (modes 4, 5)
+ *  "device_normalise"  1 (default; 2 accepted) sweeps that stay on the
+ *      value-sorted path with integer statistics normalise the group set on
+ *      the device, no host round trip per batch; such a run stays OPEN when
+ *      dist_gibbs_sweep / dist_gibbs_sweep_sharded return (the next sweep of
+ *      the same tiling goes on with it, any other call pulls the host's
+ *      mirrors first), so they return before the device has finished.  An
+ *      open run is queued on the stream of the thread that swept; a call from
+ *      another thread drains that stream before it reads the state.  0 never.
+ *      test_gpu_sweep.py::test_device_side_normalisation_under_group_churn
+ *  "sharded_device_normalise"  1 (default) lets dist_gibbs_sweep_sharded do the
+ *      same: the ranks agree among themselves, on EVERY call (one all-reduce
+ *      of a flag), whether their open runs go on -- a rank whose run was
+ *      settled in between by any other call makes all of them open a new one
+ *      -- and, when a run is opened, whether every one of them can; 0 keeps
+ *      this rank, and so all of them, on the host-normalised loop.  Calls
+ *      between two passes need not be the same on every rank.
+ *      tests/test_gpu_native_comm.py
+ *  "fused_tables"  1 (default) a device-normalised run spends ONE launch between
+ *      a batch's statistics and the next batch's sampling (k_vs_tables: group
+ *      set, caches, per-value tables) and the rows a tile hands over are
+ *      sampled by k_vs_apply | 0 k_normalise, k_batch_finish, k_vs_prepare and
+ *      k_rows_wave as launches of their own -- the path every batch takes
+ *      that is NOT part of a device-normalised run of integer statistics
+ *      (float statistics: GammaPoisson, NormalInverseChiSq; LowEntropy; more
+ *      than 8128 groups; apply chunks of several values; the table-free
+ *      kernel).  test_device_side_normalisation_under_group_churn,
+ *      test_fused_batches_with_values_of_several_apply_chunks
+ *  "kernel_timing"  n: HIP events around the score+sample kernel of every n-th
+ *      batch feed dist_gibbs_kernel_stats (1, the default: every batch; 0
+ *      none; two events cost a batch some 8 us).
+ *      test_gpu_sweep.py::test_kernel_timing_samples_every_nth_batch
+ *  "phase_timing"  1: events at a sub-sweep's phase boundaries feed
+ *      dist_gibbs_phase_stats (bench.py's step_breakdown); default 0.
+ *      tests/test_bench_cli.py
+ *  "float_stats"  0 (default) float statistics by the ordered replay | 1 merged
+ *      sums (dist_gibbs_float_delta_words): TOLERANCE-LEVEL.
+ *      tests/test_gpu_scan.py, tests/test_gpu_fullsize_modes.py
+ *  "sampling"  0 (default, the line of record: the reference's float
+ *      operations in the reference's order, bit-identical assignments) | 1 SCAN
+ *      SAMPLING, TOLERANCE-LEVEL: the same scores bit for bit and the same
+ *      engine step per row, but the softmax and its inverse CDF by a running
+ *      log-sum-exp and cumulative sums (random.hpp:316-333 in distribution;
+ *      the index can differ where u * total falls within float rounding of a
+ *      boundary between two groups).  tests/test_gpu_scan.py,
+ *      tests/test_gpu_fullsize_modes.py
+ *
+ * Test hooks, spelled "debug.<name>": each forces a kernel variant the library
+ * otherwise picks by itself, so that the differential fuzz (tools/fuzz.py,
+ * tests/test_gpu_fuzz.py) reaches every variant at every size; not for
+ * callers, and none changes a result.  sequential_chain (1 the device-resident
+ * chain kernel | 0 rows as batches of one), running_sums_min_tiles (launches of
+ * at least this many tiles use the per-value running sums and band tiles:
+ * 2048), narrow_read_ahead (k_vs_narrow's instance: 0 by launch size | 4 | 8
+ * float4s), stream_scratch (k_vs_stream keeps a tile's likelihoods between its
+ * passes: 1 | 0 computes them again), rows_scratch (general rows: 3
+ * k_rows_scratch | 0 k_sweep_program, which feature lists beyond 64 parameter
+ * slots take anyway), rows_scratch_lds_log (FastLog's table in LDS: 1 | 0),
+ * rows_scratch_block (threads per workgroup of that kernel: 512), rows_fold
+ * (leading discrete features folded into a per-(joint value, group) table:
+ * 1 where 128 rows share a value | 2 whenever the joint domain fits | 0),
+ * apply_stage (general rows' integer statistics summed in LDS: 1 | 0),
+ * program_all (every batch outside the value-sorted path through the
+ * per-batch score program: 1 | 0).
  */
 int dist_gibbs_set_option(dist_gibbs_t * g, const char * name, int value);
 /* how many batches each score+sample kernel has served */

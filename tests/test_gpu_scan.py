@@ -35,7 +35,7 @@ def engine_for(config, n, k, sampling, fold=1, seed=workloads.SEED,
     gpu = engine.Gibbs(1.0, 0.2, gsh)
     gpu.set_option("value_sorted", value_sorted)
     gpu.set_option("sampling", sampling)
-    gpu.set_option("rows_fold", fold)
+    gpu.set_option("debug.rows_fold", fold)
     gpu.load_rows(vals, assign, k, 1)
     return gpu, vals, assign
 

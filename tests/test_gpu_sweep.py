@@ -31,7 +31,7 @@ def both(config, n, k, alpha, d, empty=1, dim=None, seed=workloads.SEED,
         gpu.set_option("value_sorted", min(mode, 2))
         gpu.set_option("value_stream", 2 if mode == 3 else 0)
         gpu.set_option("narrow_tiles", 2 if mode in (4, 5) else 0)
-        gpu.set_option("narrow_read_ahead", {4: 8, 5: 4}.get(mode, 0))
+        gpu.set_option("debug.narrow_read_ahead", {4: 8, 5: 4}.get(mode, 0))
     gpu.load_rows(vals, assign, k, empty)
     return orc, gpu
 
@@ -139,10 +139,10 @@ def test_general_rows_scratch_kernel_bit_exact(config, scratch, lds_log, block,
     orc.init_from_assignments(vals, assign, k, 1)
     gpu = engine.Gibbs(1.0, 0.2, gsh)
     gpu.set_option("value_sorted", 0)
-    gpu.set_option("rows_scratch", scratch)
-    gpu.set_option("rows_scratch_lds_log", lds_log)
-    gpu.set_option("rows_scratch_block", block)
-    gpu.set_option("rows_fold", fold)
+    gpu.set_option("debug.rows_scratch", scratch)
+    gpu.set_option("debug.rows_scratch_lds_log", lds_log)
+    gpu.set_option("debug.rows_scratch_block", block)
+    gpu.set_option("debug.rows_fold", fold)
     gpu.load_rows(vals, assign, k, 1)
     seed = 4242
     st = ol.oracle().orc_rng_seed(seed)
@@ -290,7 +290,7 @@ def test_value_sorted_running_sums(config, dim, k):
     n = 60000
     orc, gpu = both(config, n, k, 1.0, 0.1, dim=dim)
     gpu.set_option("value_sorted", 2)
-    gpu.set_option("running_sums_min_tiles", 0)
+    gpu.set_option("debug.running_sums_min_tiles", 0)
     seed = 77
     st = ol.oracle().orc_rng_seed(seed)
     for sweep in range(3):
@@ -361,7 +361,7 @@ def test_device_side_normalisation_under_group_churn(config, dim, stream,
         # (tables: one engine through k_vs_narrow, the others through the
         # 128-row tiles)
         gpu.set_option("narrow_tiles", 2 * fused)
-        gpu.set_option("narrow_read_ahead", 4)
+        gpu.set_option("debug.narrow_read_ahead", 4)
         gpu.load_rows(vals, assign, k, empty)
         engines.append(gpu)
     seed = 4242
@@ -441,8 +441,8 @@ def test_randomised_configurations():
         gpu.set_option("value_sorted", int(rng.choice([0, 1, 2])))
         gpu.set_option("value_stream", int(rng.choice([0, 1, 2])))
         gpu.set_option("narrow_tiles", int(rng.choice([0, 1, 2])))
-        gpu.set_option("narrow_read_ahead", int(rng.choice([0, 4, 8])))
-        gpu.set_option("stream_scratch", int(rng.choice([0, 1])))
+        gpu.set_option("debug.narrow_read_ahead", int(rng.choice([0, 4, 8])))
+        gpu.set_option("debug.stream_scratch", int(rng.choice([0, 1])))
         gpu.set_option("device_normalise", int(rng.choice([0, 1, 2])))
         gpu.load_rows(vals, assign, k, empty)
         seed = int(rng.integers(1, 2 ** 31))

@@ -112,23 +112,23 @@ def trial(seed, large=False):
     mode = int(rng.choice([0, 1, 2]))
     gpu.set_option("value_sorted", mode)
     if rng.integers(0, 2):   # the per-value running sums, also on small launches
-        gpu.set_option("running_sums_min_tiles", 0)
+        gpu.set_option("debug.running_sums_min_tiles", 0)
     # per-value tables or the table-free kernel (and its packed apply chunks)
     gpu.set_option("value_stream", int(rng.choice([0, 1, 2])))
     gpu.set_option("narrow_tiles", int(rng.choice([0, 1, 2])))
-    gpu.set_option("narrow_read_ahead", int(rng.choice([0, 4, 8])))
-    gpu.set_option("stream_scratch", int(rng.choice([0, 1])))
+    gpu.set_option("debug.narrow_read_ahead", int(rng.choice([0, 4, 8])))
+    gpu.set_option("debug.stream_scratch", int(rng.choice([0, 1])))
     gpu.set_option("device_normalise", int(rng.choice([0, 1, 2])))
     gpu.set_option("fused_tables", int(rng.choice([0, 1, 1, 1])))
     # the general-row kernels: round 2's, k_rows_scratch with the likelihoods
     # / scores as well in its scratch, without a scratch; LDS or global
     # FastLog table; workgroup size; folded leading features; staged apply
-    gpu.set_option("rows_scratch", int(rng.choice([0, 3, 3, 3])))
-    gpu.set_option("rows_scratch_lds_log", int(rng.choice([0, 1])))
-    gpu.set_option("rows_scratch_block", int(rng.choice([64, 256, 512, 1024])))
-    gpu.set_option("rows_fold", int(rng.choice([0, 1, 2, 2])))
-    gpu.set_option("apply_stage", int(rng.choice([0, 1])))
-    gpu.set_option("program_all", int(rng.choice([0, 1, 1])))
+    gpu.set_option("debug.rows_scratch", int(rng.choice([0, 3, 3, 3])))
+    gpu.set_option("debug.rows_scratch_lds_log", int(rng.choice([0, 1])))
+    gpu.set_option("debug.rows_scratch_block", int(rng.choice([64, 256, 512, 1024])))
+    gpu.set_option("debug.rows_fold", int(rng.choice([0, 1, 2, 2])))
+    gpu.set_option("debug.apply_stage", int(rng.choice([0, 1])))
+    gpu.set_option("debug.program_all", int(rng.choice([0, 1, 1])))
     gpu.load_rows(vals, assign, k, empty)
     what = "seed %d: n=%d k=%d empty=%d feats=%s mode=%d %s" % (
         seed, n, k, empty, "+".join(desc), mode,
@@ -188,15 +188,15 @@ def trial_collective(seed):
     gpu = engine.Gibbs(alpha, d, gsh)
     gpu.set_option("value_sorted", int(rng.choice([0, 1, 2])))
     if rng.integers(0, 2):
-        gpu.set_option("running_sums_min_tiles", 0)
+        gpu.set_option("debug.running_sums_min_tiles", 0)
     gpu.set_option("value_stream", int(rng.choice([0, 1, 2])))
     gpu.set_option("narrow_tiles", int(rng.choice([0, 1, 2])))
-    gpu.set_option("narrow_read_ahead", int(rng.choice([0, 4, 8])))
-    gpu.set_option("stream_scratch", int(rng.choice([0, 1])))
+    gpu.set_option("debug.narrow_read_ahead", int(rng.choice([0, 4, 8])))
+    gpu.set_option("debug.stream_scratch", int(rng.choice([0, 1])))
     gpu.set_option("fused_tables", int(rng.choice([0, 1, 1])))
-    gpu.set_option("rows_scratch", int(rng.choice([0, 3])))
-    gpu.set_option("rows_fold", int(rng.choice([0, 1, 2])))
-    gpu.set_option("apply_stage", int(rng.choice([0, 1])))
+    gpu.set_option("debug.rows_scratch", int(rng.choice([0, 3])))
+    gpu.set_option("debug.rows_fold", int(rng.choice([0, 1, 2])))
+    gpu.set_option("debug.apply_stage", int(rng.choice([0, 1])))
     gpu.load_rows_torch(cols, a.clone(), k, 2)
     sharded = engine.ShardedGibbs(gpu.core, n, 0, device=dev,
                                   force_collective=True, columns=cols,
