@@ -42,7 +42,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s
 SIMDS = 1024            # 256 CUs x 4 SIMDs
 CLOCK_GHZ = 2.4         # MI355X_MICROARCH.md: max clock
-COUNTERS_FILE = "r4_counters.json"   # tools/counters.py, this round's sources
+COUNTERS_FILE = "r5_counters.json"   # tools/counters.py, this round's sources
 # what one wave64 vector instruction costs its SIMD when issued back to back,
 # by class (tools/microbench/valu_issue.hip, profiles/r2_final_valu_issue.txt)
 ISSUE_CYCLES_PACKED = 4.19   # v_pk_*, also shifts and compares
@@ -211,7 +211,7 @@ def source_hash():
 
 def committed_counters(kernel):
     """Per-launch counter means of `kernel` from the committed rocprofv3
-    --pmc passes (profiles/r4_counters.json, written by tools/counters.py on
+    --pmc passes (profiles/r5_counters.json, written by tools/counters.py on
     the GPU box from separate passes of this command).  None when there is no
     record or the kernel sources changed since it was taken."""
     path = os.path.join(ROOT, "profiles", COUNTERS_FILE)

@@ -3598,13 +3598,33 @@ struct Gibbs {
     // all ranks agreed on when it was opened
     size_t sharded_batches = 0, sharded_batch_rows = 0;
     DeviceBuf<int> agree_flag;
-    void async_begin(size_t n_first) {
+    // Is [r0, r1) a range whose batches the fused launch takes, as far as
+    // that is known before a run is open?  (ADVICE: a long run sizes every
+    // OTHER path by its inflated bound on the group count -- k_vs_prepare's
+    // tables, k_vs_apply's LDS, the staging matrix -- so it is only opened
+    // where the first range has been seen to take the fused launch: a range
+    // that was never sorted yet, i.e. a first sweep, gets a short run.)
+    bool vs_expect_fused(size_t r0, size_t r1) const {
+        if (!fused_tables_mode || sampling_mode != 0 || any_float_stats())
+            return false;
+        for (size_t i = 0; i < vs_ranges.size(); ++i) {
+            if (vs_ranges[i].first != r0 || vs_ranges[i].second != r1) continue;
+            const VsCache & c = *vs_cache[i];
+            const int kind0 = feats[0]->sh.kind;
+            if (c.mixed_chunks || use_stream(c)) return false;
+            if ((kind0 == DIST_BNB || kind0 == DIST_GP) && c.n_other)
+                return false;
+            return (size_t)c.n_chunks * kTablesMaxK <= ((size_t)1 << 22);
+        }
+        return false;
+    }
+    void async_begin(size_t n_first, bool expect_fused = true) {
         const int K0 = K();
         const size_t ne = (size_t)py.n_empty;
         size_t n_batches = kAsyncSweeps * n_first;
         // (only where the fused launch will run: every other path sizes its
         // work by the run's bound -- the scan mode's prefix tables, for one)
-        if (fused_tables_mode && sampling_mode == 0
+        if (expect_fused && fused_tables_mode && sampling_mode == 0
             && (size_t)K0 + n_first * ne + 64 <= kTablesMaxK) {
             const size_t room = ((size_t)kTablesMaxK - 64 - (size_t)K0) / ne;
             const size_t sweeps =
@@ -3753,7 +3773,14 @@ struct Gibbs {
     void sweep_async(size_t r0, size_t r1, size_t batch, uint32_t seed,
                      uint64_t draw_base) {
         const size_t n_batches = (r1 - r0 + batch - 1) / batch;
-        if (!async_active) async_begin(n_batches);   // else: it goes on
+        if (!async_active) {   // else: it goes on
+            // (the first range sorted now rather than by its first batch:
+            // what it looks like decides how long a run is opened)
+            const size_t e0 = std::min(r1, r0 + batch);
+            drop_overlapping_caches(r0, e0, true);
+            vs_get(r0, e0);
+            async_begin(n_batches, vs_expect_fused(r0, e0));
+        }
         async_left -= n_batches;
         async_peek_collect();
         try {
@@ -4925,6 +4952,9 @@ int dist_gibbs_sweep_sharded(dist_gibbs_t * g, dist_comm_t * c,
                        && s.async_eligible_sharded(n_batches, batch_rows)
                    ? 1 : 0);
             if (on_device) {
+                // (the run's bound on the group count fixes the delta
+                // image's layout: the same on every rank, so not a function
+                // of what this rank's ranges look like)
                 s.async_begin(n_batches);
                 s.sharded_batches = n_batches;
                 s.sharded_batch_rows = batch_rows;
