@@ -1411,17 +1411,20 @@ struct Gibbs {
         words.reserve(std::max<size_t>(stat_words(), 1), 0);
         HIP_CHECK(hipMemsetAsync(words.p, 0, stat_words() * sizeof(int32_t),
                                  stream()));
+        // (rows beyond assigned_rows have no group yet: load_rows_unassigned
+        // / init_sequential, examples/mixture/main.py:227-232)
+        const size_t rows = assigned_rows;
         DeviceBuf<uint32_t> packed;
-        packed.reserve(std::max<size_t>(n_rows, 1), 0);
+        packed.reserve(std::max<size_t>(rows, 1), 0);
         DeviceBuf<unsigned long long> out;
         out.reserve(2, 0);
         const unsigned long long init[2] = {~0ull, 0ull};
         out.upload(init, 2);
-        SweepParams P = params(0, n_rows, 1, 0);
+        SweepParams P = params(0, rows, 1, 0);
         StatImage recount = word_image(words.p);
-        if (n_rows)
-            LAUNCH(k_validate_rows, n_rows, P, recount, d_g2p_ptr,
-                   (uint32_t)tracker.g2p.size(), n_rows, packed.p, out.p,
+        if (rows)
+            LAUNCH(k_validate_rows, rows, P, recount, d_g2p_ptr,
+                   (uint32_t)tracker.g2p.size(), rows, packed.p, out.p,
                    out.p + 1);
         StatImage live = live_image();
         if (Kn) LAUNCH(k_validate_compare, Kn, P, live, recount, -1, Kn, out.p);

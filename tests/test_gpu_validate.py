@@ -81,3 +81,23 @@ def test_mixture_validate():
         mixture.remove_group(shared, 0)
         mixture.add_group(shared)
         mixture._core.validate()
+
+
+def test_validate_during_sequential_initialisation():
+    """rows without a group yet (load_rows_unassigned, then init_sequential
+    over a prefix: examples/mixture/main.py:227-232) are not the recount's"""
+    import oracle_lib as ol
+    from distributions_amd import engine
+    n = 2000
+    osh, gsh, vals, assign = workloads.make("gp_nich", n, 1, seed=2)
+    gpu = engine.Gibbs(1.0, 0.1, gsh)
+    gpu.load_rows_unassigned(vals, empty_groups=1)
+    report = gpu.validate()
+    assert report["code"] == 0 and report["rows_assigned"] == 0
+    state = ol.oracle().orc_rng_seed(5)
+    state = gpu.init_sequential(0, 700, state)
+    report = gpu.validate()
+    assert report["code"] == 0 and report["rows_assigned"] == 700
+    gpu.init_sequential(700, n, state)
+    report = gpu.validate()
+    assert report["code"] == 0 and report["rows_assigned"] == n
