@@ -1293,15 +1293,16 @@ cdef class GibbsEngine:
 
     def debug_counts(self):
         """dict of the engine's path diagnostics (dist_gibbs_debug_counts)"""
-        cdef uint64_t out[14]
-        check(dist_gibbs_debug_counts(self.ptr, out, 14))
+        cdef uint64_t out[15]
+        check(dist_gibbs_debug_counts(self.ptr, out, 15))
         return {"value_sorted_batches": out[0], "other_batches": out[1],
                 "band_launches": out[2], "running_sum_launches": out[3],
                 "band_values_last": out[4], "handed_over_last": out[5],
                 "stream_batches": out[6], "device_normalised": out[7],
                 "narrow_batches": out[8], "scratch_batches": out[9],
                 "fold_batches": out[10], "scan_batches": out[11],
-                "merged_batches": out[12], "fused_batches": out[13]}
+                "merged_batches": out[12], "fused_batches": out[13],
+                "resumed_runs": out[14]}
 
     def set_option(self, name, int value):
         check(dist_gibbs_set_option(self.ptr, name.encode(), value))

@@ -1658,6 +1658,7 @@ struct Gibbs {
         // largest value of each discrete feature (validation; sizes the
         // value tables of the count-valued ones)
         max_value.assign((size_t)F(), 0);
+        resume_bound = resume_left = 0;
         vs_cache.clear();
         vs_ranges.clear();
         vs_last = 0;
@@ -2723,6 +2724,9 @@ struct Gibbs {
         if (r0 == r1) return;
         timing_this_batch =
             kernel_timing > 0 && timing_tick++ % (uint64_t)kernel_timing == 0;
+        // (a host-driven batch: whatever sharded run was closed before it is
+        // not taken up again)
+        if (!async_active) resume_bound = resume_left = 0;
         upload_maps();
         SweepParams P;
         {
@@ -3600,6 +3604,15 @@ struct Gibbs {
     // a sharded run (dist_gibbs_sweep_sharded) goes on only with the tiling
     // all ranks agreed on when it was opened
     size_t sharded_batches = 0, sharded_batch_rows = 0;
+    // A sharded run this rank closed ITSELF between two passes (any look at
+    // the state does: settle) can be taken up again with the bound on the
+    // group count and the batches it had left -- to its peers, who kept
+    // theirs open, it then looks like a run that went on: the same collectives
+    // of the same size (stat_words() follows the bound), and the same results
+    // (closing a run never changes one).  So whether open runs go on needs
+    // no word between the ranks, and no pass begins with a host round trip.
+    size_t resume_bound = 0, resume_left = 0;   // 0: nothing to take up
+    uint64_t resumed_runs = 0;
     DeviceBuf<int> agree_flag;
     // Is [r0, r1) a range whose batches the fused launch takes, as far as
     // that is known before a run is open?  (ADVICE: a long run sizes every
@@ -3621,7 +3634,9 @@ struct Gibbs {
         }
         return false;
     }
-    void async_begin(size_t n_first, bool expect_fused = true) {
+    int async_bound_K = 0;   // the open run's bound on the group count
+    void async_begin(size_t n_first, bool expect_fused = true,
+                     size_t forced_bound = 0, size_t forced_left = 0) {
         const int K0 = K();
         const size_t ne = (size_t)py.n_empty;
         size_t n_batches = kAsyncSweeps * n_first;
@@ -3637,6 +3652,7 @@ struct Gibbs {
         if (!async_bound_fits((size_t)K0 + n_batches * ne)
             || n_batches > kAsyncMaxBatches)
             n_batches = n_first;
+        if (forced_bound) n_batches = forced_left;   // (a run taken up again)
         async_left = n_batches;
         run_batches = 0;
         K_seen = K0;
@@ -3645,7 +3661,12 @@ struct Gibbs {
             (void)hipEventSynchronize(peek_event);
             peek_pending = false;
         }
-        const int bound = K0 + (int)n_batches * py.n_empty;
+        const int bound = forced_bound ? (int)forced_bound
+                                       : K0 + (int)n_batches * py.n_empty;
+        DIST_REQUIRE((size_t)K0 + n_batches * ne <= (size_t)bound,
+                     "internal: a run's bound below what its batches can grow");
+        async_bound_K = bound;
+        resume_bound = resume_left = 0;
         py.reserve(bound);
         for (auto & s : feats) s->reserve(bound);
         if ((size_t)bound > base.cap || (size_t)bound > base_single.cap) {
@@ -3761,6 +3782,9 @@ struct Gibbs {
             async_active = false;
             throw;
         }
+        // (a sharded run: remember what it had left, see resume_bound)
+        resume_bound = sharded_batches ? (size_t)async_bound_K : 0;
+        resume_left = sharded_batches ? async_left : 0;
         async_active = false;
         collect_comm_timing();
         for (size_t i = 0; i < async_rows.size(); ++i) {
@@ -3783,6 +3807,7 @@ struct Gibbs {
             drop_overlapping_caches(r0, e0, true);
             vs_get(r0, e0);
             async_begin(n_batches, vs_expect_fused(r0, e0));
+            sharded_batches = sharded_batch_rows = 0;   // (not a sharded run)
         }
         async_left -= n_batches;
         async_peek_collect();
@@ -3906,6 +3931,7 @@ struct Gibbs {
     }
     void sweep_sequential(size_t r0, size_t r1, uint32_t * rng_state) {
         DIST_REQUIRE(!batch_open, "previous batch not finished");
+        resume_bound = resume_left = 0;
         DIST_REQUIRE(r0 <= r1 && r1 <= n_rows, "bad row range");
         DIST_REQUIRE(r1 <= assigned_rows || r0 == r1,
                      "rows without a group yet: init_sequential first");
@@ -4811,6 +4837,7 @@ int dist_gibbs_export_stats_dev(const dist_gibbs_t * g, int32_t * stats_dev) {
 int dist_gibbs_import_stats_dev(dist_gibbs_t * g, const int32_t * stats_dev) {
     return guarded([&] {
         g->impl->copy_stats(const_cast<int32_t *>(stats_dev), false);
+        g->impl->resume_bound = g->impl->resume_left = 0;
         g->impl->pairs_ticket = 0;   // whatever a batch published is stale now
         g->impl->refresh_host_counts();
         g->impl->rebuild_caches();
@@ -4942,14 +4969,36 @@ int dist_gibbs_sweep_sharded(dist_gibbs_t * g, dist_comm_t * c,
             e.agree_flag.download(&mine, 1);
             return mine != 0;
         };
-        bool on_device = agree(
-            *open, open->async_active && !open->batch_open
-                       && open->sharded_batches == n_batches
-                       && open->sharded_batch_rows == batch_rows
-                       && n_batches <= open->async_left
-                   ? 1 : 0);   // the open runs go on, everywhere or nowhere
+        // Does the ranks' run go on?  Decided by every rank for itself, from
+        // what is the same on all of them: the tiling of this call and of the
+        // run, and the batches the run has left.  A rank that kept its run
+        // open goes on with it; a rank that closed it between the passes --
+        // any look at its state does -- takes it up again with the same bound
+        // and the same batches left (resume_bound): its collectives are the
+        // ones its peers issue.  No word between the ranks, no host round
+        // trip at the start of a pass (round 4 agreed on every call: 50 us
+        // per pass, profiles/r5_collective_pass.txt).  Only when the run is
+        // used up, on every rank at the same call, do they agree on a new one.
+        const bool tiling_same = open->sharded_batches == n_batches
+                                 && open->sharded_batch_rows == batch_rows;
+        bool on_device = false;
+        if (open->async_active && !open->batch_open && tiling_same
+            && n_batches <= open->async_left) {
+            on_device = true;
+        } else if (!open->async_active && !open->batch_open && tiling_same
+                   && open->resume_bound && n_batches <= open->resume_left
+                   && (size_t)open->K() + open->resume_left
+                              * (size_t)open->py.n_empty <= open->resume_bound
+                   && open->sharded_device_normalise
+                   && open->async_eligible_sharded(n_batches, batch_rows)) {
+            const size_t bound = open->resume_bound, left = open->resume_left;
+            open->async_begin(n_batches, true, bound, left);
+            open->resumed_runs += 1;
+            on_device = true;
+        }
         if (!on_device) {
             Gibbs & s = *g->impl;   // (settles an open run)
+            s.resume_bound = s.resume_left = 0;
             on_device = agree(
                 s, s.sharded_device_normalise
                        && s.async_eligible_sharded(n_batches, batch_rows)
@@ -4961,6 +5010,8 @@ int dist_gibbs_sweep_sharded(dist_gibbs_t * g, dist_comm_t * c,
                 s.async_begin(n_batches);
                 s.sharded_batches = n_batches;
                 s.sharded_batch_rows = batch_rows;
+            } else {
+                s.sharded_batches = s.sharded_batch_rows = 0;
             }
         }
         Gibbs & e = *open;
@@ -5342,11 +5393,11 @@ int dist_gibbs_path_counts(const dist_gibbs_t * g, uint64_t * value_sorted,
 int dist_gibbs_debug_counts(dist_gibbs_t * g, uint64_t * out, size_t n) {
     return guarded([&] {
         Gibbs & e = *g->impl;
-        uint64_t v[14] = {e.vs_batches, e.generic_batches, e.band_batches,
+        uint64_t v[15] = {e.vs_batches, e.generic_batches, e.band_batches,
                           e.prefix_batches, 0, 0, e.stream_batches,
                           e.async_batches, e.narrow_batches,
                           e.scratch_batches, e.fold_batches, e.scan_batches,
-                          e.merged_batches, e.fused_batches};
+                          e.merged_batches, e.fused_batches, e.resumed_runs};
         if (e.last_bands && !e.batch_open && e.vsBandMode.p) {
             // values whose arg-max group's rows had a tile of their own in
             // the last value-sorted launch
@@ -5359,7 +5410,7 @@ int dist_gibbs_debug_counts(dist_gibbs_t * g, uint64_t * out, size_t n) {
             e.deferred_count.download(&d, 1);
             v[5] = d;
         }
-        for (size_t i = 0; i < n && i < 14; ++i) out[i] = v[i];
+        for (size_t i = 0; i < n && i < 15; ++i) out[i] = v[i];
     });
 }
 int dist_gibbs_phase_stats(dist_gibbs_t * g, double ms_out[5],

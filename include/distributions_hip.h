@@ -612,7 +612,7 @@ int dist_gibbs_set_option(dist_gibbs_t * g, const char * name, int value);
 /* how many batches each score+sample kernel has served */
 int dist_gibbs_path_counts(const dist_gibbs_t * g, uint64_t * value_sorted,
                            uint64_t * generic);
-/* diagnostics for the tests: out[0..13] = batches through the value-sorted
+/* diagnostics for the tests: out[0..14] = batches through the value-sorted
  * kernel, through the other kernels, launches with band tiles on, launches
  * with running sums on, values whose arg-max rows had their own tile in the
  * last value-sorted launch, rows that launch handed to the wave-per-row
@@ -621,7 +621,8 @@ int dist_gibbs_path_counts(const dist_gibbs_t * g, uint64_t * value_sorted,
  * took the small-launch kernel, batches through k_rows_scratch, batches with
  * folded leading features, batches sampled in scan mode, batches with merged
  * float statistics, batches whose group set, caches and tables came from the
- * one fused launch (first min(n, 14) entries are written) */
+ * one fused launch, sharded runs this rank closed between two passes and took
+ * up again (first min(n, 15) entries are written) */
 int dist_gibbs_debug_counts(dist_gibbs_t * g, uint64_t * out, size_t n);
 /* "phase_timing" = 1 (a diagnostic: six events per sub-sweep): HIP-event time
  * (ms, summed) of the five phases of the device-normalised value-sorted

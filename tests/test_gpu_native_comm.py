@@ -21,7 +21,7 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 pytestmark = pytest.mark.gpu
 
-K, BATCH, SWEEPS, SEED = 24, 1500, 2, 4242
+K, BATCH, SWEEPS, SEED = 24, 1500, 3, 4242
 
 
 def worker(rank, port, out, config, mode, N, peek=False, float_stats=0):
@@ -51,11 +51,16 @@ def worker(rank, port, out, config, mode, N, peek=False, float_stats=0):
     for s in range(SWEEPS):
         sharded.sweep(BATCH, _core.rng_seed(SEED), draw_base=s * N)
         if peek:
-            # a look at the state between two passes settles the open run:
-            # the next pass must find that out by asking (all ranks do, on
-            # every call) and open a new one
+            # a look at the state between two passes settles the open run;
+            # the next pass takes it up again with the same bound on the
+            # group count and the same batches left -- no word between the
+            # ranks (a rank that never looked goes on with its run and issues
+            # the very same collectives)
             assert len(gpu) >= K
+            assert gpu.validate()["code"] == 0
     torch.cuda.synchronize()
+    np.save(os.path.join(out, "resumed.npy"),
+            np.array([gpu.core.debug_counts()["resumed_runs"]]))
     np.save(os.path.join(out, "native.npy"), np.array([int(native)]))
     np.save(os.path.join(out, "on_device.npy"),
             np.array([gpu.core.debug_counts()["device_normalised"]]))
@@ -94,6 +99,9 @@ def test_native_loop_equals_oracle(tmp_path, config, mode, N, peek):
     # the device (no host round trip between the all-reduces)
     on_device = int(np.load(tmp_path / "on_device.npy")[0])
     assert (on_device > 0) == (native and len(osh) == 1 and mode == 2)
+    # a run closed by a look at the state is taken up again, pass after pass
+    resumed = int(np.load(tmp_path / "resumed.npy")[0])
+    assert resumed == ((SWEEPS - 1) if peek and on_device else 0)
     m = ol.OracleMixture(1.0, 0.2, osh)
     m.init_from_assignments(vals, assign, K, 2)
     for s in range(SWEEPS):
