@@ -554,13 +554,17 @@ int dist_gibbs_sharded_device_normalise_ok(const dist_gibbs_t * g,
  *      another thread drains that stream before it reads the state.  0 never.
  *      test_gpu_sweep.py::test_device_side_normalisation_under_group_churn
  *  "sharded_device_normalise"  1 (default) lets dist_gibbs_sweep_sharded do the
- *      same: the ranks agree among themselves, on EVERY call (one all-reduce
- *      of a flag), whether their open runs go on -- a rank whose run was
- *      settled in between by any other call makes all of them open a new one
- *      -- and, when a run is opened, whether every one of them can; 0 keeps
- *      this rank, and so all of them, on the host-normalised loop.  Calls
- *      between two passes need not be the same on every rank.
- *      tests/test_gpu_native_comm.py
+ *      same: when a run is opened the ranks agree among themselves (one
+ *      all-reduce of a flag) whether every one of them can; 0 keeps this
+ *      rank, and so all of them, on the host-normalised loop.  Whether an
+ *      open run GOES ON needs no word between them: it follows from the
+ *      call's tiling and the batches the run has left, the same on every
+ *      rank, and a rank that closed its run between two passes (any look at
+ *      its state does) takes it up again with the same bound on the group
+ *      count and the same batches left -- the collectives its peers issue.
+ *      So READ-ONLY calls between two passes need not be the same on every
+ *      rank; calls that change the state must be, as for any replicated state.
+ *      tests/test_gpu_native_comm.py (a peek between passes: resumed_runs)
  *  "fused_tables"  1 (default) a device-normalised run spends ONE launch between
  *      a batch's statistics and the next batch's sampling (k_vs_tables: group
  *      set, caches, per-value tables) and the rows a tile hands over are
