@@ -1096,6 +1096,14 @@ struct Gibbs {
     // kVsNarrowBelowTiles regular tiles, 2 whenever the vectors fit
     int narrow_mode = 1;
     int narrow_read_ahead = 0;   // float4s per vector: 0 auto, 4 or 8
+    // Wave priorities by phase (k_vs_sample, k_vs_stream, k_rows_scratch):
+    // 0x10000 | set-up << 12 | first pass << 8 | ... | last pass.  A SIMD
+    // issues from its oldest ready wave, so at equal priority its waves
+    // finish one after the other and the last ones run their dependent adds
+    // alone; with the earlier phase ahead of the later one whoever is behind
+    // goes first and they end together (profiles/r5_wave_priorities.txt).
+    int sample_prio_mode = 0x13210;   // VsTables::prio_mode, k_vs_stream
+    int rows_prio_mode = 0x13210;     // RowsArgs::pad
     uint64_t narrow_batches = 0;
     // (measured, round 4, K = 1024, rows per launch: 400 k 49.5 us against
     // k_vs_sample's 51.3, 524 k 61.2 / 68.5, 655 k 66.7 / 69.0, 786 k 77.1 /
@@ -1784,6 +1792,7 @@ struct Gibbs {
                              size_t n) {
         RowsArgs A;
         memset(&A, 0, sizeof(A));
+        A.pad = rows_prio_mode;   // (wave priorities by pass)
         GtabSource src;
         memset(&src, 0, sizeof(src));
         int n_ops = 0;
@@ -2455,7 +2464,8 @@ struct Gibbs {
                                    dim3(kVsStreamBlock), 0, stream(), *P,
                                    c->tiles.p, c->n_tiles, c->sorted_rows.p,
                                    self->deferred.p, self->deferred_count.p,
-                                   scratch, (uint32_t)stride);
+                                   scratch, (uint32_t)stride,
+                                   self->sample_prio_mode);
             HIP_CHECK(hipGetLastError());
             self->mark(self->ev1);
         }
@@ -2651,7 +2661,7 @@ struct Gibbs {
                             bands ? vsBandTile.p : nullptr, c.val_start.p,
                             nv, nullptr, c.chunk_first.p,
                             fused ? vsOwn.p : nullptr, Kuse, band_count,
-                            fused ? 1 : 0}, narrow, fused};
+                            fused ? 1 : 0, sample_prio_mode}, narrow, fused};
         // DIST_VS_STAMPS=<file>: per-wave phase stamps of every launch (the
         // last one stays in the file): tools/vs_stamps.py
         static const char * stamps_path = getenv("DIST_VS_STAMPS");
@@ -5270,13 +5280,20 @@ int dist_gibbs_set_option(dist_gibbs_t * g, const char * name, int value) {
         static const char * const hooks[] = {
             "sequential_chain", "running_sums_min_tiles", "narrow_read_ahead",
             "stream_scratch", "rows_scratch", "rows_scratch_lds_log",
-            "rows_scratch_block", "rows_fold", "apply_stage", "program_all"};
+            "rows_scratch_block", "rows_fold", "apply_stage", "program_all",
+            "sample_prio", "rows_prio"};
         bool is_hook = false;
         for (const char * h : hooks) is_hook = is_hook || key == h;
         DIST_REQUIRE(hook == is_hook,
                      is_hook ? "a test hook: spell it debug." + key
                              : "unknown option debug." + key);
-        if (key == "value_sorted") {
+        if (key == "sample_prio" || key == "rows_prio") {
+            // wave priorities by phase: 0 none, else 0x10000 | four levels
+            DIST_REQUIRE(value == 0 || (value >> 16) == 1,
+                         "sample_prio / rows_prio: 0 or 0x1abcd");
+            (key == "sample_prio" ? g->impl->sample_prio_mode
+                                  : g->impl->rows_prio_mode) = value;
+        } else if (key == "value_sorted") {
             DIST_REQUIRE(value >= 0 && value <= 2, "value_sorted: 0, 1 or 2");
             g->impl->value_sorted_mode = value;
         } else if (key == "value_stream") {

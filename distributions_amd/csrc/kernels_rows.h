@@ -1168,10 +1168,24 @@ __global__ __launch_bounds__(kScratchMaxBlock) void k_rows_scratch(RowsArgs A) {
     // instead of 60 instructions per (row, group), but 8 / 16 B of private
     // write-then-read traffic that tops out at 0.45 of the HBM roof:
     // profiles/r3_pmc_rows_scratch_mode1.txt)
+    // (A.pad: wave priorities by pass -- a wave that is behind goes first, so
+    // that a SIMD's waves end together instead of one after the other)
+    const int prio = A.pad;   // 0x10000 | load << 12 | max << 8 | total << 4 | scan
+    auto set_prio = [](int p) {
+        switch (p & 3) {
+        case 0: __builtin_amdgcn_s_setprio(0); break;
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        default: __builtin_amdgcn_s_setprio(3); break;
+        }
+    };
     for (; tile < n_work; tile += stride) {
+        if (prio) set_prio(prio >> 12);
         load_row(tile, cur);
         float m = -INFINITY;
+        if (prio) set_prio(prio >> 8);
         for (int k0 = 0; k0 < K8; k0 += kRowsBlock) max_block(cur, k0, m);
+        if (prio) set_prio(prio >> 4);
         // total in index order (random.cc:100-103)
         float total = 0.f;
         for (int k0 = 0; k0 < K8; k0 += kRowsBlock) {
@@ -1186,6 +1200,7 @@ __global__ __launch_bounds__(kScratchMaxBlock) void k_rows_scratch(RowsArgs A) {
         // through K - 1, which the final clamp maps to K - 1 as well)
         float t = total * draw(cur);
         int steps = 0;
+        if (prio) set_prio(prio);
         for (int k0 = 0; k0 < K8; k0 += kRowsBlock) {
             float l[kRowsBlock];
             like_block(cur, k0, m, l);

@@ -103,6 +103,9 @@ struct VsTables {
     // the tables (used by the values whose rows fit ONE chunk)
     uint32_t band_count;
     int band_by_chunk;
+    // wave priorities by phase (0: none; 0x10000 | set-up << 12 | total <<
+    // 8 | the scan's first half << 4 | its second half): see k_vs_sample
+    int prio_mode;
 };
 constexpr uint32_t kVsBandWalkRows = 8192;
 
@@ -856,6 +859,15 @@ __device__ __forceinline__ void vs_fetch_chunk(uniform_fp lp, int k0,
 #pragma unroll
     for (int j = 0; j < kVsUnroll; ++j) l[j] = lp[k0 + j];
 }
+// s_setprio takes an immediate
+__device__ __forceinline__ void vs_set_prio(int p) {
+    switch (p & 3) {
+    case 0: __builtin_amdgcn_s_setprio(0); break;
+    case 1: __builtin_amdgcn_s_setprio(1); break;
+    case 2: __builtin_amdgcn_s_setprio(2); break;
+    default: __builtin_amdgcn_s_setprio(3); break;
+    }
+}
 typedef float v2f __attribute__((ext_vector_type(2)));
 static_assert(kVsR == 2, "the recurrences below are written for two rows per "
                          "lane (one v_pk_add_f32 per entry)");
@@ -882,7 +894,7 @@ __device__ __forceinline__ void vs_sum_and_scan(
         uniform_fp lp, const float * lp_vec, uniform_fp prefix, int K,
         const int (&g)[kVsR],
         const float (&l_own)[kVsR], const float (&u)[kVsR],
-        const bool (&active)[kVsR], int (&found)[kVsR]
+        const bool (&active)[kVsR], int (&found)[kVsR], int prio_steps
 #ifdef DIST_VS_STAMPS
         , int & chunks_done
 #endif
@@ -947,9 +959,11 @@ __device__ __forceinline__ void vs_sum_and_scan(
     float t_start[kVsR] = {t.x, t.y};
     int npos[kVsR] = {0, 0};
     const int nchunks = (K + kVsUnroll - 1) / kVsUnroll;
+    if (prio_steps) vs_set_prio(prio_steps >> 4);
     for (int c = 0, k0 = 0; k0 < K; ++c, k0 += kVsUnroll) {
         float l[kVsUnroll];
         vs_fetch_chunk(lp, k0, l);
+        if (prio_steps && c == nchunks / 2) vs_set_prio(prio_steps);
 #ifdef DIST_VS_STAMPS
         ++chunks_done;
 #endif
@@ -1045,6 +1059,16 @@ void k_vs_sample(
     int chunks_done = 0;   // chunks of both recurrences, both vectors
     if (T.stamps) st0 = __builtin_amdgcn_s_memtime();
 #endif
+    // A SIMD issues from its oldest ready wave: at equal priority the waves
+    // still gathering their rows get few slots beside the ones that run
+    // their chains, reach their own chains late and finish them alone, one
+    // dependent add at a time (tools/vs_stamps.py: the slowest waves spent
+    // 65 k cycles in a set-up that takes the median wave 19 k; the launch
+    // ended at 157 k, the median SIMD at 130 k).  With the set-up ahead of the
+    // total, the total ahead of the scan and the scan's first half ahead of
+    // its second, whoever is behind goes first and a SIMD's waves end
+    // together: 69 -> 64 us per launch at C2 (profiles/r5_wave_priorities.txt).
+    if (T.prio_mode) vs_set_prio(T.prio_mode >> 12);
     const bool band = id < n_band_ids;
     const VsTile * mine = band ? T.band_tile + id : tiles + (id - n_band_ids);
     if (band ? id >= T.band_count : id - n_band_ids >= n_tiles) return;
@@ -1131,7 +1155,9 @@ void k_vs_sample(
     // one dependent add at a time (measured: +30 % on that SIMD's time, and
     // the slowest SIMD is the kernel's time); ahead of its neighbours it ends
     // with them.
-    if (__any(anyA) && __any(anyB)) __builtin_amdgcn_s_setprio(3);
+    const bool both = __any(anyA) && __any(anyB);
+    if (both) __builtin_amdgcn_s_setprio(3);
+    else if (T.prio_mode) vs_set_prio(T.prio_mode >> 8);
 #ifdef DIST_VS_STAMPS
     if (T.stamps) st1 = __builtin_amdgcn_s_memtime();
 #endif
@@ -1141,7 +1167,7 @@ void k_vs_sample(
         vs_sum_and_scan(as_uniform(vec), vec,
                         T.PA ? as_uniform(T.PA + (size_t)x
                                           * (T.Kpad / kVsUnroll)) : nullptr,
-                        K, g, l_own, u, inA, f
+                        K, g, l_own, u, inA, f, both ? 0 : T.prio_mode
 #ifdef DIST_VS_STAMPS
                         , chunks_done
 #endif
@@ -1158,7 +1184,7 @@ void k_vs_sample(
         vs_sum_and_scan(as_uniform(vec), vec,
                         T.PB ? as_uniform(T.PB + (size_t)x
                                           * (T.Kpad / kVsUnroll)) : nullptr,
-                        K, g, l_own, u, inB, f
+                        K, g, l_own, u, inB, f, both ? 0 : T.prio_mode
 #ifdef DIST_VS_STAMPS
                         , chunks_done
 #endif
@@ -1721,7 +1747,10 @@ void k_vs_stream(
         SweepParams P, const VsTile * __restrict__ tiles, uint32_t n_tiles,
         const uint32_t * __restrict__ sorted_rows,
         uint32_t * __restrict__ deferred, uint32_t * deferred_count,
-        float * __restrict__ scratch, uint32_t scratch_stride) {
+        float * __restrict__ scratch, uint32_t scratch_stride, int prio_mode) {
+    // (wave priorities by phase, as in k_vs_sample: whoever is behind goes
+    // first)
+    if (prio_mode) vs_set_prio(prio_mode >> 12);
     __shared__ uint32_t s_exp[1024];
     __shared__ float s_strip[kVsStreamBlock / 64][2][kVsStreamChunk];
     for (int i = threadIdx.x; i < 1024; i += kVsStreamBlock)
@@ -1962,6 +1991,7 @@ void k_vs_stream(
     const float4 * src = reinterpret_cast<const float4 *>(mine);
     auto run_pass = [&](auto pass_tag) {
         constexpr int pass = decltype(pass_tag)::value;
+        if (prio_mode) vs_set_prio(pass == 0 ? prio_mode >> 8 : prio_mode >> 4);
         if (pass == 1) {
             acc = acc * (v2f){u[0], u[1]};
             t_start[0] = acc.x;
@@ -2016,6 +2046,9 @@ void k_vs_stream(
         fetch_chunk(0);
         bool done = false;
         for (int k0 = 0; k0 < K && !done; k0 += kVsStreamChunk) {
+            if (pass == 1 && prio_mode && k0 >= K / 2
+                && k0 - kVsStreamChunk < K / 2)
+                vs_set_prio(prio_mode);
             // the chunk's likelihoods, 64 at a time, into the strips
 #pragma unroll
             for (int j = 0; j < J; ++j) {

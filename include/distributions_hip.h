@@ -610,7 +610,10 @@ int dist_gibbs_sharded_device_normalise_ok(const dist_gibbs_t * g,
  * 1 where 128 rows share a value | 2 whenever the joint domain fits | 0),
  * apply_stage (general rows' integer statistics summed in LDS: 1 | 0),
  * program_all (every batch outside the value-sorted path through the
- * per-batch score program: 1 | 0).
+ * per-batch score program: 1 | 0), sample_prio / rows_prio (wave priorities
+ * by phase in k_vs_sample + k_vs_stream / k_rows_scratch: 0x13210 set-up,
+ * first pass, ..., last pass | 0 none -- the A/B of
+ * profiles/r5_wave_priorities.txt).
  */
 int dist_gibbs_set_option(dist_gibbs_t * g, const char * name, int value);
 /* how many batches each score+sample kernel has served */
