@@ -173,6 +173,9 @@ class Group(GroupBase):
     def init(self, shared):
         self._sparse = None
         self._values = shared.values
+        if shared.params.dim == 0:      # (a Shared without a value yet)
+            self.words = np.zeros(1, np.uint32)
+            return
         GroupBase.init(self, shared)
 
     def load(self, raw):                       # dpd.pyx:141-148
@@ -209,11 +212,18 @@ class Group(GroupBase):
 
     def score_value(self, shared, value):
         self._bind(shared)
-        return shared.params.group_score_value(self.words,
-                                               shared.remap(value))
+        slot = shared.remap(value)
+        if shared.params.dim == 0:      # (only OTHER exists: dpd.hpp:223-232)
+            alpha = np.float32(shared.alpha)
+            numer = np.float32(alpha * np.float32(shared.beta0))
+            return float(_core.vector_log(np.array([numer / alpha],
+                                                   np.float32))[0])
+        return shared.params.group_score_value(self.words, slot)
 
     def score_data(self, shared):
         self._bind(shared)
+        if shared.params.dim == 0:
+            return 0.0
         return GroupBase.score_data(self, shared)
 
     def merge(self, shared, source):           # sparse.hpp:163-168 (as built)
@@ -240,10 +250,20 @@ class Mixture(MixtureBase):
             if isinstance(item, Group):
                 item._bind(shared)
                 self._pending[i] = np.array(item.words, np.uint32)
+        if shared.params.dim == 0:
+            # a Shared without a value yet (the reference's EXAMPLES start
+            # there, dpd.pyx:52-66): nothing to count under, the groups -- all
+            # empty -- stay on the host until the first value exists
+            if self._core is not None:
+                self._pending = [self._core.get_group(i)[:1].copy()
+                                 for i in range(len(self._core))]
+                self._core = None
+                self._inited_empty = True
+            return None
         key = (id(shared), shared.version)
         if self._core is None or key != self._key:
-            fresh = self._core is None
-            groups = self._pending if fresh else [
+            fresh = self._core is None and not self._inited_empty
+            groups = self._pending if self._core is None else [
                 self._core.get_group(i) for i in range(len(self._core))]
             self._core = _core.SlaveMixture(shared.params)
             for words in groups:
@@ -252,11 +272,21 @@ class Mixture(MixtureBase):
             if not fresh:
                 self._core.init()
             self._pending = []
+            self._inited_empty = False
             self._key = key
             self._values_of_shared = shared.values
         return self._core
 
     _values_of_shared = None
+    _inited_empty = False
+
+    def _other_score(self, shared):
+        """a group without rows scores OTHER, the only value there is, with
+        fast_log(alpha * beta0 / alpha) (dpd.hpp:223-232)"""
+        alpha = np.float32(shared.alpha)
+        numer = np.float32(alpha * np.float32(shared.beta0))
+        return float(_core.vector_log(np.array([numer / alpha],
+                                               np.float32))[0])
 
     def __getitem__(self, groupid):
         if self._core is None and isinstance(self._pending[groupid], Group):
@@ -267,7 +297,24 @@ class Mixture(MixtureBase):
 
     def init(self, shared):
         self._values_of_shared = shared.values
+        if self._handle(shared) is None:
+            self._inited_empty = True
+            return
         MixtureBase.init(self, shared)
+
+    def add_group(self, shared):
+        if self._handle(shared) is None:
+            self._pending.append(np.zeros(1, np.uint32))
+            return
+        MixtureBase.add_group(self, shared)
+
+    def remove_group(self, shared, groupid):
+        if self._handle(shared) is None:      # (packed_remove, vector.hpp:47-56)
+            assert groupid < len(self._pending), "groupid out of bounds"
+            self._pending[groupid] = self._pending[-1]
+            self._pending.pop()
+            return
+        MixtureBase.remove_group(self, shared, groupid)
 
     def add_value(self, shared, groupid, value):
         self._handle(shared).add_value(groupid, shared.remap(value))
@@ -276,9 +323,33 @@ class Mixture(MixtureBase):
         self._handle(shared).remove_value(groupid, shared.remap(value))
 
     def score_value_group(self, shared, groupid, value):
-        return self._handle(shared).score_value_group(groupid,
-                                                      shared.remap(value))
+        slot = shared.remap(value)
+        if self._handle(shared) is None:
+            assert groupid < len(self), "groupid out of bounds"
+            return self._other_score(shared)
+        return self._handle(shared).score_value_group(groupid, slot)
 
     def score_value(self, shared, value, scores_accum):
         assert len(scores_accum) == len(self), "scores_accum != len(mixture)"
-        self._handle(shared).score_value(shared.remap(value), scores_accum)
+        slot = shared.remap(value)
+        if self._handle(shared) is None:
+            scores_accum += np.float32(self._other_score(shared))
+            return
+        self._handle(shared).score_value(slot, scores_accum)
+
+    def score_values(self, shared, values, scores_accum):
+        if self._handle(shared) is None:
+            for value in values:
+                shared.remap(value)
+            scores_accum += np.float32(self._other_score(shared))
+            return
+        MixtureBase.score_values(self, shared, values, scores_accum)
+
+    def score_data(self, shared):
+        if self._handle(shared) is None:
+            return 0.0      # (no rows: dpd.hpp:234-250 sums nothing)
+        return MixtureBase.score_data(self, shared)
+
+    def validate(self, shared):
+        if self._handle(shared) is not None:
+            MixtureBase.validate(self, shared)

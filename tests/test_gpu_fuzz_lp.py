@@ -18,3 +18,13 @@ def test_per_row_api_fuzz(first):
     failures = [err for err in (fuzz_lp.trial(seed)
                                 for seed in range(first, first + 200)) if err]
     assert not failures, failures
+
+
+def test_growing_dpd_shared_fuzz():
+    """tools/fuzz_lp.py's second kind of trial: values appear in and vanish
+    from a DirichletProcessDiscrete Shared (dpd.hpp:66-83) under a live device
+    mixture"""
+    import fuzz_lp
+    failures = [err for err in (fuzz_lp.trial_growing_dpd(seed)
+                                for seed in range(4000, 4040)) if err]
+    assert not failures, failures

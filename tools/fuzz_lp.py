@@ -141,13 +141,99 @@ def trial(seed):
     return None
 
 
+def trial_growing_dpd(seed):
+    """A DirichletProcessDiscrete feature whose Shared starts (nearly) empty:
+    values appear through Shared.add_value (the stick breaks, dpd.hpp:66-74),
+    vanish through remove_value (:76-83) and their dense slots are taken
+    again, while a device mixture lives on that Shared.  Every few steps the
+    mixture's scores over all live values and OTHER, score_values, and the
+    groups' counts are compared with an oracle mixture built from scratch on
+    the Shared's current dense view with the same memberships (bit for bit)."""
+    from distributions_amd.lp import random as lprandom
+    from distributions_amd.lp.models import dpd
+    rng = np.random.default_rng(seed)
+    L = ol.oracle()
+    lprandom.seed(int(rng.integers(1, 2 ** 31 - 1)))
+    what = "seed %d growing DPD" % seed
+    start = {int(v): 1 for v in rng.choice(50, int(rng.integers(0, 4)),
+                                           replace=False)}
+    betas = {v: float(b) for v, b in zip(
+        start, rng.dirichlet(np.ones(len(start) + 1))[:len(start)] * 0.6)}
+    shared = dpd.Shared.from_dict({'gamma': float(rng.uniform(0.3, 6)),
+                                   'alpha': float(rng.uniform(0.2, 3)),
+                                   'betas': betas, 'counts': start})
+    K = int(rng.integers(1, 7))
+    members = [[] for _ in range(K)]
+    mixture = dpd.Mixture()
+    for _ in range(K):
+        mixture.append(dpd.Group.from_values(shared))
+    mixture.init(shared)
+    universe = int(rng.choice([6, 40]))
+
+    def compare(step):
+        p = shared.params
+        if p.dim == 0:
+            return None
+        osh = ol.make_shared(ol.DPD, alpha=p.p[0], beta0=p.p[1], betas=p.betas)
+        orc = ol.OracleMixture(1.0, 0.0, [osh])
+        for g in range(K):
+            L.orc_mix_slave_append_empty(orc.h, 0)
+            for v in members[g]:
+                L.orc_mix_slave_group_add_value(orc.h, 0, g, shared.remap(v))
+        L.orc_mix_slave_init(orc.h, 0)
+        live = [v for v in shared.values if v is not None] + [dpd.OTHER]
+        batch = np.zeros((len(live), K), np.float32)
+        mixture.score_values(shared, live, batch)
+        for i, v in enumerate(live):
+            got = np.zeros(K, np.float32)
+            want = np.zeros(K, np.float32)
+            mixture.score_value(shared, v, got)
+            L.orc_mix_slave_score_value(orc.h, 0, shared.remap(v), want)
+            if not np.array_equal(bits(got), bits(want)):
+                return what + " step %d score_value(%r)" % (step, v)
+            if not np.array_equal(bits(batch[i]), bits(want)):
+                return what + " step %d score_values(%r)" % (step, v)
+        for g in range(K):
+            want = {}
+            for v in members[g]:
+                want[v] = want.get(v, 0) + 1
+            if mixture[g].dump()['counts'] != want:
+                return what + " step %d counts of group %d" % (step, g)
+        mixture.validate(shared)
+        return None
+
+    for step in range(80):
+        op = rng.choice(["add", "add", "add", "remove", "remove", "check"])
+        if op == "add":
+            v = int(rng.integers(0, universe))
+            if shared.beta0 <= 0 and v not in shared.dump()['betas']:
+                continue   # (the stick is used up: dpd.hpp:69)
+            shared.add_value(v)
+            g = int(rng.integers(0, K))
+            mixture.add_value(shared, g, v)
+            members[g].append(v)
+        elif op == "remove":
+            g = int(rng.integers(0, K))
+            if members[g]:
+                v = members[g].pop(int(rng.integers(0, len(members[g]))))
+                mixture.remove_value(shared, g, v)
+                # (the values the Shared was loaded with keep the one row
+                # they came with; every other value vanishes with its last)
+                shared.remove_value(v)
+        else:
+            err = compare(step)
+            if err:
+                return err
+    return compare(80)
+
+
 def main():
     trials = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     failures = 0
     for seed in range(first, first + trials):
         try:
-            err = trial(seed)
+            err = trial_growing_dpd(seed) if seed % 5 == 4 else trial(seed)
         except Exception as e:   # noqa: BLE001
             err = "seed %d: exception %r" % (seed, e)
         if err:
