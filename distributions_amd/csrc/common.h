@@ -60,6 +60,19 @@ inline size_t grow_capacity(size_t need) {
     return c;
 }
 
+// hipMemcpyAsync from PAGEABLE host memory returns when the copy has been
+// done, and the copy waits for whatever the stream still holds: a 100-byte
+// upload behind a 260 us kernel parks the host for 260 us, and the launches it
+// would have queued meanwhile start late (the host-normalised paths upload a
+// handful of small tables per batch: 29 + 6 + 4 + 16 us of idle device per C3
+// sub-sweep, profiles/r5_timeline_c3.txt).  Small uploads therefore go through
+// a ring of pinned memory: the bytes are copied into the next free stretch
+// and the asynchronous copy reads from there.  A stretch is written again one
+// lap later; each half of the ring carries an event recorded when the writer
+// left it, waited for before the writer enters it again (long complete by
+// then), so no copy ever reads bytes that were overwritten.
+const void * staged_for_upload(const void * host, size_t bytes);
+
 template <class T>
 struct DeviceBuf {
     T * p = nullptr;
@@ -99,8 +112,9 @@ struct DeviceBuf {
     void upload(const T * host, size_t n) {
         if (n > cap) reserve(grow_capacity(n), 0);   // headroom: no realloc per call
         if (n)
-            HIP_CHECK(hipMemcpyAsync(p, host, n * sizeof(T),
-                                     hipMemcpyHostToDevice, stream()));
+            HIP_CHECK(hipMemcpyAsync(p, staged_for_upload(host, n * sizeof(T)),
+                                     n * sizeof(T), hipMemcpyHostToDevice,
+                                     stream()));
     }
     void download(T * host, size_t n) const {
         if (n)

@@ -87,6 +87,66 @@ void ensure_device_ready() {
 static thread_local hipStream_t t_stream = nullptr;
 hipStream_t stream() { return t_stream; }
 
+// the pinned ring behind DeviceBuf::upload (common.h): per host thread
+namespace {
+struct UploadRing {
+    static constexpr size_t kBytes = 8u << 20, kHalf = kBytes / 2;
+    static constexpr size_t kMaxUpload = 256u << 10;   // larger: as before
+    char * base = nullptr;
+    size_t head = 0;
+    hipEvent_t left[2] = {nullptr, nullptr};   // recorded on leaving a half
+    bool recorded[2] = {false, false};
+    hipStream_t on = nullptr;   // the stream the recorded events are of
+    ~UploadRing() {
+        // (process teardown: the runtime may be gone; nothing to wait for)
+    }
+    const void * stage(const void * host, size_t bytes) {
+        if (bytes > kMaxUpload) return host;
+        if (!base) {
+            if (hipHostMalloc((void **)&base, kBytes, hipHostMallocDefault)
+                    != hipSuccess) {
+                base = nullptr;
+                return host;   // (no pinned memory: the synchronous copy)
+            }
+            for (int i = 0; i < 2; ++i)
+                HIP_CHECK(hipEventCreateWithFlags(&left[i],
+                                                  hipEventDisableTiming));
+        }
+        hipStream_t now = stream();
+        if (now != on) {
+            // copies of another stream may still read the ring: drain it
+            if (recorded[0] || recorded[1] || head)
+                HIP_CHECK(hipStreamSynchronize(on));
+            recorded[0] = recorded[1] = false;
+            on = now;
+        }
+        const size_t need = (bytes + 255) & ~(size_t)255;
+        // the half written last, and what is left of it
+        const int half_now = head == 0 ? 0 : (int)((head - 1) / kHalf);
+        size_t at = head;
+        if (head + need > (size_t)(half_now + 1) * kHalf) {
+            const int half_next = half_now ^ 1;
+            // leaving half_now: everything queued from it so far ...
+            HIP_CHECK(hipEventRecord(left[half_now], now));
+            recorded[half_now] = true;
+            // ... entering half_next: its last lap's copies must be done
+            if (recorded[half_next]) {
+                HIP_CHECK(hipEventSynchronize(left[half_next]));
+                recorded[half_next] = false;
+            }
+            at = (size_t)half_next * kHalf;
+        }
+        memcpy(base + at, host, bytes);
+        head = at + need;
+        return base + at;
+    }
+};
+}  // namespace
+const void * staged_for_upload(const void * host, size_t bytes) {
+    static thread_local UploadRing ring;
+    return ring.stage(host, bytes);
+}
+
 // (y, glibc lgammaf(y)) pairs for the current device's table, sorted by y
 // (y -> glibc lgammaf(y), users) per device.  lgammaf is a pure function, so
 // an entry is right whoever put it there; `users` only decides what may be
@@ -1259,6 +1319,7 @@ struct Gibbs {
         HIP_CHECK(hipEventCreate(&ev1));
     }
     ~Gibbs() {
+        if (publish_ev) (void)hipEventDestroy(publish_ev);
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
         for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
@@ -1537,6 +1598,53 @@ struct Gibbs {
         py.rebuild(alpha, d);
         for (auto & s : feats) s->init();
     }
+    // The group sizes are final once a batch's integer statistics are applied;
+    // the ordered replay of its float statistics (C3: 0.26 of 2.2 ms) does
+    // not touch them.  Published BEFORE the replay, they are on the host when
+    // batch_finish asks, the host works out the normalisation while the
+    // replay runs, and the kernels that follow start the moment it ends (they
+    // used to start 25-35 us after it: the wait, the host's work, the
+    // launches -- profiles/r5_timeline_c3.txt).
+    unsigned early_ticket = 0;
+    size_t early_n = 0;
+    uint64_t batch_serial = 0, early_serial = 0;   // (which batch it is of)
+    unsigned launch_publish(size_t n) {
+        if (n > pinned_cap) {
+            sync();   // (an earlier publish may still write the old buffer)
+            if (pinned_counts) (void)hipHostFree(pinned_counts);
+            pinned_cap = grow_capacity(n);
+            HIP_CHECK(hipHostMalloc((void **)&pinned_counts,
+                                    pinned_cap * sizeof(int),
+                                    hipHostMallocCoherent));
+        }
+        if (!pinned_seq) {
+            HIP_CHECK(hipHostMalloc((void **)&pinned_seq, sizeof(unsigned),
+                                    hipHostMallocCoherent));
+            *pinned_seq = 0;
+        }
+        const unsigned ticket = ++publish_ticket;
+        hipLaunchKernelGGL(k_publish_counts, dim3(1), dim3(1024), 0, stream(),
+                           py.d_counts.p, (int)n, pinned_counts,
+                           (volatile unsigned *)pinned_seq, ticket);
+        HIP_CHECK(hipGetLastError());
+        // (what a waiter that has spun long enough sleeps on: THIS kernel,
+        // not the stream -- the replay queued behind it is not its business)
+        if (!publish_ev)
+            HIP_CHECK(hipEventCreateWithFlags(
+                &publish_ev, hipEventDisableTiming | hipEventBlockingSync));
+        HIP_CHECK(hipEventRecord(publish_ev, stream()));
+        return ticket;
+    }
+    hipEvent_t publish_ev = nullptr;
+    void publish_counts_early() {
+        // (k_vs_reduce publishes the sizes of a value-sorted batch itself;
+        // an open device-normalised run never asks)
+        if (async_active || (pairs_ticket != 0 && pairs_ticket == publish_ticket))
+            return;
+        early_n = (size_t)K();
+        early_serial = batch_serial;
+        early_ticket = launch_publish(early_n);
+    }
     void refresh_host_counts() {
         const size_t n = (size_t)K();
         if (n > pinned_cap) {
@@ -1586,17 +1694,12 @@ struct Gibbs {
             return;
         }
         pairs_ticket = 0;
-        if (!pinned_seq) {
-            HIP_CHECK(hipHostMalloc((void **)&pinned_seq, sizeof(unsigned),
-                                    hipHostMallocCoherent));
-            *pinned_seq = 0;
-        }
         // one block writes the sizes into the pinned buffer, then the ticket
-        const unsigned ticket = ++publish_ticket;
-        hipLaunchKernelGGL(k_publish_counts, dim3(1), dim3(1024), 0, stream(),
-                           py.d_counts.p, (int)n, pinned_counts,
-                           (volatile unsigned *)pinned_seq, ticket);
-        HIP_CHECK(hipGetLastError());
+        // (or did already: publish_counts_early)
+        unsigned ticket = early_ticket;
+        early_ticket = 0;
+        if (!ticket || early_n != n || early_serial != batch_serial)
+            ticket = launch_publish(n);
         bool seen = false;
         const auto t_poll = std::chrono::steady_clock::now();
         while (!seen) {
@@ -1606,9 +1709,14 @@ struct Gibbs {
                 > std::chrono::microseconds(200))
                 break;
         }
-        // (not yet: drain the stream, which also surfaces the error of a
-        // failed kernel -- that one never writes the ticket)
-        if (!seen) HIP_CHECK(hipStreamSynchronize(stream()));
+        // (not yet: sleep until the publishing kernel is done, which also
+        // surfaces the error of a failed kernel -- that one never writes the
+        // ticket)
+        if (!seen) {
+            HIP_CHECK(hipEventSynchronize(publish_ev));
+            DIST_REQUIRE(*(volatile unsigned *)pinned_seq == ticket,
+                         "group sizes were not published");
+        }
         std::atomic_thread_fence(std::memory_order_acquire);
         std::copy(pinned_counts, pinned_counts + n, py.counts.begin());
     }
@@ -2726,6 +2834,7 @@ struct Gibbs {
                      "rows without a group yet: init_sequential first");
         batch_begin = r0;
         batch_end = r1;
+        batch_serial += 1;
         batch_seed = seed;
         batch_draw_base = draw_base;
         batch_open = true;
@@ -3251,6 +3360,7 @@ struct Gibbs {
         DIST_REQUIRE(batch_open, "no open batch");
         if (batch_end == batch_begin) return;
         apply_ints(live_image());
+        if (any_float_stats()) publish_counts_early();
         replay_floats();
     }
     // zeroed = the caller's image is all zero already (see clear below)
@@ -3313,7 +3423,10 @@ struct Gibbs {
         batch_open = false;
         const std::vector<int> snap = py.counts;
         const int K0 = K();
-        refresh_host_counts();
+        {
+            HOST_PROBE(17, "  finish: refresh_host_counts");
+            refresh_host_counts();
+        }
         int created = 0;
         for (int k = 0; k < K0; ++k)
             if (snap[k] == 0 && py.counts[k] > 0) created += 1;
@@ -3895,9 +4008,18 @@ struct Gibbs {
         }
         for (size_t b = r0; b < r1; b += batch) {
             const size_t e = std::min(r1, b + batch);
-            batch_sample(b, e, seed, draw_base);
-            batch_apply_local();
-            batch_finish();
+            {
+                HOST_PROBE(14, "sweep: batch_sample");
+                batch_sample(b, e, seed, draw_base);
+            }
+            {
+                HOST_PROBE(15, "sweep: batch_apply_local");
+                batch_apply_local();
+            }
+            {
+                HOST_PROBE(16, "sweep: batch_finish");
+                batch_finish();
+            }
         }
         sync();
     }
