@@ -1164,6 +1164,7 @@ struct Gibbs {
     // goes first and they end together (profiles/r5_wave_priorities.txt).
     int sample_prio_mode = 0x13210;   // VsTables::prio_mode, k_vs_stream
     int rows_prio_mode = 0x13210;     // RowsArgs::pad
+    int apply_overlap_mode = 1;       // k_vs_apply: hand-overs beside the adds
     uint64_t narrow_batches = 0;
     // (measured, round 4, K = 1024, rows per launch: 400 k 49.5 us against
     // k_vs_sample's 51.3, 524 k 61.2 / 68.5, 655 k 66.7 / 69.0, 786 k 77.1 /
@@ -2400,7 +2401,8 @@ struct Gibbs {
             // was measured: k_vs_apply 17.4 -> 14.8 us on average, k_vs_sample
             // 79 -> 86: its 64 registers spill.)
             const VsDefer D{self->deferred.p, self->deferred_count.p,
-                            fused ? c->def_counts.p : nullptr, c->chunks.p};
+                            fused ? c->def_counts.p : nullptr, c->chunks.p,
+                            0};
             self->phase_mark(1);
             {
                 HOST_PROBE(10, "      mark(ev0)");
@@ -2467,8 +2469,11 @@ struct Gibbs {
         // those sums: not in one launch
         const int kind0 = feats[0]->sh.kind;
         if ((kind0 == DIST_BNB || kind0 == DIST_GP) && c.n_other) return false;
+        // (k_vs_apply's LDS follows the batch's own bound on the group
+        // count, not the run's: the device lays it out by the true count)
         const size_t lds_sort =
-            ((size_t)K() * 2 + kVsApplyBlock / 64 + 4 * kVsApplyRows + 4) * 4;
+            ((size_t)batch_k_limit * 2 + kVsApplyBlock / 64 + 4 * kVsApplyRows
+             + 4) * 4;
         if (lds_sort > 144 * 1024) return false;
         return (size_t)c.n_chunks * K() <= ((size_t)1 << 22);
     }
@@ -2687,6 +2692,7 @@ struct Gibbs {
         VsCache & c = *cp;
         phase_mark(0);
         const int Kpad = (K() + kVsUnroll - 1) / kVsUnroll * kVsUnroll;
+        batch_k_limit = k_limit();
         const bool fused = sampling_mode != 1 && !use_stream(c)
                            && fused_ok(c, Kpad);
         batch_fused = fused;
@@ -3118,8 +3124,11 @@ struct Gibbs {
             HOST_PROBE(9, "  params() in apply");
             P = params(batch_begin, batch_end, batch_seed, batch_draw_base);
         }
+        // (a fused batch: the bound its launches were sized with, see
+        // fused_ok; the device's layout follows the true group count)
+        const size_t k_lds = batch_fused ? (size_t)batch_k_limit : (size_t)K();
         const size_t lds_sort =
-            ((size_t)K() * 2 + kVsApplyBlock / 64 + 4 * kVsApplyRows + 4) * 4;
+            (k_lds * 2 + kVsApplyBlock / 64 + 4 * kVsApplyRows + 4) * 4;
         const size_t lds_plain = (size_t)K() * 4;
         // a 1024-thread workgroup may take most of the CU's 160 KiB of LDS
         const size_t lds_limit = 144 * 1024;
@@ -3171,9 +3180,37 @@ struct Gibbs {
             // (fused batches: the chunk samples its handed-over rows itself)
             DIST_REQUIRE(!batch_fused || (sort && stage),
                          "internal: fused batch without the sorting apply");
+            // (and, LDS permitting, a few of them in strips of their own
+            // while the chunk's other waves add up the moves)
+            int lds_told = 0;
+            size_t lds_sort_used = lds_sort;
+            if (batch_fused && sort && !gp && apply_overlap_mode) {
+                const size_t strip_bytes = ((k_lds + 63) & ~(size_t)63) * 4;
+                lds_sort_used = std::min(lds_limit, lds_sort + 4 * strip_bytes);
+                lds_told = (int)lds_sort_used;
+            }
             const VsDefer D{deferred.p, deferred_count.p,
                             batch_fused ? c.def_counts.p : nullptr,
-                            c.chunks.p};
+                            c.chunks.p, lds_told};
+            static const bool trace_deferred = getenv("DIST_TRACE_DEFERRED");
+            if (trace_deferred && batch_fused) {   // (diagnostic: drains)
+                std::vector<uint32_t> h(c.n_chunks);
+                HIP_CHECK(hipStreamSynchronize(stream()));
+                HIP_CHECK(hipMemcpy(h.data(), c.def_counts.p,
+                                    h.size() * sizeof(uint32_t),
+                                    hipMemcpyDeviceToHost));
+                uint32_t total = 0, most = 0, chunks_with = 0;
+                for (uint32_t v : h) {
+                    total += v;
+                    most = std::max(most, v);
+                    chunks_with += v != 0;
+                }
+                fprintf(stderr, "[dist] batch [%zu, %zu): %u rows handed over "
+                        "in %u of %u chunks, at most %u in one; %d bytes of "
+                        "LDS at a bound of %d groups\n",
+                        batch_begin, batch_end, total, chunks_with,
+                        (unsigned)c.n_chunks, most, lds_told, (int)k_lds);
+            }
             // the sorting form of a device-normalised run leaves the groups'
             // offsets per chunk (bands without a walk, k_vs_tables); any
             // other form clears the stamps of a range that has some
@@ -3243,15 +3280,15 @@ struct Gibbs {
                                    c.assign_pos.p, refresh, stage);
                 HIP_CHECK(hipGetLastError());
             }
-            if (bb && sort) VS_APPLY(DIST_BB, true, lds_sort);
+            if (bb && sort) VS_APPLY(DIST_BB, true, lds_sort_used);
             else if (bb) VS_APPLY(DIST_BB, false, lds_plain);
-            else if (gp && sort) VS_APPLY(DIST_GP, true, lds_sort);
+            else if (gp && sort) VS_APPLY(DIST_GP, true, lds_sort_used);
             else if (gp) VS_APPLY(DIST_GP, false, lds_plain);
-            else if (bnb && sort) VS_APPLY(DIST_BNB, true, lds_sort);
+            else if (bnb && sort) VS_APPLY(DIST_BNB, true, lds_sort_used);
             else if (bnb) VS_APPLY(DIST_BNB, false, lds_plain);
             else if (sort && feats[0]->sh.kind == DIST_DPD)
-                VS_APPLY(DIST_DPD, true, lds_sort);   // (its rows' scorer)
-            else if (sort) VS_APPLY(DIST_DD, true, lds_sort);
+                VS_APPLY(DIST_DPD, true, lds_sort_used);   // (its rows' scorer)
+            else if (sort) VS_APPLY(DIST_DD, true, lds_sort_used);
             else VS_APPLY(DIST_DD, false, lds_plain);
 #undef VS_APPLY
             HIP_CHECK(hipGetLastError());
@@ -3688,6 +3725,7 @@ struct Gibbs {
     size_t run_batches = 0;          // batches sampled in the open run
     int K_seen = 0;
     size_t K_seen_batch = 0;
+    int batch_k_limit = 0;           // k_limit() when the open batch was sampled
     DevState * pinned_state = nullptr;
     hipEvent_t peek_event = nullptr;
     bool peek_pending = false;
@@ -5403,7 +5441,7 @@ int dist_gibbs_set_option(dist_gibbs_t * g, const char * name, int value) {
             "sequential_chain", "running_sums_min_tiles", "narrow_read_ahead",
             "stream_scratch", "rows_scratch", "rows_scratch_lds_log",
             "rows_scratch_block", "rows_fold", "apply_stage", "program_all",
-            "sample_prio", "rows_prio"};
+            "sample_prio", "rows_prio", "apply_overlap"};
         bool is_hook = false;
         for (const char * h : hooks) is_hook = is_hook || key == h;
         DIST_REQUIRE(hook == is_hook,
@@ -5415,6 +5453,11 @@ int dist_gibbs_set_option(dist_gibbs_t * g, const char * name, int value) {
                          "sample_prio / rows_prio: 0 or 0x1abcd");
             (key == "sample_prio" ? g->impl->sample_prio_mode
                                   : g->impl->rows_prio_mode) = value;
+        } else if (key == "apply_overlap") {
+            // k_vs_apply samples a chunk's few handed-over rows while its
+            // other waves add up the moves (1, default) or before (0)
+            DIST_REQUIRE(value == 0 || value == 1, "apply_overlap: 0 or 1");
+            g->impl->apply_overlap_mode = value;
         } else if (key == "value_sorted") {
             DIST_REQUIRE(value >= 0 && value <= 2, "value_sorted: 0, 1 or 2");
             g->impl->value_sorted_mode = value;

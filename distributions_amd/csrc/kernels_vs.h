@@ -32,8 +32,11 @@ constexpr int kVsUnroll = 32;   // entries per scalar-loaded chunk
 // 1.75x the rows per second of v_sub_f32, bit-identical)
 constexpr int kVsR = 2;
 // rows per apply work item (k_vs_apply), all of one value: a multiple of the
-// tile sizes, so a tile's rows lie in one chunk
-constexpr int kVsApplyRows = 4096;
+// tile sizes, so a tile's rows lie in one chunk.  (5120, not 4096: the 3906
+// +- 62 rows a value has in the headline's 10^6-row batches went over 4096 for
+// a value or two in two batches out of ten -- 258 chunks for 256 CUs that take
+// one workgroup each: a second round, k_vs_apply 23 us instead of 14.5.)
+constexpr int kVsApplyRows = 5120;
 struct VsTile {
     uint32_t x;      // the tile's value
     uint32_t pos;    // first position in the sorted row list
@@ -51,6 +54,11 @@ struct VsDefer {
     uint32_t * count;
     uint32_t * chunk_counts;
     const VsTile * chunks;
+    // k_vs_apply: its dynamic LDS in bytes (0: not told).  What lies behind
+    // the sort buffers -- sized by the host's BOUND on the group count, laid
+    // out by the true one -- holds strips of K floats for the rows sampled
+    // WHILE the chunk's other waves add up the moves
+    int lds_bytes;
 };
 __device__ __forceinline__ void vs_hand_over(const VsDefer & D, uint32_t chunk,
                                              uint32_t at) {
@@ -2170,6 +2178,87 @@ void k_vs_stream(
     }
 }
 
+// A handed-over row of a chunk whose value x is known (k_vs_apply), by one
+// wave: RowScorer + wave_row_update's arithmetic to the letter, the loads in a
+// different order.  A row that comes alone pays for latency, not throughput:
+// every slot's cache entry and both driver vectors are requested BEFORE the
+// chain g2p -> counts -> own entry that tells what the row's view is, so the
+// row costs two trips to memory instead of the chain's three plus one per 256
+// slots.  Leaves the move in old_packed / new_packed and returns it.
+template <int KIND>
+__device__ __forceinline__ void vs_deferred_row(
+        const SweepParams & P, float * sl, const uint32_t * s_exp, float ea,
+        float eb, int K, int lane, uint32_t x, size_t row,
+        uint32_t global_id, size_t out, int & g_old, int & g_new) {
+    SlaveView v = P.feat[0];
+    v.kind = KIND;
+    const float lf = KIND == DIST_GP ? fast_log_factorial(x) : 0.f;
+    constexpr int U = 16;
+    Entry e[U];
+    float b[U], bs[U];
+#pragma unroll
+    for (int q = 0; q < U; ++q) {
+        // (slots beyond K read the last one's: loaded, never used)
+        const int k = min(lane + 64 * q, K - 1);
+        e[q] = load_entry(v, k, x);
+        b[q] = P.base[k];
+        bs[q] = P.base_single[k];
+    }
+    // (RowScorer's constructor)
+    const float shift = P.scalars->shift;
+    const int g = P.g2p[global_id];
+    const int n_g = P.counts[g];
+    const bool singleton = (n_g == 1);
+    const int Kl = K - (singleton ? 1 : 0);
+    float s_own;
+    if (!singleton) {
+        s_own = accumulate(KIND, cluster_own_score(P, n_g - 1, shift),
+                           entry_after_remove(v, g, x), x, lf, v.p);
+    } else {   // slot g holds what was the last group
+        const int src = K - 1;
+        s_own = accumulate(KIND, P.base_single[src], load_entry(v, src, x), x,
+                           lf, v.p);
+    }
+    float m = -INFINITY;
+#pragma unroll
+    for (int q = 0; q < U; ++q) {
+        const int k = lane + 64 * q;
+        if (k < Kl) {
+            const float one = bs[q], many = b[q];   // (by value)
+            float s = accumulate(KIND, singleton ? one : many, e[q], x, lf,
+                                 v.p);
+            s = k == g ? s_own : s;
+            sl[k] = s;
+            m = s > m ? s : m;
+        }
+    }
+    for (int k = lane + 64 * U; k < Kl; k += 64) {   // (K > 1024)
+        float s = accumulate(KIND, singleton ? P.base_single[k] : P.base[k],
+                             load_entry(v, k, x), x, lf, v.p);
+        s = k == g ? s_own : s;
+        sl[k] = s;
+        m = s > m ? s : m;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const float o = __shfl_xor(m, off);
+        m = o > m ? o : m;
+    }
+    for (int k = lane; k < ((Kl + 63) & ~63); k += 64)
+        sl[k] = k < Kl ? fast_exp_nonpos(sl[k] - m, s_exp, ea, eb) : 0.f;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const float total = strip_total(sl, Kl);
+    int g2 = strip_sample(sl, Kl, total * batch_row_unif01(P, row));
+    if (singleton && g2 == g) g2 = K - 1;   // slot g held group K-1
+    if (lane == 0) {
+        P.old_packed[out] = (uint32_t)g;
+        P.new_packed[out] = (uint32_t)g2;
+    }
+    g_old = g;
+    g_new = g2;
+}
+
 // Applying a batch's moves in value-sorted order: one workgroup takes up to
 // kVsApplyRows rows of ONE value x and accumulates the per-group change d[k]
 // in LDS.  What every chunk changes alike -- counts[k], and the per-group
@@ -2219,63 +2308,116 @@ __global__ __launch_bounds__(kVsApplyBlock) void k_vs_apply(
     // The rows of this chunk that the tiles handed over (VsDefer: alone in
     // their group, own score above the value's maximum) -- or the whole chunk
     // when its values lie beyond the tables -- are sampled here, a wave per
-    // row as k_rows_wave does it, before the moves are added up: the strips
-    // lie where the sort keeps its copies later on.  (GP's float statistics
-    // want the moves before this kernel runs: the launch in between stays.)
-    if (SORT && KIND != DIST_GP && D.chunk_counts) {
-        const uint32_t n_def = x >= nvals ? n : D.chunk_counts[blockIdx.x];
-        if (n_def) {   // (uniform over the workgroup)
-            __shared__ uint32_t s_exp[1024];
-            for (int i = threadIdx.x; i < 1024; i += kVsApplyBlock)
-                s_exp[i] = g_tables_dev.exp_table[i];
-            __syncthreads();
-            const float ea = u2f(g_tables_dev.exp_ab[0]);
-            const float eb = u2f(g_tables_dev.exp_ab[1]);
-            const int strip = (K + 63) & ~63;
-            const int waves = min(kVsApplyBlock / 64, 4 * kVsApplyRows / strip);
-            const int wave = threadIdx.x >> 6;
-            // (16-byte aligned: the recurrences read them as float4; the host
-            // leaves four words of slack behind the sort's buffers)
-            float * sl = reinterpret_cast<float *>(
-                             ((unsigned long long)rows_l + 15ull) & ~15ull)
-                         + (size_t)wave * strip;
-            if (wave < waves)
-                for (uint32_t item = wave; item < n_def; item += waves) {
-                    const uint32_t at = x >= nvals ? pos + item
-                                                   : D.list[pos + item];
-                    wave_row_update<KIND, -1, 1>(
-                        P, sl, s_exp, ea, eb, K, threadIdx.x & 63,
-                        P.row_begin + sorted_rows[at], assign_pos[at], at);
-                }
-            __syncthreads();   // (their moves are read below)
-            if (threadIdx.x == 0 && x < nvals) D.chunk_counts[blockIdx.x] = 0;
-        }
-    }
+    // row.  (GP's float statistics want the moves before this kernel runs:
+    // the launch in between stays.)
+    uint32_t n_def = 0;
+    if (SORT && KIND != DIST_GP && D.chunk_counts)
+        n_def = x >= nvals ? n : D.chunk_counts[blockIdx.x];
+    __shared__ uint32_t s_exp[1024];
+    if (n_def)   // (uniform over the workgroup)
+        for (int i = threadIdx.x; i < 1024; i += kVsApplyBlock)
+            s_exp[i] = g_tables_dev.exp_table[i];
     for (int k = threadIdx.x; k < K; k += kVsApplyBlock) {
         delta[k] = 0;
         if (SORT) hist[k] = 0;
     }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < n; i += kVsApplyBlock) {
-        const uint32_t go = P.old_packed[pos + i], gn = P.new_packed[pos + i];
-        if (go != gn) {
-            atomicAdd(&delta[go], -1);
-            atomicAdd(&delta[gn], 1);
-            if ((KIND == DIST_GP || KIND == DIST_BNB) && x >= nvals) {
-                // the chunk of counts beyond the value table: every row
-                // brings its own value to the sums
-                const int32_t v = (int32_t)P.values[0][P.row_begin
-                                                      + sorted_rows[pos + i]];
-                atomicAdd(&img.i1[0][go], -v);
-                atomicAdd(&img.i1[0][gn], v);
+    const float ea = u2f(g_tables_dev.exp_ab[0]);
+    const float eb = u2f(g_tables_dev.exp_ab[1]);
+    const int strip = (K + 63) & ~63;
+    const int wave = threadIdx.x >> 6;
+    // A few of them (the usual case: one): the LAST waves take a row each,
+    // in strips of their own, while the others add up the moves of the rest
+    // -- the row's two recurrences (some 1.5 K dependent adds) are longer
+    // than everything else this workgroup does, and used to stand in front
+    // of it.
+    constexpr int kMaxOverlap = 4;
+    const int strips_free =
+        (D.lds_bytes - (int)((2 * K + kVsApplyBlock / 64 + 4 * kVsApplyRows + 4)
+                             * sizeof(int))) / (strip * (int)sizeof(float));
+    const int n_over = (SORT && KIND != DIST_GP && x < nvals
+                        && (int)n_def <= min(strips_free, kMaxOverlap))
+                           ? (int)n_def : 0;
+    if (n_def && !n_over) {
+        // many, or no room: every wave samples, in the strips where the sort
+        // keeps its copies later on, before the moves are added up
+        const int waves = min(kVsApplyBlock / 64, 4 * kVsApplyRows / strip);
+        // (16-byte aligned: the recurrences read them as float4; the host
+        // leaves four words of slack behind the sort's buffers)
+        float * sl = reinterpret_cast<float *>(
+                         ((unsigned long long)rows_l + 15ull) & ~15ull)
+                     + (size_t)wave * strip;
+        if (wave < waves)
+            for (uint32_t item = wave; item < n_def; item += waves) {
+                const uint32_t at = x >= nvals ? pos + item
+                                               : D.list[pos + item];
+                wave_row_update<KIND, -1, 1>(
+                    P, sl, s_exp, ea, eb, K, threadIdx.x & 63,
+                    P.row_begin + sorted_rows[at], assign_pos[at], at);
             }
-        }
-        if (SORT) {
-            rows_l[i] = sorted_rows[pos + i];
-            gn_l[i] = gn;
+        __syncthreads();   // (their moves are read below)
+    }
+    if (n_def && threadIdx.x == 0 && x < nvals) D.chunk_counts[blockIdx.x] = 0;
+    uint32_t skip[kMaxOverlap];
+#pragma unroll
+    for (int j = 0; j < kMaxOverlap; ++j)
+        skip[j] = j < n_over ? D.list[pos + j] - pos : 0xFFFFFFFFu;
+    const int first_over = kVsApplyBlock / 64 - n_over;
+    if (SORT && KIND != DIST_GP && wave >= first_over) {
+        float * sl = reinterpret_cast<float *>(
+                         ((unsigned long long)(gid_s + kVsApplyRows) + 15ull)
+                         & ~15ull)
+                     + (size_t)(wave - first_over) * strip;
+        // (whoever is behind goes first: these waves' recurrences are the
+        // workgroup's critical path)
+        __builtin_amdgcn_s_setprio(3);
+        uint32_t i = 0;
+#pragma unroll
+        for (int j = 0; j < kMaxOverlap; ++j)
+            if (wave == first_over + j) i = skip[j];
+        const uint32_t at = pos + i;
+        const uint32_t srow = sorted_rows[at];
+        int go, gn;
+        vs_deferred_row<KIND>(P, sl, s_exp, ea, eb, K, threadIdx.x & 63, x,
+                              P.row_begin + srow, assign_pos[at], at, go, gn);
+        if ((threadIdx.x & 63) == 0) {
+            if (go != gn) {
+                atomicAdd(&delta[go], -1);
+                atomicAdd(&delta[gn], 1);
+            }
+            rows_l[i] = srow;
+            gn_l[i] = (uint32_t)gn;
             atomicAdd(&hist[gn], 1);
-        } else {
-            assign_pos[pos + i] = p2g[gn];
+        }
+        __builtin_amdgcn_s_setprio(0);
+    } else {
+        const uint32_t step = (uint32_t)first_over * 64u;
+        for (uint32_t i = threadIdx.x; i < n; i += step) {
+            bool handed = false;
+#pragma unroll
+            for (int j = 0; j < kMaxOverlap; ++j) handed = handed || i == skip[j];
+            if (handed) continue;
+            const uint32_t go = P.old_packed[pos + i],
+                           gn = P.new_packed[pos + i];
+            if (go != gn) {
+                atomicAdd(&delta[go], -1);
+                atomicAdd(&delta[gn], 1);
+                if ((KIND == DIST_GP || KIND == DIST_BNB) && x >= nvals) {
+                    // the chunk of counts beyond the value table: every row
+                    // brings its own value to the sums
+                    const int32_t v = (int32_t)P.values[0][P.row_begin
+                                                          + sorted_rows[pos + i]];
+                    atomicAdd(&img.i1[0][go], -v);
+                    atomicAdd(&img.i1[0][gn], v);
+                }
+            }
+            if (SORT) {
+                rows_l[i] = sorted_rows[pos + i];
+                gn_l[i] = gn;
+                atomicAdd(&hist[gn], 1);
+            } else {
+                assign_pos[pos + i] = p2g[gn];
+            }
         }
     }
     __syncthreads();
@@ -2289,6 +2431,7 @@ __global__ __launch_bounds__(kVsApplyBlock) void k_vs_apply(
     // value has).
     const bool defer_cells = SORT && stage && D.chunk_counts
                              && chunks[blockIdx.x].chunk > 1u;
+
     for (int k = threadIdx.x; k < K; k += kVsApplyBlock) {
         const int dlt = delta[k];
         if (stage) stage[(size_t)blockIdx.x * P.K + k] = dlt;
@@ -2333,7 +2476,7 @@ __global__ __launch_bounds__(kVsApplyBlock) void k_vs_apply(
     int sum = 0;
     for (int k = lo; k < hi; ++k) sum += hist[k];
     int incl = sum;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
         const int up = __shfl_up(incl, off);

@@ -613,7 +613,9 @@ int dist_gibbs_sharded_device_normalise_ok(const dist_gibbs_t * g,
  * per-batch score program: 1 | 0), sample_prio / rows_prio (wave priorities
  * by phase in k_vs_sample + k_vs_stream / k_rows_scratch: 0x13210 set-up,
  * first pass, ..., last pass | 0 none -- the A/B of
- * profiles/r5_wave_priorities.txt).
+ * profiles/r5_wave_priorities.txt), apply_overlap (k_vs_apply samples a
+ * chunk's few handed-over rows while its other waves add up the moves: 1 | 0
+ * before they do).
  */
 int dist_gibbs_set_option(dist_gibbs_t * g, const char * name, int value);
 /* how many batches each score+sample kernel has served */

@@ -786,3 +786,36 @@ def test_fused_batches_with_values_of_several_apply_chunks(config, dim,
     # between batches, its runs are not device-normalised at all)
     assert (counts["device_normalised"] > 0) == (config != "gp")
     assert (counts["fused_batches"] > 0) == (not big_values)
+
+
+@pytest.mark.parametrize("config,dim", [("dd", 64), ("dpd", 40), ("bb", None),
+                                        ("bnb", None)])
+@pytest.mark.parametrize("overlap", [1, 0])
+def test_fused_chunks_with_one_or_two_handed_over_rows(config, dim, overlap):
+    """Where a chunk was handed only a few rows (the usual case at full size:
+    a handful of rows alone in their group per value) its last waves sample
+    them, one each, WHILE the others add up the moves of the rest
+    (vs_deferred_row, k_vs_apply; debug.apply_overlap 0: before, as chunks
+    with many do).  Moderate alpha: every batch has such rows, few per chunk.
+    Bit for bit against the oracle either way, validate() after each sweep."""
+    from distributions_amd import engine
+    n, k = 60000, 300
+    osh, gsh, vals, assign = workloads.make(config, n, k, dim=dim, seed=5)
+    orc = ol.OracleMixture(3.0, 0.3, osh)
+    orc.init_from_assignments(vals, assign, k, 2)
+    gpu = engine.Gibbs(3.0, 0.3, gsh)
+    gpu.set_option("value_sorted", 2)
+    gpu.set_option("device_normalise", 1)
+    gpu.set_option("fused_tables", 1)
+    gpu.set_option("debug.apply_overlap", overlap)
+    gpu.load_rows(vals, assign, k, 2)
+    seed = 4242
+    st = ol.oracle().orc_rng_seed(seed)
+    for sweep, batch in enumerate([n, 20000, n, 30000]):
+        for b in range(0, n, batch):
+            orc.gibbs_batch(b, min(n, b + batch), st, sweep * n)
+        gpu.sweep(0, n, batch, seed, draw_base=sweep * n)
+        assert gpu.validate()["code"] == 0
+        assert_same_state(orc, gpu, "%s sweep %d" % (config, sweep))
+    counts = gpu.core.debug_counts()
+    assert counts["fused_batches"] > 0

@@ -22,3 +22,5 @@ step = max(1, len(d) // buckets)
 print("  by tenth of the run:", " ".join(
     "%.1f" % (sum(d[i:i + step]) / len(d[i:i + step]))
     for i in range(0, len(d), step)))
+if len(sys.argv) > 4:   # the last launches one by one
+    print("  last %s:" % sys.argv[4], " ".join("%.1f" % x for x in d[-int(sys.argv[4]):]))
