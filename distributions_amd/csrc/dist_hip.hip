@@ -87,7 +87,8 @@ void ensure_device_ready() {
 static thread_local hipStream_t t_stream = nullptr;
 hipStream_t stream() { return t_stream; }
 
-// the pinned ring behind DeviceBuf::upload (common.h): per host thread
+// the pinned ring behind DeviceBuf::upload (common.h): per host thread and
+// device
 namespace {
 struct UploadRing {
     static constexpr size_t kBytes = 8u << 20, kHalf = kBytes / 2;
@@ -143,8 +144,13 @@ struct UploadRing {
 };
 }  // namespace
 const void * staged_for_upload(const void * host, size_t bytes) {
-    static thread_local UploadRing ring;
-    return ring.stage(host, bytes);
+    // (a ring per device: its events belong to the device that was current
+    // when they were made, and a thread may drive several)
+    static thread_local UploadRing rings[16];
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= 16)
+        return host;
+    return rings[device].stage(host, bytes);
 }
 
 // (y, glibc lgammaf(y)) pairs for the current device's table, sorted by y
