@@ -752,7 +752,7 @@ def test_fused_batches_with_values_of_several_apply_chunks(config, dim,
                                                            big_values):
     """A fused batch's chunks sample the rows they were handed inside
     k_vs_apply, in the launch in which sibling chunks add up their moves.  A
-    value with more than 4096 rows has several chunks: their count cells are
+    value with more than 5120 rows has several chunks: their count cells are
     left to k_vs_reduce (a handed-over row must see the cell as the batch
     found it), and batches with rows beyond the value table of a count model
     (BetaNegativeBinomial / GammaPoisson values > 255: sums changed in place)
