@@ -183,7 +183,13 @@ cdef extern from "distributions_hip.h" nogil:
         pass
     int dist_comm_available()
     int dist_comm_unique_id(uint8_t *)
+    int dist_comm_unique_id_host(uint8_t *)
     dist_comm_t * dist_comm_create(const uint8_t *, int, int)
+    int dist_comm_size(const dist_comm_t *, int *, int *)
+    int dist_comm_all_reduce_dev(dist_comm_t *, void *, size_t, int, int)
+    int dist_gibbs_partition_by_value(dist_gibbs_t *, dist_comm_t *)
+    int dist_gibbs_gather_cells(dist_gibbs_t *, dist_comm_t *)
+    int dist_gibbs_comm_volume(dist_gibbs_t *, uint64_t *, int)
     void dist_comm_destroy(dist_comm_t *)
     int dist_gibbs_sweep_sharded(dist_gibbs_t *, dist_comm_t *, size_t, size_t,
                                  uint32_t, uint64_t)
@@ -1005,8 +1011,17 @@ def comm_unique_id():
     return out
 
 
+def comm_unique_id_host():
+    """128 bytes naming a host (shared-memory) communicator: ranks that share
+    one GPU, where RCCL cannot be used"""
+    cdef cnp.ndarray[cnp.uint8_t, ndim=1] out = np.zeros(128, np.uint8)
+    check(dist_comm_unique_id_host(<uint8_t *> out.data))
+    return out
+
+
 cdef class Comm:
-    """the library's own RCCL communicator (collective constructor)"""
+    """the library's own communicator (collective constructor): RCCL, or the
+    host transport when the id came from comm_unique_id_host()"""
     cdef dist_comm_t * ptr
 
     def __cinit__(self, unique_id, int rank, int world):
@@ -1023,6 +1038,22 @@ cdef class Comm:
     def __dealloc__(self):
         if self.ptr != NULL:
             dist_comm_destroy(self.ptr)
+
+    def size(self):
+        """-> (rank, world)"""
+        cdef int r = 0, w = 0
+        check(dist_comm_size(self.ptr, &r, &w))
+        return r, w
+
+    def all_reduce_dev(self, size_t ptr, size_t count, dtype="int32",
+                       op="sum"):
+        """in place, on device memory; waited for"""
+        cdef int t = {"int32": 0, "float64": 1}[dtype]
+        cdef int o = {"sum": 0, "min": 1}[op]
+        cdef int rc
+        with nogil:
+            rc = dist_comm_all_reduce_dev(self.ptr, <void *> ptr, count, t, o)
+        check(rc)
 
 
 cdef class GibbsEngine:
@@ -1173,6 +1204,29 @@ cdef class GibbsEngine:
             rc = dist_gibbs_sweep_sharded(self.ptr, comm.ptr, n_batches,
                                           batch_rows, seed_state, db)
         check(rc)
+
+    def partition_by_value(self, Comm comm):
+        """collective: no value has rows on two ranks -> sweep_sharded
+        exchanges 3 words per group instead of the cells"""
+        cdef int rc
+        with nogil:
+            rc = dist_gibbs_partition_by_value(self.ptr, comm.ptr)
+        check(rc)
+
+    def gather_cells(self, Comm comm):
+        """collective: make a value-partitioned replica whole again"""
+        cdef int rc
+        with nogil:
+            rc = dist_gibbs_gather_cells(self.ptr, comm.ptr)
+        check(rc)
+
+    def comm_volume(self, reset=False):
+        """-> dict: all-reduces of sweep_sharded, int32 words sent in all,
+        the largest, the last"""
+        cdef uint64_t v[4]
+        check(dist_gibbs_comm_volume(self.ptr, v, 1 if reset else 0))
+        return {"collectives": int(v[0]), "words": int(v[1]),
+                "words_max": int(v[2]), "words_last": int(v[3])}
 
     def batch_sample(self, size_t row_begin, size_t row_end,
                      uint32_t seed_state, draw_base=0):

@@ -18,8 +18,7 @@
 #include <set>
 
 #include "common.h"
-#include <dlfcn.h>
-#include <rccl/rccl.h>   // declarations only: RCCL is bound with dlopen
+#include "comm.h"
 
 #include "kernels.h"
 #include "le_table.h"
@@ -1082,6 +1081,23 @@ struct Gibbs {
     int stream_scratch_mode = 1;   // 0: recompute them in the scan instead
     DeviceBuf<ChainResult> chain_result;
     DeviceBuf<int32_t> delta_image;         // dist_gibbs_sweep_sharded
+    // (what its header words hold: sharded_header's tag, 0 = nothing)
+    uint64_t delta_header_tag = 0;
+    unsigned * comm_fault = nullptr;        // pinned: raised by k_add_words
+    uint64_t comm_words_total = 0, comm_collectives = 0, comm_words_last = 0,
+             comm_words_max = 0;
+    // dist_gibbs_partition_by_value: this rank's rows carry values no other
+    // rank's rows do, so the cells cnt[.][x] of its values are its own and
+    // never travel; cells_partial: the OTHER values' cells here are stale
+    // (dist_gibbs_gather_cells makes the replicas whole again)
+    bool value_partitioned = false, cells_partial = false;
+    DeviceBuf<int32_t> owned_values;        // [dim] 1: this rank's
+    void require_whole(const char * what) const {
+        DIST_REQUIRE(!cells_partial,
+                     std::string(what) + ": the cells of other ranks' values "
+                     "are stale on a value-partitioned rank "
+                     "(dist_gibbs_gather_cells first)");
+    }
     DeviceBuf<float> own_score;             // k_row_prepass
     // general rows: 3 = k_rows_scratch (default), 0 = k_sweep_program, the
     // kernel that stays for feature lists k_rows_scratch's table does not
@@ -1341,6 +1357,7 @@ struct Gibbs {
         if (pinned_counts) (void)hipHostFree(pinned_counts);
         if (pinned_seq) (void)hipHostFree(pinned_seq);
         if (pinned_pairs) (void)hipHostFree(pinned_pairs);
+        if (comm_fault) (void)hipHostFree(comm_fault);
     }
 
     int F() const { return (int)feats.size(); }
@@ -1564,16 +1581,18 @@ struct Gibbs {
         }
     }
 
-    size_t stat_words() const {
-        size_t n = (size_t)K();
-        for (auto & s : feats)
-            n += 2 * (size_t)K() + (size_t)K() * s->dim();
+    // the integer statistics as one image of words, laid out for `k` groups
+    // (group sizes | per feature: i0, i1, cells [k][dim])
+    size_t stat_words(size_t k) const {
+        size_t n = k;
+        for (auto & s : feats) n += 2 * k + k * s->dim();
         return n;
     }
-    StatImage word_image(int32_t * w) {
+    size_t stat_words() const { return stat_words((size_t)K()); }
+    StatImage word_image(int32_t * w) { return word_image(w, (size_t)K()); }
+    StatImage word_image(int32_t * w, size_t k) {
         StatImage img;
         memset(&img, 0, sizeof(img));
-        const size_t k = (size_t)K();
         img.counts = w;
         w += k;
         for (int f = 0; f < F(); ++f) {
@@ -1782,6 +1801,7 @@ struct Gibbs {
         // value tables of the count-valued ones)
         max_value.assign((size_t)F(), 0);
         resume_bound = resume_left = 0;
+        value_partitioned = cells_partial = false;
         vs_cache.clear();
         vs_ranges.clear();
         vs_last = 0;
@@ -3414,6 +3434,23 @@ struct Gibbs {
         if (batch_end == batch_begin) return;
         apply_ints(word_image(delta_dev));
     }
+    // the sharded loop's exchange image: the words of `k` groups (exchange_K)
+    // behind the header; value-partitioned ranks leave the cells out -- they
+    // change their own, in place
+    StatImage exchange_image(int32_t * words, size_t k) {
+        StatImage img = word_image(words, k);
+        if (value_partitioned) img.cnt[0] = feats[0]->cnt.p;
+        return img;
+    }
+    size_t exchange_words(size_t k) const {
+        return value_partitioned ? 3 * k : stat_words(k);
+    }
+    void batch_delta_exchange(int32_t * words, size_t k) {
+        DIST_REQUIRE(batch_open, "no open batch");
+        if (value_partitioned) cells_partial = true;
+        if (batch_end == batch_begin) return;
+        apply_ints(exchange_image(words, k));
+    }
     unsigned long long * pairs_buffer() {
         if ((size_t)K() > pinned_pairs_cap) {
             if (pinned_pairs) (void)hipHostFree(pinned_pairs);
@@ -3427,9 +3464,16 @@ struct Gibbs {
     }
     // clear = leave the image zeroed behind (it is not const then)
     void batch_apply_delta(int32_t * delta_dev, bool clear = false) {
+        CommCheck none;
+        memset(&none, 0, sizeof(none));
+        batch_apply_words(delta_dev, clear, (size_t)K(), true, none);
+    }
+    // k: the group count the image is laid out for; cells: whether it holds
+    // the categorical cells
+    void batch_apply_words(int32_t * delta_dev, bool clear, size_t k,
+                           bool cells, const CommCheck & chk) {
         DIST_REQUIRE(batch_open, "no open batch");
         StatImage a = live_image();
-        const size_t k = (size_t)K();
         WordSegments seg;
         memset(&seg, 0, sizeof(seg));
         size_t off = 0;
@@ -3444,15 +3488,16 @@ struct Gibbs {
         for (int f = 0; f < F(); ++f) {
             push(a.i0[f], k);
             push(a.i1[f], k);
-            push(a.cnt[f], k * feats[f]->dim());
+            if (cells) push(a.cnt[f], k * feats[f]->dim());
         }
         unsigned long long * pairs = nullptr;
         if (!async_active) {   // the host will want the new group sizes
             pairs = pairs_buffer();
             pairs_ticket = ++publish_ticket;
         }
+        early_ticket = 0;   // (sizes published before this are stale now)
         LAUNCH(k_add_words, off, seg, delta_dev, off, clear ? 1 : 0, pairs,
-               pairs_ticket);
+               pairs_ticket, chk);
         // the order-dependent statistics (NICH, GP log_prod) are not in the
         // image: the caller gathers the moves and calls replay_ordered
     }
@@ -3779,6 +3824,36 @@ struct Gibbs {
     // (closing a run never changes one).  So whether open runs go on needs
     // no word between the ranks, and no pass begins with a host round trip.
     size_t resume_bound = 0, resume_left = 0;   // 0: nothing to take up
+    // What the ranks exchange per sub-sweep is sized by the LIVE part of the
+    // group set, not by the run's bound (round 5 sent the bound's image: 8.4
+    // MB where 1.1 MB were in use): a batch's deltas touch the groups that
+    // existed when it was sampled, and every batch can fill each empty group
+    // once, so batch j of a run that began with K0 groups touches slots below
+    // K0 + j * n_empty -- a number every rank knows without asking (the
+    // device's own count, K_seen, arrives asynchronously and is not).  A rank
+    // that closed its run and takes it up again keeps the origin it shared
+    // with its peers.
+    size_t run_origin_K0 = 0, run_origin_done = 0;
+    size_t resume_K0 = 0, resume_done = 0;
+    uint64_t sharded_run_serial = 0;   // runs the ranks agreed to open
+    size_t exchange_K() const {
+        if (!async_active) return (size_t)K();
+        return std::min<size_t>((size_t)K(), run_origin_K0
+                                + run_origin_done * (size_t)py.n_empty);
+    }
+    void forget_resume() { resume_bound = resume_left = 0; }
+    // the exchange's header did not add up (k_add_words, CommCheck): some
+    // rank's run stood elsewhere, the sums applied since are not to be trusted
+    void check_comm_fault() {
+        if (!comm_fault || *comm_fault == 0) return;
+        const unsigned at = *comm_fault & 0x7FFFFFFFu;
+        *comm_fault = 0;
+        poisoned = true;
+        throw Error("ERROR ranks diverged: the header of exchange #"
+                    + std::to_string(at) + " did not add up -- a rank changed "
+                    "its engine between two passes of dist_gibbs_sweep_sharded "
+                    "(or passes a different tiling); the statistics are lost");
+    }
     uint64_t resumed_runs = 0;
     DeviceBuf<int> agree_flag;
     // Is [r0, r1) a range whose batches the fused launch takes, as far as
@@ -3802,6 +3877,7 @@ struct Gibbs {
         return false;
     }
     int async_bound_K = 0;   // the open run's bound on the group count
+    int run_batches_cap = 0; // debug.run_batches_cap (0: none)
     void async_begin(size_t n_first, bool expect_fused = true,
                      size_t forced_bound = 0, size_t forced_left = 0) {
         const int K0 = K();
@@ -3819,6 +3895,10 @@ struct Gibbs {
         if (!async_bound_fits((size_t)K0 + n_batches * ne)
             || n_batches > kAsyncMaxBatches)
             n_batches = n_first;
+        // (debug.run_batches_cap: short runs, so that a test sees one used up)
+        if (run_batches_cap && n_first)
+            n_batches = std::min(n_batches, std::max<size_t>(
+                n_first, (size_t)run_batches_cap / n_first * n_first));
         if (forced_bound) n_batches = forced_left;   // (a run taken up again)
         async_left = n_batches;
         run_batches = 0;
@@ -3833,6 +3913,13 @@ struct Gibbs {
         DIST_REQUIRE((size_t)K0 + n_batches * ne <= (size_t)bound,
                      "internal: a run's bound below what its batches can grow");
         async_bound_K = bound;
+        if (forced_bound) {   // (taken up again: the peers' origin)
+            run_origin_K0 = resume_K0;
+            run_origin_done = resume_done;
+        } else {
+            run_origin_K0 = (size_t)K0;
+            run_origin_done = 0;
+        }
         resume_bound = resume_left = 0;
         py.reserve(bound);
         for (auto & s : feats) s->reserve(bound);
@@ -3952,6 +4039,8 @@ struct Gibbs {
         // (a sharded run: remember what it had left, see resume_bound)
         resume_bound = sharded_batches ? (size_t)async_bound_K : 0;
         resume_left = sharded_batches ? async_left : 0;
+        resume_K0 = run_origin_K0;
+        resume_done = run_origin_done;
         async_active = false;
         collect_comm_timing();
         for (size_t i = 0; i < async_rows.size(); ++i) {
@@ -4015,8 +4104,10 @@ struct Gibbs {
     bool poisoned = false;   // a run could not be closed: state unknown
     void settle() {
         DIST_REQUIRE(!poisoned, "engine state lost: an open device-normalised "
-                                "run failed to close (see the earlier error)");
+                                "run failed to close, or the ranks diverged "
+                                "(see the earlier error)");
         if (async_active && !batch_open) async_end(false);
+        check_comm_fault();
     }
     // the sharded loop (dist_gibbs_sweep_sharded): rank-local conditions; the
     // ranks must agree before they rely on it (engine.ShardedGibbs)
@@ -4038,6 +4129,12 @@ struct Gibbs {
                uint64_t draw_base) {
         DIST_REQUIRE(batch > 0, "batch_rows must be positive");
         DIST_REQUIRE(r0 <= r1 && r1 <= n_rows, "bad row range");
+        // (a rank-local sweep is not a pass of the ranks' run: the run is
+        // closed and not taken up again -- this rank's next sharded pass asks
+        // its peers for a new one, and if they did not sweep likewise the
+        // exchange's header tells, sharded_header)
+        if (async_active && sharded_batches) settle();
+        forget_resume();
         if (async_active) {   // an open run: go on with it, or close it
             if (async_continues(r0, r1, batch)) {
                 sweep_async(r0, r1, batch, seed, draw_base);
@@ -4237,13 +4334,23 @@ struct GibbsRef {
     // call that follows meets the same broken device)
     // (every entry point dereferences inside its own guarded(): a failure
     // while closing an open run is that call's failure, not a later one's)
+    // (... and, unless the entry point is known to leave the chain's state
+    // alone -- read() --, forgets the sharded run this rank could have taken
+    // up again: a rank that CHANGED something between two passes must not
+    // pass for one that went on)
     Gibbs * operator->() const {
         p->settle();
+        p->forget_resume();
         return p.get();
     }
     Gibbs & operator*() const {
         p->settle();
+        p->forget_resume();
         return *p;
+    }
+    Gibbs * read() const {
+        p->settle();
+        return p.get();
     }
     Gibbs * open() const { return p.get(); }
     void reset(Gibbs * q) { p.reset(q); }
@@ -4594,7 +4701,7 @@ dist_le_mixture_t * dist_le_mixture_create(void) {
 }
 void dist_le_mixture_destroy(dist_le_mixture_t * m) { delete m; }
 int dist_le_mixture_init(dist_le_mixture_t * m, const int * counts, size_t n) {
-    return guarded([&] { m->impl.init(0.f, 0.f, counts, n); sync(); });
+    return guarded([&] { m->impl.init(0.f, 0.f, counts, n); dist::sync(); });
 }
 int dist_le_mixture_add_value(dist_le_mixture_t * m, size_t groupid,
                               int * added_out) {
@@ -4646,7 +4753,7 @@ dist_py_mixture_t * dist_py_mixture_create(void) {
 void dist_py_mixture_destroy(dist_py_mixture_t * m) { delete m; }
 int dist_py_mixture_init(dist_py_mixture_t * m, float alpha, float d,
                          const int * counts, size_t n) {
-    return guarded([&] { m->impl.init(alpha, d, counts, n); sync(); });
+    return guarded([&] { m->impl.init(alpha, d, counts, n); dist::sync(); });
 }
 int dist_py_mixture_add_value(dist_py_mixture_t * m, float alpha, float d,
                               size_t groupid, int * added_out) {
@@ -4708,11 +4815,11 @@ int dist_mixture_append(dist_mixture_t * m, const uint32_t * group) {
 }
 int dist_mixture_get_group(const dist_mixture_t * m, size_t groupid,
                            uint32_t * out) {
-    return guarded([&] { sync(); m->impl->get_group(groupid, out); });
+    return guarded([&] { dist::sync(); m->impl->get_group(groupid, out); });
 }
 size_t dist_mixture_size(const dist_mixture_t * m) { return (size_t)m->impl->K; }
 int dist_mixture_init(dist_mixture_t * m) {
-    return guarded([&] { m->impl->init(); sync(); });
+    return guarded([&] { m->impl->init(); dist::sync(); });
 }
 int dist_mixture_add_group(dist_mixture_t * m) {
     return guarded([&] { m->impl->add_group(); });
@@ -5004,20 +5111,26 @@ int dist_gibbs_load_rows_dev(dist_gibbs_t * g, size_t n_rows,
 // with its message in dist_last_error)
 size_t dist_gibbs_stat_words(const dist_gibbs_t * g) {
     size_t n = (size_t)-1;
-    (void)guarded([&] { n = g->impl->stat_words(); });
+    (void)guarded([&] { n = g->impl.read()->stat_words(); });
     return n;
 }
 int dist_gibbs_export_stats_dev(const dist_gibbs_t * g, int32_t * stats_dev) {
-    return guarded([&] { g->impl->copy_stats(stats_dev, true); sync(); });
+    return guarded([&] {
+        g->impl.read()->require_whole("export_stats");
+        g->impl.read()->copy_stats(stats_dev, true);
+        dist::sync();
+    });
 }
 int dist_gibbs_import_stats_dev(dist_gibbs_t * g, const int32_t * stats_dev) {
     return guarded([&] {
         g->impl->copy_stats(const_cast<int32_t *>(stats_dev), false);
         g->impl->resume_bound = g->impl->resume_left = 0;
         g->impl->pairs_ticket = 0;   // whatever a batch published is stale now
+        g->impl->early_ticket = 0;
+        g->impl->cells_partial = false;   // (whole again: the caller's image)
         g->impl->refresh_host_counts();
         g->impl->rebuild_caches();
-        sync();
+        dist::sync();
     });
 }
 int dist_gibbs_sweep(dist_gibbs_t * g, size_t row_begin, size_t row_end,
@@ -5028,60 +5141,6 @@ int dist_gibbs_sweep(dist_gibbs_t * g, size_t row_begin, size_t row_end,
                               draw_base);
     });
 }
-// ---- RCCL, bound at run time ----------------------------------------------
-namespace {
-struct Rccl {
-    void * handle = nullptr;
-    decltype(&ncclGetUniqueId) get_unique_id = nullptr;
-    decltype(&ncclCommInitRank) comm_init_rank = nullptr;
-    decltype(&ncclCommDestroy) comm_destroy = nullptr;
-    decltype(&ncclAllReduce) all_reduce = nullptr;
-    decltype(&ncclGetErrorString) error_string = nullptr;
-    bool ok = false;
-};
-Rccl & rccl() {
-    static Rccl r;
-    static std::once_flag once;
-    std::call_once(once, [] {
-        // the copy that is already in the process wins (PyTorch ships its own)
-        const char * names[] = {"librccl.so.1", "librccl.so",
-                                "/opt/rocm/lib/librccl.so.1"};
-        for (const char * name : names) {
-            r.handle = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
-            if (r.handle) break;
-        }
-        for (const char * name : names) {
-            if (r.handle) break;
-            r.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-        }
-        if (!r.handle) return;
-#define DIST_SYM(field, symbol)                                              \
-        r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.handle, symbol))
-        DIST_SYM(get_unique_id, "ncclGetUniqueId");
-        DIST_SYM(comm_init_rank, "ncclCommInitRank");
-        DIST_SYM(comm_destroy, "ncclCommDestroy");
-        DIST_SYM(all_reduce, "ncclAllReduce");
-        DIST_SYM(error_string, "ncclGetErrorString");
-#undef DIST_SYM
-        r.ok = r.get_unique_id && r.comm_init_rank && r.comm_destroy
-            && r.all_reduce && r.error_string;
-    });
-    return r;
-}
-#define RCCL_CHECK(expr)                                                     \
-    do {                                                                     \
-        ncclResult_t rc_ = (expr);                                           \
-        if (rc_ != ncclSuccess)                                              \
-            throw Error(std::string("RCCL error: ")                          \
-                        + rccl().error_string(rc_) + " at " #expr);          \
-    } while (0)
-}  // namespace
-
-struct dist_comm {
-    ncclComm_t comm = nullptr;
-    int rank = 0, world = 1;
-};
-
 int dist_comm_available(void) { return rccl().ok ? 1 : 0; }
 int dist_comm_unique_id(uint8_t id_out[128]) {
     return guarded([&] {
@@ -5092,18 +5151,43 @@ int dist_comm_unique_id(uint8_t id_out[128]) {
         memcpy(id_out, &id, 128);
     });
 }
+int dist_comm_unique_id_host(uint8_t id_out[128]) {
+    return guarded([&] {
+        memset(id_out, 0, 128);
+        memcpy(id_out, kHostIdMagic, 8);
+        // the segment's name: 8 random bytes + the pid, as hex
+        unsigned char rnd[8] = {0};
+        FILE * f = fopen("/dev/urandom", "rb");
+        const size_t got = f ? fread(rnd, 1, sizeof(rnd), f) : 0;
+        if (f) fclose(f);
+        if (got != sizeof(rnd)) {
+            const uint64_t t = (uint64_t)std::chrono::steady_clock::now()
+                                   .time_since_epoch().count();
+            memcpy(rnd, &t, sizeof(rnd));
+        }
+        char hex[25];
+        snprintf(hex, sizeof(hex), "%02x%02x%02x%02x%02x%02x%02x%02x%08x",
+                 rnd[0], rnd[1], rnd[2], rnd[3], rnd[4], rnd[5], rnd[6],
+                 rnd[7], (unsigned)getpid());
+        memcpy(id_out + 8, hex, 24);
+    });
+}
 dist_comm_t * dist_comm_create(const uint8_t id[128], int rank, int world) {
     dist_comm_t * c = nullptr;
     guarded([&] {
-        DIST_REQUIRE(rccl().ok, "RCCL could not be bound");
         DIST_REQUIRE(world >= 1 && rank >= 0 && rank < world, "bad rank/world");
         ensure_device_ready();
         std::unique_ptr<dist_comm> p(new dist_comm());
-        ncclUniqueId uid;
-        memcpy(&uid, id, 128);
-        RCCL_CHECK(rccl().comm_init_rank(&p->comm, world, uid, rank));
         p->rank = rank;
         p->world = world;
+        if (memcmp(id, kHostIdMagic, 8) == 0) {   // dist_comm_unique_id_host
+            p->host.reset(new HostComm(id, rank, world));
+        } else {
+            DIST_REQUIRE(rccl().ok, "RCCL could not be bound");
+            ncclUniqueId uid;
+            memcpy(&uid, id, 128);
+            RCCL_CHECK(rccl().comm_init_rank(&p->comm, world, uid, rank));
+        }
         c = p.release();
     });
     return c;
@@ -5113,11 +5197,36 @@ void dist_comm_destroy(dist_comm_t * c) {
     if (c->comm && rccl().ok) (void)rccl().comm_destroy(c->comm);
     delete c;
 }
+int dist_comm_size(const dist_comm_t * c, int * rank_out, int * world_out) {
+    return guarded([&] {
+        DIST_REQUIRE(c && c->valid(), "no communicator");
+        if (rank_out) *rank_out = c->rank;
+        if (world_out) *world_out = c->world;
+    });
+}
+int dist_comm_all_reduce_dev(dist_comm_t * c, void * data_dev, size_t count,
+                             int type, int op) {
+    return guarded([&] {
+        DIST_REQUIRE(c && c->valid(), "no communicator");
+        DIST_REQUIRE((type == COMM_I32 || type == COMM_F64)
+                         && (op == COMM_SUM || op == COMM_MIN),
+                     "unknown element type or operation");
+        c->all_reduce(data_dev, count, (CommType)type, (CommOp)op, stream());
+        HIP_CHECK(hipStreamSynchronize(stream()));
+    });
+}
+// (splitmix64's finaliser: the header's signatures)
+static uint64_t mix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
 int dist_gibbs_sweep_sharded(dist_gibbs_t * g, dist_comm_t * c,
                              size_t n_batches, size_t batch_rows,
                              uint32_t seed_state, uint64_t draw_base) {
     return guarded([&] {
-        DIST_REQUIRE(c && c->comm, "no communicator");
+        DIST_REQUIRE(c && c->valid(), "no communicator");
         DIST_REQUIRE(batch_rows > 0, "batch_rows must be positive");
         DIST_REQUIRE(!g->impl.open()->any_float_stats()
                          || g->impl.open()->merged_floats(),
@@ -5129,32 +5238,32 @@ int dist_gibbs_sweep_sharded(dist_gibbs_t * g, dist_comm_t * c,
         // flag when a run is opened: the layout of the delta image depends
         // on it).  Like the single-engine sweep, the run then stays open
         // across passes of the same tiling; any other call settles it.
-        // Whether an open run goes on is decided by ALL ranks, on every
-        // call: a rank whose run was settled in between (any other entry
-        // point does that -- a look at the group count, a checkpoint) would
-        // otherwise issue the one-word agreement while its peers issue the
-        // delta all-reduce, collectives of different size and operation.
         Gibbs * open = g->impl.open();
+        open->check_comm_fault();
         auto agree = [&](Gibbs & e, int mine) {
             e.agree_flag.reserve(1, 0);
             HIP_CHECK(hipMemcpyAsync(e.agree_flag.p, &mine, sizeof(int),
                                      hipMemcpyHostToDevice, stream()));
-            RCCL_CHECK(rccl().all_reduce(e.agree_flag.p, e.agree_flag.p, 1,
-                                         ncclInt32, ncclMin, c->comm,
-                                         stream()));
+            c->all_reduce(e.agree_flag.p, 1, COMM_I32, COMM_MIN, stream());
             e.agree_flag.download(&mine, 1);
             return mine != 0;
         };
         // Does the ranks' run go on?  Decided by every rank for itself, from
         // what is the same on all of them: the tiling of this call and of the
         // run, and the batches the run has left.  A rank that kept its run
-        // open goes on with it; a rank that closed it between the passes --
-        // any look at its state does -- takes it up again with the same bound
-        // and the same batches left (resume_bound): its collectives are the
-        // ones its peers issue.  No word between the ranks, no host round
-        // trip at the start of a pass (round 4 agreed on every call: 50 us
-        // per pass, profiles/r5_collective_pass.txt).  Only when the run is
-        // used up, on every rank at the same call, do they agree on a new one.
+        // open goes on with it; a rank that closed it between the passes by
+        // LOOKING at its state (the entry points that read: GibbsRef::read)
+        // takes it up again with the same bound, the same batches left and
+        // the same origin (resume_bound): its collectives are the ones its
+        // peers issue.  No word between the ranks, no host round trip at the
+        // start of a pass (round 4 agreed on every call: 50 us per pass,
+        // profiles/r5_collective_pass.txt).  Only when the run is used up, on
+        // every rank at the same call, do they agree on a new one.  A rank
+        // that CHANGED something in between (any other entry point: options,
+        // rows, statistics, a sweep of its own) has forgotten the run and asks
+        // for a new one here while its peers go on: a caller's error, told by
+        // the host transport at once (collectives of different sizes) and,
+        // where the sizes happen to agree, by the exchange's header.
         const bool tiling_same = open->sharded_batches == n_batches
                                  && open->sharded_batch_rows == batch_rows;
         bool on_device = false;
@@ -5173,16 +5282,16 @@ int dist_gibbs_sweep_sharded(dist_gibbs_t * g, dist_comm_t * c,
             on_device = true;
         }
         if (!on_device) {
-            Gibbs & s = *g->impl;   // (settles an open run)
-            s.resume_bound = s.resume_left = 0;
+            Gibbs & s = *g->impl;   // (settles an open run, forgets it)
             on_device = agree(
                 s, s.sharded_device_normalise
                        && s.async_eligible_sharded(n_batches, batch_rows)
                    ? 1 : 0);
+            s.sharded_run_serial += 1;
             if (on_device) {
-                // (the run's bound on the group count fixes the delta
-                // image's layout: the same on every rank, so not a function
-                // of what this rank's ranges look like)
+                // (the run's bound on the group count sizes the buffers: the
+                // same on every rank, so not a function of what this rank's
+                // ranges look like)
                 s.async_begin(n_batches);
                 s.sharded_batches = n_batches;
                 s.sharded_batch_rows = batch_rows;
@@ -5195,21 +5304,54 @@ int dist_gibbs_sweep_sharded(dist_gibbs_t * g, dist_comm_t * c,
             e.async_left -= std::min(e.async_left, n_batches);
             e.async_peek_collect();
         }
+        if (!e.comm_fault) {
+            HIP_CHECK(hipHostMalloc((void **)&e.comm_fault, sizeof(unsigned),
+                                    hipHostMallocDefault));
+            *e.comm_fault = 0;
+        }
+        const int ne = e.py.n_empty;
+        // where this rank believes the ranks' run stands at batch `done` of
+        // it, exchanging `kx` groups: two 12-bit signatures
+        auto signature = [&](size_t done, size_t kx, uint64_t & tag) {
+            uint64_t h = mix64(e.sharded_run_serial);
+            h = mix64(h ^ (uint64_t)done);
+            h = mix64(h ^ (uint64_t)kx);
+            h = mix64(h ^ (uint64_t)n_batches);
+            h = mix64(h ^ (uint64_t)batch_rows);
+            h = mix64(h ^ (uint64_t)(e.value_partitioned ? 1 : 0));
+            h = mix64(h ^ (uint64_t)(on_device ? 1 : 0));
+            tag = h | 1ull;
+            return std::make_pair((int32_t)(h & 0xFFF),
+                                  (int32_t)((h >> 12) & 0xFFF));
+        };
         try {
             for (size_t b = 0; b < n_batches; ++b) {
                 const size_t r0 = std::min(e.n_rows, b * batch_rows);
                 const size_t r1 = std::min(e.n_rows, r0 + batch_rows);
+                // the groups this batch's deltas can touch: rank-independent
+                // (the run's bound only sizes buffers, see exchange_K)
+                const size_t kx = e.exchange_K();
+                const size_t done = on_device ? e.run_origin_done : b;
                 if (on_device) e.async_sample(r0, r1, seed_state, draw_base);
                 else e.batch_sample(r0, r1, seed_state, draw_base);
-                const size_t words = e.stat_words();
+                const size_t words = e.exchange_words(kx);
+                const size_t total = kCommHeaderWords + words;
                 // the exchange buffer is zeroed once; k_add_words clears what
                 // it consumes, so it is all zero again before every batch
-                if (words > e.delta_image.cap || !e.delta_image.p) {
-                    e.delta_image.reserve(grow_capacity(words), 0);
+                if (total > e.delta_image.cap || !e.delta_image.p) {
+                    e.delta_image.reserve(grow_capacity(total), 0);
                     HIP_CHECK(hipMemsetAsync(e.delta_image.p, 0,
                                              e.delta_image.cap * 4, stream()));
+                    e.delta_header_tag = 0;
                 }
-                e.batch_delta(e.delta_image.p, true);
+                int32_t * image = e.delta_image.p + kCommHeaderWords;
+                uint64_t tag = 0;
+                const auto sig = signature(done, kx, tag);
+                if (e.delta_header_tag != tag)   // (not left by the last batch)
+                    hipLaunchKernelGGL(k_comm_header, dim3(1), dim3(1), 0,
+                                       stream(), e.delta_image.p, sig.first,
+                                       sig.second);
+                e.batch_delta_exchange(image, kx);
                 // in place, on the engine's stream: no hop to another stream
                 const bool timed = e.kernel_timing > 0
                                    && e.comm_tick++ % (uint64_t)e.kernel_timing
@@ -5220,20 +5362,50 @@ int dist_gibbs_sweep_sharded(dist_gibbs_t * g, dist_comm_t * c,
                     t1 = e.comm_event();
                     HIP_CHECK(hipEventRecord(t0, stream()));
                 }
-                RCCL_CHECK(rccl().all_reduce(e.delta_image.p, e.delta_image.p,
-                                             words, ncclInt32, ncclSum,
-                                             c->comm, stream()));
+                c->all_reduce(e.delta_image.p, total, COMM_I32, COMM_SUM,
+                              stream());
+                e.comm_collectives += 1;
+                e.comm_words_total += total;
+                e.comm_words_last = total;
+                e.comm_words_max = std::max<uint64_t>(e.comm_words_max, total);
                 if (timed) {
                     HIP_CHECK(hipEventRecord(t1, stream()));
                     e.comm_ev_pending.emplace_back(t0, t1);
                 }
-                e.batch_apply_delta(e.delta_image.p, true);
+                // the kernel that consumes the sum checks the header and
+                // leaves the NEXT batch's behind (no launch of its own then)
+                CommCheck chk;
+                memset(&chk, 0, sizeof(chk));
+                chk.header = e.delta_image.p;
+                chk.world = c->world;
+                chk.fault = e.comm_fault;
+                chk.tag = (unsigned)(e.comm_collectives & 0x7FFFFFFFu)
+                          | 0x80000000u;
+                e.delta_header_tag = 0;
+                if (b + 1 < n_batches) {
+                    const size_t kx_next =
+                        on_device ? std::min<size_t>(
+                                        (size_t)e.K(),
+                                        e.run_origin_K0
+                                            + (e.run_origin_done + 1) * (size_t)ne)
+                                  : 0;
+                    if (on_device) {
+                        uint64_t tag_next = 0;
+                        const auto nx = signature(done + 1, kx_next, tag_next);
+                        chk.next[0] = nx.first;
+                        chk.next[1] = nx.first * nx.first;
+                        chk.next[2] = nx.second;
+                        chk.next[3] = nx.second * nx.second;
+                        e.delta_header_tag = tag_next;
+                    }
+                }
+                e.batch_apply_words(image, true, kx, !e.value_partitioned, chk);
+                if (on_device) e.run_origin_done += 1;
                 if (e.merged_floats()) {   // the float statistics as sums
                     e.merge_float_delta();
-                    RCCL_CHECK(rccl().all_reduce(
-                        e.merge_image.p, e.merge_image.p,
-                        (size_t)e.merge_layout().words, ncclDouble, ncclSum,
-                        c->comm, stream()));
+                    c->all_reduce(e.merge_image.p,
+                                  (size_t)e.merge_layout().words, COMM_F64,
+                                  COMM_SUM, stream());
                     e.merge_float_apply(e.merge_image.p);
                 }
                 if (on_device) e.batch_finish_device();
@@ -5245,10 +5417,82 @@ int dist_gibbs_sweep_sharded(dist_gibbs_t * g, dist_comm_t * c,
             throw;
         }
         if (!on_device) {
-            sync();
+            dist::sync();
             e.collect_comm_timing();
+            e.check_comm_fault();
         }
         // (an on-device run stays open: Gibbs::settle)
+    });
+}
+
+// ---- value-partitioned ranks ------------------------------------------------
+int dist_gibbs_partition_by_value(dist_gibbs_t * g, dist_comm_t * c) {
+    return guarded([&] {
+        DIST_REQUIRE(c && c->valid(), "no communicator");
+        Gibbs & e = *g->impl;
+        DIST_REQUIRE(e.F() == 1 && is_cat(e.feats[0]->sh.kind)
+                         && e.feats[0]->dim() > 0,
+                     "value partitioning takes engines with one categorical "
+                     "feature (DirichletDiscrete, DirichletProcessDiscrete)");
+        DIST_REQUIRE(!e.batch_open, "a batch is open");
+        const int dim = e.feats[0]->dim();
+        DeviceBuf<int32_t> has;
+        has.reserve((size_t)dim * 2, 0);   // [mine | everybody's]
+        if (e.n_rows)
+            LAUNCH(k_value_presence,
+                   std::min<size_t>(e.n_rows, (size_t)2048 * kBlock),
+                   e.values[0], e.n_rows, dim, has.p);
+        HIP_CHECK(hipMemcpyAsync(has.p + dim, has.p, (size_t)dim * 4,
+                                 hipMemcpyDeviceToDevice, stream()));
+        c->all_reduce(has.p + dim, (size_t)dim, COMM_I32, COMM_SUM, stream());
+        std::vector<int32_t> h((size_t)dim * 2);
+        has.download(h.data(), h.size());
+        std::vector<int32_t> owned((size_t)dim);
+        for (int x = 0; x < dim; ++x) {
+            DIST_REQUIRE(h[(size_t)dim + x] <= 1,
+                         "value " + std::to_string(x) + " has rows on "
+                         + std::to_string(h[(size_t)dim + x])
+                         + " ranks: not a partition by value");
+            // (a value nobody has rows of: its cells never change; rank 0's)
+            owned[x] = h[x] || (h[(size_t)dim + x] == 0 && c->rank == 0);
+        }
+        e.owned_values.upload(owned.data(), owned.size());
+        e.value_partitioned = true;
+        dist::sync();
+    });
+}
+int dist_gibbs_gather_cells(dist_gibbs_t * g, dist_comm_t * c) {
+    return guarded([&] {
+        DIST_REQUIRE(c && c->valid(), "no communicator");
+        Gibbs & e = *g->impl.read();
+        DIST_REQUIRE(e.value_partitioned, "not a value-partitioned engine");
+        DIST_REQUIRE(!e.batch_open, "a batch is open");
+        const int dim = e.feats[0]->dim();
+        const size_t cells = (size_t)e.K() * dim;
+        DeviceBuf<int32_t> image;
+        image.reserve(std::max<size_t>(cells, 1), 0);
+        if (cells)
+            LAUNCH(k_owned_cells, cells, e.feats[0]->cnt.p, e.owned_values.p,
+                   cells, dim, image.p);
+        c->all_reduce(image.p, cells, COMM_I32, COMM_SUM, stream());
+        if (cells)
+            HIP_CHECK(hipMemcpyAsync(e.feats[0]->cnt.p, image.p, cells * 4,
+                                     hipMemcpyDeviceToDevice, stream()));
+        e.cells_partial = false;
+        e.rebuild_caches();
+        dist::sync();
+    });
+}
+int dist_gibbs_comm_volume(dist_gibbs_t * g, uint64_t out[4], int reset) {
+    return guarded([&] {
+        Gibbs * e = g->impl.open();   // (counters only: the run stays open)
+        out[0] = e->comm_collectives;
+        out[1] = e->comm_words_total;
+        out[2] = e->comm_words_max;
+        out[3] = e->comm_words_last;
+        if (reset)
+            e->comm_collectives = e->comm_words_total = e->comm_words_max =
+                e->comm_words_last = 0;
     });
 }
 
@@ -5281,7 +5525,7 @@ int dist_gibbs_batch_apply_local(dist_gibbs_t * g) {
 int dist_gibbs_ordered_features(const dist_gibbs_t * g, int * count_out) {
     return guarded([&] {
         int n = 0;
-        for (auto & f : g->impl->feats)
+        for (auto & f : g->impl.read()->feats)
             if (has_float_stats(f->sh.kind)) n += 1;
         *count_out = n;
     });
@@ -5310,7 +5554,7 @@ size_t dist_gibbs_float_delta_words(const dist_gibbs_t * g) {
 }
 int dist_gibbs_export_float_moments_dev(dist_gibbs_t * g, double * out_dev) {
     return guarded([&] {
-        Gibbs & e = *g->impl;
+        Gibbs & e = *g->impl.read();
         DIST_REQUIRE(!e.batch_open, "a batch is open");
         DIST_REQUIRE(e.merged_floats(), "float_stats is not 1 (merged)");
         const MergeLayout L = e.merge_layout();
@@ -5326,7 +5570,7 @@ int dist_gibbs_import_float_moments_dev(dist_gibbs_t * g,
         DIST_REQUIRE(e.merged_floats(), "float_stats is not 1 (merged)");
         e.merge_float_apply(image_dev, true);
         e.rebuild_caches();
-        sync();
+        dist::sync();
     });
 }
 int dist_gibbs_batch_float_delta_dev(dist_gibbs_t * g, double * delta_dev) {
@@ -5354,18 +5598,18 @@ int dist_gibbs_batch_finish(dist_gibbs_t * g) {
 }
 int dist_gibbs_row_scores(dist_gibbs_t * g, size_t row, float * scores_out,
                           size_t * size_out) {
-    return guarded([&] { g->impl->get_row_scores(row, scores_out, size_out); });
+    return guarded([&] { g->impl.read()->get_row_scores(row, scores_out, size_out); });
 }
 int dist_gibbs_score_rows_dev(dist_gibbs_t * g, size_t row_begin,
                               size_t row_end, float * scores_dev, size_t ld) {
     return guarded([&] {
-        g->impl->score_rows(row_begin, row_end, scores_dev, ld);
-        sync();
+        g->impl.read()->score_rows(row_begin, row_end, scores_dev, ld);
+        dist::sync();
     });
 }
 size_t dist_gibbs_group_count(const dist_gibbs_t * g) {
     size_t n = (size_t)-1;
-    (void)guarded([&] { n = (size_t)g->impl->K(); });
+    (void)guarded([&] { n = (size_t)g->impl.read()->K(); });
     return n;
 }
 size_t dist_gibbs_row_count(const dist_gibbs_t * g) {
@@ -5373,48 +5617,49 @@ size_t dist_gibbs_row_count(const dist_gibbs_t * g) {
 }
 int dist_gibbs_counts(const dist_gibbs_t * g, int * out) {
     return guarded([&] {
-        std::vector<int> dev((size_t)g->impl->K());
-        g->impl->py.d_counts.download(dev.data(), dev.size());
+        std::vector<int> dev((size_t)g->impl.read()->K());
+        g->impl.read()->py.d_counts.download(dev.data(), dev.size());
         std::copy(dev.begin(), dev.end(), out);
     });
 }
 int dist_gibbs_assignments(const dist_gibbs_t * g, uint32_t * global_out) {
     return guarded([&] {
-        g->impl->flush_assign_pos();
-        sync();
-        if (g->impl->n_rows) {
-            HIP_CHECK(hipMemcpyAsync(global_out, g->impl->assign,
-                                     g->impl->n_rows * 4,
+        g->impl.read()->flush_assign_pos();
+        dist::sync();
+        if (g->impl.read()->n_rows) {
+            HIP_CHECK(hipMemcpyAsync(global_out, g->impl.read()->assign,
+                                     g->impl.read()->n_rows * 4,
                                      hipMemcpyDeviceToHost, stream()));
-            sync();
+            dist::sync();
         }
     });
 }
 int dist_gibbs_get_group(const dist_gibbs_t * g, int feature, size_t groupid,
                          uint32_t * group_out) {
     return guarded([&] {
-        DIST_REQUIRE(feature >= 0 && feature < g->impl->F(), "bad feature");
-        sync();
-        g->impl->feats[feature]->get_group(groupid, group_out);
+        DIST_REQUIRE(feature >= 0 && feature < g->impl.read()->F(), "bad feature");
+        g->impl.read()->require_whole("get_group");
+        dist::sync();
+        g->impl.read()->feats[feature]->get_group(groupid, group_out);
     });
 }
 int dist_gibbs_packed_to_global(const dist_gibbs_t * g, uint32_t packed,
                                 uint32_t * out) {
-    return guarded([&] { *out = g->impl->tracker.packed_to_global(packed); });
+    return guarded([&] { *out = g->impl.read()->tracker.packed_to_global(packed); });
 }
 int dist_gibbs_global_to_packed(const dist_gibbs_t * g, uint32_t global,
                                 uint32_t * out) {
-    return guarded([&] { *out = g->impl->tracker.global_to_packed(global); });
+    return guarded([&] { *out = g->impl.read()->tracker.global_to_packed(global); });
 }
 size_t dist_gibbs_global_size(const dist_gibbs_t * g) {
     size_t n = (size_t)-1;
-    (void)guarded([&] { n = g->impl->tracker.g2p.size(); });
+    (void)guarded([&] { n = g->impl.read()->tracker.g2p.size(); });
     return n;
 }
 int dist_gibbs_validate(dist_gibbs_t * g, dist_validate_report_t * report) {
     dist_validate_report_t local;
     dist_validate_report_t * rep = report ? report : &local;
-    const int rc = guarded([&] { g->impl->validate(rep); });
+    const int rc = guarded([&] { g->impl.read()->validate(rep); });
     if (rc) return rc;
     if (rep->code == 0) return 0;
     char msg[256];
@@ -5432,7 +5677,7 @@ int dist_gibbs_sharded_device_normalise_ok(const dist_gibbs_t * g,
                                            size_t n_batches,
                                            size_t batch_rows, int * ok_out) {
     return guarded([&] {
-        *ok_out = g->impl->async_eligible_sharded(n_batches, batch_rows) ? 1 : 0;
+        *ok_out = g->impl.read()->async_eligible_sharded(n_batches, batch_rows) ? 1 : 0;
     });
 }
 int dist_gibbs_set_option(dist_gibbs_t * g, const char * name, int value) {
@@ -5447,7 +5692,7 @@ int dist_gibbs_set_option(dist_gibbs_t * g, const char * name, int value) {
             "sequential_chain", "running_sums_min_tiles", "narrow_read_ahead",
             "stream_scratch", "rows_scratch", "rows_scratch_lds_log",
             "rows_scratch_block", "rows_fold", "apply_stage", "program_all",
-            "sample_prio", "rows_prio", "apply_overlap"};
+            "sample_prio", "rows_prio", "apply_overlap", "run_batches_cap"};
         bool is_hook = false;
         for (const char * h : hooks) is_hook = is_hook || key == h;
         DIST_REQUIRE(hook == is_hook,
@@ -5459,6 +5704,11 @@ int dist_gibbs_set_option(dist_gibbs_t * g, const char * name, int value) {
                          "sample_prio / rows_prio: 0 or 0x1abcd");
             (key == "sample_prio" ? g->impl->sample_prio_mode
                                   : g->impl->rows_prio_mode) = value;
+        } else if (key == "run_batches_cap") {
+            // a device-normalised run covers at most this many batches (a
+            // whole number of passes, at least one); 0: as many as fit
+            DIST_REQUIRE(value >= 0, "run_batches_cap: >= 0");
+            g->impl->run_batches_cap = value;
         } else if (key == "apply_overlap") {
             // k_vs_apply samples a chunk's few handed-over rows while its
             // other waves add up the moves (1, default) or before (0)
@@ -5574,13 +5824,13 @@ int dist_gibbs_set_option(dist_gibbs_t * g, const char * name, int value) {
 int dist_gibbs_path_counts(const dist_gibbs_t * g, uint64_t * value_sorted,
                            uint64_t * generic) {
     return guarded([&] {
-        *value_sorted = g->impl->vs_batches;
-        *generic = g->impl->generic_batches;
+        *value_sorted = g->impl.read()->vs_batches;
+        *generic = g->impl.read()->generic_batches;
     });
 }
 int dist_gibbs_debug_counts(dist_gibbs_t * g, uint64_t * out, size_t n) {
     return guarded([&] {
-        Gibbs & e = *g->impl;
+        Gibbs & e = *g->impl.read();
         uint64_t v[15] = {e.vs_batches, e.generic_batches, e.band_batches,
                           e.prefix_batches, 0, 0, e.stream_batches,
                           e.async_batches, e.narrow_batches,
@@ -5604,7 +5854,7 @@ int dist_gibbs_debug_counts(dist_gibbs_t * g, uint64_t * out, size_t n) {
 int dist_gibbs_phase_stats(dist_gibbs_t * g, double ms_out[5],
                            uint64_t * batches_out, int reset) {
     return guarded([&] {
-        Gibbs & e = *g->impl;   // (settles an open run: its events are read)
+        Gibbs & e = *g->impl.read();   // (settles an open run: its events are read)
         e.collect_comm_timing();
         for (int i = 0; i < Gibbs::kPhases; ++i) ms_out[i] = e.phase_ms[i];
         *batches_out = e.phase_batches;
@@ -5617,7 +5867,7 @@ int dist_gibbs_phase_stats(dist_gibbs_t * g, double ms_out[5],
 int dist_gibbs_comm_stats(dist_gibbs_t * g, double * ms_out,
                           uint64_t * launches_out, int reset) {
     return guarded([&] {
-        Gibbs & e = *g->impl;   // (settles an open run: its events are read)
+        Gibbs & e = *g->impl.read();   // (settles an open run: its events are read)
         e.collect_comm_timing();
         if (ms_out) *ms_out = e.comm_ms;
         if (launches_out) *launches_out = e.comm_launches;
@@ -5631,13 +5881,13 @@ int dist_gibbs_kernel_stats(dist_gibbs_t * g, double * ms_out,
                             uint64_t * launches_out, uint64_t * rows_out,
                             int reset) {
     return guarded([&] {
-        if (ms_out) *ms_out = g->impl->kernel_ms;
-        if (launches_out) *launches_out = g->impl->kernel_launches;
-        if (rows_out) *rows_out = g->impl->kernel_rows;
+        if (ms_out) *ms_out = g->impl.read()->kernel_ms;
+        if (launches_out) *launches_out = g->impl.read()->kernel_launches;
+        if (rows_out) *rows_out = g->impl.read()->kernel_rows;
         if (reset) {
-            g->impl->kernel_ms = 0.0;
-            g->impl->kernel_launches = 0;
-            g->impl->kernel_rows = 0;
+            g->impl.read()->kernel_ms = 0.0;
+            g->impl.read()->kernel_launches = 0;
+            g->impl.read()->kernel_rows = 0;
         }
     });
 }

@@ -196,6 +196,32 @@ struct WordSegments {
     int32_t * dst[1 + 3 * kMaxF];
     unsigned long long end[1 + 3 * kMaxF];   // running end offset in the image
 };
+// The header of the ranks' exchange (dist_gibbs_sweep_sharded).  In front of
+// its delta image every rank puts two 12-bit signatures of where it believes
+// the ranks' run stands -- run serial, batch index, groups exchanged, tiling --
+// each as (x, x * x).  After the sum over W ranks, W * sum(x^2) == (sum x)^2
+// holds if and only if every rank put the same x (Cauchy-Schwarz; exact:
+// 64 * 4095^2 < 2^31).  A rank that changed something between two passes, or
+// whose run stands elsewhere, therefore shows up in the very collective its
+// peers issue, without a word of its own and without a host round trip: the
+// kernel that consumes the sum raises `fault` in pinned host memory, and the
+// engine's next entry point fails with "ranks diverged".  (Collectives of
+// DIFFERENT sizes cannot be told this way -- RCCL hangs on them; the host
+// transport, comm.h, checks sizes too.)
+constexpr int kCommHeaderWords = 4;
+struct CommCheck {
+    int32_t * header;      // null: no check
+    int world;
+    unsigned * fault;      // pinned host word
+    unsigned tag;          // what to raise
+    int32_t next[kCommHeaderWords];   // left behind for the next batch
+};
+__global__ void k_comm_header(int32_t * header, int32_t a, int32_t b) {
+    header[0] = a;
+    header[1] = a * a;
+    header[2] = b;
+    header[3] = b * b;
+}
 // clear: leave the image zeroed for the next batch (the library's own
 // exchange buffer is never memset again).  host_pairs: segment 0 is the group
 // sizes; their new values go to pinned host memory with the batch's ticket
@@ -203,8 +229,18 @@ struct WordSegments {
 __global__ void k_add_words(WordSegments seg, int32_t * __restrict__ src,
                             size_t total, int clear,
                             unsigned long long * host_pairs,
-                            unsigned int seq) {
+                            unsigned int seq, CommCheck chk) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0 && chk.header) {
+        const long long w = chk.world;
+        const long long s1 = chk.header[0], q1 = chk.header[1],
+                        s2 = chk.header[2], q2 = chk.header[3];
+        if (w * q1 != s1 * s1 || w * q2 != s2 * s2)
+            __hip_atomic_store(chk.fault, chk.tag, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
+#pragma unroll
+        for (int j = 0; j < kCommHeaderWords; ++j) chk.header[j] = chk.next[j];
+    }
     if (i >= total) return;
     int j = 0;
     while (i >= seg.end[j]) ++j;
@@ -218,6 +254,25 @@ __global__ void k_add_words(WordSegments seg, int32_t * __restrict__ src,
         seg.dst[j][i - begin] += d;
     }
     if (clear && d) src[i] = 0;
+}
+
+// value-partitioned ranks (dist_gibbs_partition_by_value): which values have
+// rows here, and the cells of the values a rank owns (zero elsewhere) -- the
+// summands of dist_gibbs_gather_cells
+__global__ void k_value_presence(const uint32_t * __restrict__ values,
+                                 size_t n, int dim, int32_t * has) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t x = values[i];
+        if (x < (uint32_t)dim && has[x] == 0) has[x] = 1;   // (benign race)
+    }
+}
+__global__ void k_owned_cells(const int32_t * __restrict__ cnt,
+                              const int32_t * __restrict__ owned, size_t cells,
+                              int dim, int32_t * out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cells) return;
+    out[i] = owned[i % (size_t)dim] ? cnt[i] : 0;
 }
 
 // dst += the staged rows of k_apply_moves_stage, summed per word

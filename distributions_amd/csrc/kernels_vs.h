@@ -2638,7 +2638,11 @@ void k_vs_reduce(StatImage img, const int32_t * __restrict__ stage,
     const int slice = threadIdx.x / kVsReduceGroups;
     const int k = blockIdx.x * kVsReduceGroups + kk;
     int a = 0, b = 0;   // a: plain sum; b: BB heads part / GP value-weighted
-    if (k < k_limit) {   // (slots past the group count: nothing is used)
+    // (slots past the group count of record: k_vs_apply staged nothing there
+    // -- the words are stale -- and a delta image laid out for the live part
+    // of the group set, Gibbs::exchange_K, has no room for them)
+    (void)k_limit;
+    if (k < K) {
         for (uint32_t c = slice; c < n_chunks; c += kVsReduceSlices) {
             const int d = stage[(size_t)c * stride + k];
             const uint32_t x = chunks[c].x;
@@ -2651,7 +2655,7 @@ void k_vs_reduce(StatImage img, const int32_t * __restrict__ stage,
     // the cells k_vs_apply left to this kernel (a fused batch's values with
     // several chunks; multi[] = {value, first chunk, chunks} each): thread
     // (k, slice) owns cell (k, x) of the slice's values
-    if ((KIND == DIST_DD || KIND == DIST_DPD) && k < k_limit)
+    if ((KIND == DIST_DD || KIND == DIST_DPD) && k < K)
         for (uint32_t m = slice; m < n_multi; m += kVsReduceSlices) {
             const uint32_t x = multi[3 * m], c0 = multi[3 * m + 1],
                            nc = multi[3 * m + 2];

@@ -300,33 +300,45 @@ class ShardedGibbs(object):
             self._replay(None, self.assign_packed, cols, int(nmax.item()),
                          reset=True)
 
-    def use_native_comm(self, comm=None):
-        """Give the library its own RCCL communicator (or share `comm`, the
-        `native_comm` of another engine of this process group): the sub-sweep loop then
-        runs inside it, the all-reduce on the engine's stream (no Python and
-        no stream hop per sub-sweep).  Collective.  Returns False -- and the
-        torch.distributed path stays in use -- when the backend is not RCCL,
-        the engine has order-dependent statistics, or RCCL cannot be bound."""
-        import numpy as np
+    def use_native_comm(self, comm=None, transport=None):
+        """Give the library its own communicator (or share `comm`, the
+        `native_comm` of another engine of this process group): the sub-sweep
+        loop then runs inside it, the all-reduce on the engine's stream (no
+        Python and no stream hop per sub-sweep).  Collective.  transport:
+        "rccl" (the default under an NCCL process group) or "host" -- the
+        library's shared-memory transport for ranks that share one GPU (the
+        default under gloo with device tensors: RCCL refuses two ranks on a
+        device).  Returns False -- and the torch.distributed path stays in use
+        -- when the engine has order-dependent statistics or the transport
+        cannot be had."""
         import torch
         core = self.backend
         if not (self.collective and not self.ordered
-                and hasattr(core, "sweep_sharded")
-                and self.dist.get_backend(self.group) == "nccl"):
+                and hasattr(core, "sweep_sharded")):
+            return False
+        backend = self.dist.get_backend(self.group)
+        if transport is None:
+            transport = "rccl" if backend == "nccl" else "host"
+        if transport == "rccl" and backend != "nccl":
             return False
         from . import _core
         if comm is not None:
             self._comm = comm
             return True
-        ok = torch.tensor([1 if _core.comm_available() else 0],
-                          dtype=torch.int32, device=self.device)
-        self._all_reduce(ok, op=self.dist.ReduceOp.MIN)
+        # (flags and the id travel on whatever the process group moves:
+        # device tensors under NCCL, host tensors under gloo)
+        where = self.device if backend == "nccl" else "cpu"
+        have = transport == "host" or _core.comm_available()
+        ok = torch.tensor([1 if have else 0], dtype=torch.int32, device=where)
+        self.dist.all_reduce(ok, op=self.dist.ReduceOp.MIN, group=self.group)
         if not int(ok.item()):
             return False
         rank = self.dist.get_rank(self.group)
-        uid = torch.zeros(128, dtype=torch.uint8, device=self.device)
+        uid = torch.zeros(128, dtype=torch.uint8, device=where)
         if rank == 0:
-            uid.copy_(torch.from_numpy(_core.comm_unique_id()))
+            make = (_core.comm_unique_id_host if transport == "host"
+                    else _core.comm_unique_id)
+            uid.copy_(torch.from_numpy(make()))
         self.dist.broadcast(uid, src=self.dist.get_global_rank(
             self.group, 0) if self.group is not None else 0, group=self.group)
         try:
@@ -334,11 +346,25 @@ class ShardedGibbs(object):
         except RuntimeError:
             comm = None
         ok.fill_(0 if comm is None else 1)   # all ranks or none
-        self._all_reduce(ok, op=self.dist.ReduceOp.MIN)
+        self.dist.all_reduce(ok, op=self.dist.ReduceOp.MIN, group=self.group)
         if not int(ok.item()):
             return False
         self._comm = comm
         return True
+
+    def partition_by_value(self):
+        """Collective, with a native communicator, after sync_initial_stats:
+        the rows are placed so that no value of the (one, categorical)
+        feature has rows on two ranks -- checked -- and the sub-sweeps
+        exchange 3 words per group instead of the cells."""
+        if self._comm is None:
+            raise RuntimeError("partition_by_value needs use_native_comm()")
+        self.backend.partition_by_value(self._comm)
+
+    def gather_cells(self):
+        """Collective: the replicas of value-partitioned ranks are whole again
+        (before groups are read, validated, exported)."""
+        self.backend.gather_cells(self._comm)
 
     @property
     def native_comm(self):

@@ -454,27 +454,74 @@ int dist_gibbs_replay_ordered_dev(dist_gibbs_t * g,
                                   const uint32_t * const * values_dev,
                                   size_t n_rows, int reset);
 
-/* ---- the library's own RCCL communicator ----------------------------------
+/* ---- the library's own communicator ----------------------------------------
  * Optional: with it the whole multi-GPU sweep (sample -> delta -> all-reduce
  * -> apply -> finish, per sub-sweep) runs inside the library, the all-reduce
- * on the engine's own stream.  RCCL is bound at run time (the librccl.so.1
- * already in the process, e.g. PyTorch's, else ROCm's).  One process per GPU:
- * rank 0 calls dist_comm_unique_id and hands the 128 bytes to the other ranks
- * by whatever channel the application has (torch.distributed broadcast, MPI,
- * a file); every rank then calls dist_comm_create (collective).  Engines with
+ * on the engine's own stream.  Two transports, chosen by the id:
+ *   RCCL (dist_comm_unique_id): bound at run time (the librccl.so.1 already
+ *     in the process, e.g. PyTorch's, else ROCm's); one process per GPU.
+ *   host (dist_comm_unique_id_host): ranks that SHARE a GPU -- RCCL refuses
+ *     two ranks on one device -- meet in a POSIX shared-memory segment and
+ *     the all-reduce is staged through the host (drains the stream: for tests
+ *     and single-GPU rehearsals of the multi-rank protocol).  It checks that
+ *     all ranks issue the same collective and fails the call on every rank
+ *     ("ranks diverged") instead of hanging when they do not, or when a peer
+ *     does not arrive within DIST_COMM_TIMEOUT_S seconds (default 120).
+ * Rank 0 makes the id and hands the 128 bytes to the other ranks by whatever
+ * channel the application has (torch.distributed broadcast, MPI, a file);
+ * every rank then calls dist_comm_create (collective).  Engines with
  * order-dependent statistics (NormalInverseChiSq, GammaPoisson's log_prod) are
- * refused by dist_gibbs_sweep_sharded: they exchange rows (see above). */
+ * refused by dist_gibbs_sweep_sharded: they exchange rows (see above), or
+ * sums with "float_stats" = 1. */
 typedef struct dist_comm dist_comm_t;
 int dist_comm_available(void);                       /* 1 if RCCL can be bound */
 int dist_comm_unique_id(uint8_t id_out[128]);
+int dist_comm_unique_id_host(uint8_t id_out[128]);
 dist_comm_t * dist_comm_create(const uint8_t id[128], int rank, int world);
 void dist_comm_destroy(dist_comm_t * c);
+int dist_comm_size(const dist_comm_t * c, int * rank_out, int * world_out);
+/* in-place all-reduce of device memory on the calling thread's stream, waited
+ * for: type 0 = int32, 1 = binary64; op 0 = sum, 1 = min (what the engines'
+ * own exchanges use; for the application's set-up steps, e.g. the statistics
+ * after every rank loaded its rows) */
+int dist_comm_all_reduce_dev(dist_comm_t * c, void * data_dev, size_t count,
+                             int type, int op);
 /* n_batches sub-sweeps over the local rows in batches of batch_rows (ranks
  * whose shard is exhausted take part with empty batches: pass the same
- * n_batches on every rank) */
+ * n_batches on every rank).  Per sub-sweep ONE all-reduce of
+ *   4 + min(bound, K0 + j * empty_groups) * (3 + dim)   int32 words
+ * (K0: the group count the ranks' run began with, j: its batches so far --
+ * the live part of the group set, not the bound buffers are sized by), or of
+ *   4 + 3 * min(bound, K0 + j * empty_groups)
+ * on value-partitioned ranks (below).  The 4 header words let the ranks tell
+ * that one of them left the common run (dist_last_error: "ranks diverged";
+ * the engine is unusable then) -- between two passes a rank may LOOK at its
+ * engine (counts, assignments, groups, validate, statistics export, timers)
+ * but not change it. */
 int dist_gibbs_sweep_sharded(dist_gibbs_t * g, dist_comm_t * c,
                              size_t n_batches, size_t batch_rows,
                              uint32_t seed_state, uint64_t draw_base);
+/* Value-partitioned ranks (one categorical feature: DirichletDiscrete,
+ * DirichletProcessDiscrete): when the rows are placed so that no value has
+ * rows on two ranks, a rank's rows only ever touch the cells counts[.][x] of
+ * ITS values (dd.hpp:123-149, dpd.hpp:430-469) -- those cells never travel,
+ * and what the ranks exchange per sub-sweep is the group sizes and the
+ * per-group totals, 3 words per group (C2: 12 KB instead of 1.1 MB; C5: 98 KB
+ * instead of 328 MB).  partition_by_value (collective, after load_rows and
+ * the initial statistics exchange) checks the placement -- a value with rows
+ * on two ranks fails the call on every rank -- and switches
+ * dist_gibbs_sweep_sharded to that exchange.  From then on the cells of OTHER
+ * ranks' values are stale here: entry points that read whole groups
+ * (get_group, validate, export_stats, score_data) fail until gather_cells
+ * (collective: one all-reduce of the owned cells) has made the replicas
+ * whole again.  Results are those of the unpartitioned exchange, bit for
+ * bit. */
+int dist_gibbs_partition_by_value(dist_gibbs_t * g, dist_comm_t * c);
+int dist_gibbs_gather_cells(dist_gibbs_t * g, dist_comm_t * c);
+/* the exchanges of dist_gibbs_sweep_sharded since the last reset: out[0] =
+ * all-reduces issued, out[1] = int32 words sent in all of them, out[2] = the
+ * largest, out[3] = the last one (header included; does not close a run) */
+int dist_gibbs_comm_volume(dist_gibbs_t * g, uint64_t out[4], int reset);
 
 /* batch-semantics scores of one resident row (length written to *size_out;
  * scores_out needs dist_gibbs_group_count() floats) */
@@ -615,7 +662,9 @@ int dist_gibbs_sharded_device_normalise_ok(const dist_gibbs_t * g,
  * first pass, ..., last pass | 0 none -- the A/B of
  * profiles/r5_wave_priorities.txt), apply_overlap (k_vs_apply samples a
  * chunk's few handed-over rows while its other waves add up the moves: 1 | 0
- * before they do).
+ * before they do), run_batches_cap (a device-normalised run covers at most
+ * this many batches: 0 as many as fit -- tests/test_gpu_native_ranks.py sees a
+ * run used up and the ranks agree on the next one).
  */
 int dist_gibbs_set_option(dist_gibbs_t * g, const char * name, int value);
 /* how many batches each score+sample kernel has served */

@@ -1,0 +1,287 @@
+"""dist_gibbs_sweep_sharded with REAL peers: 2 and 8 processes share the one
+GPU of the test box and meet in the library's host transport
+(dist_comm_unique_id_host: shared memory, comm.h) -- RCCL refuses two ranks on
+one device, and the pool has one GPU per box.  What is exercised is the
+protocol of DESIGN section 5 itself, inside the library, with peers that can
+disagree: runs that stay open across passes, a rank that looks at its state
+between passes (and takes the run up again) while its peers do not, a run
+that is used up so that the ranks agree on a new one, group churn, the live-part
+exchange, value-partitioned ranks, merged float statistics -- and a rank that
+breaks the rules, which must be TOLD, not waited for.
+
+Expectation throughout (integer sums): N ranks == one process sampling the
+same batch composition == the CPU oracle, bit for bit."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(900)]
+
+K, SEED = 24, 4242
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def place(config, N, world, placement, dim=None, k=K):
+    """-> (osh, gsh, values per feature, assign, bounds per rank): the global
+    data set in the order the ranks hold it.  placement "block": as generated;
+    "value": rows moved (stably) so that rank r holds the rows whose value of
+    feature 0 lies in its range -- no value has rows on two ranks."""
+    import workloads
+    osh, gsh, vals, assign = workloads.make(config, N, k, dim=dim)
+    if placement == "value":
+        width = int(vals[0].max()) + 1
+        owner = (vals[0].astype(np.int64) * world // width).astype(np.int64)
+        order = np.argsort(owner, kind="stable")
+        vals = [v[order] for v in vals]
+        assign = assign[order]
+        ends = np.searchsorted(owner[order], np.arange(world), side="right")
+        bounds = [(int(ends[r - 1]) if r else 0, int(ends[r]))
+                  for r in range(world)]
+    else:
+        bounds = [(r * N // world, (r + 1) * N // world) for r in range(world)]
+    return osh, gsh, vals, assign, bounds
+
+
+def worker(rank, world, port, out, spec):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("DIST_COMM_TIMEOUT_S", "120")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle_lib as ol
+    from distributions_amd import _core, engine
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    N, per = spec["N"], spec["per"]
+    osh, gsh, vals, assign, bounds = place(
+        spec["config"], N, world, spec.get("placement", "block"),
+        spec.get("dim"), spec.get("K", K))
+    lo, hi = bounds[rank]
+    cols = [torch.from_numpy(ol.value_words(s.kind, v[lo:hi]).view(np.int32)
+                             .copy()).to(dev) for s, v in zip(osh, vals)]
+    packed = torch.from_numpy(assign[lo:hi].view(np.int32).copy()).to(dev)
+    gpu = engine.Gibbs(spec.get("alpha", 1.0), 0.2, gsh)
+    gpu.set_option("value_sorted", spec.get("mode", 2))
+    gpu.set_option("device_normalise", 1)
+    gpu.set_option("float_stats", spec.get("float_stats", 0))
+    if spec.get("run_cap"):
+        gpu.set_option("debug.run_batches_cap", spec["run_cap"])
+    gpu.load_rows_torch(cols, packed.clone(), spec.get("K", K), 2,
+                        row_offset=lo)
+    sharded = engine.ShardedGibbs(gpu.core, hi - lo, lo, device=dev,
+                                  columns=cols, assign_packed=packed)
+    sharded.sync_initial_stats()
+    native = sharded.use_native_comm()   # gloo + device tensors -> "host"
+    assert native
+    assert sharded.native_comm.size() == (rank, world)
+    if spec.get("placement") == "value":
+        sharded.partition_by_value()
+    failure = ""
+    groups_seen = []
+    try:
+        for s in range(spec["sweeps"]):
+            sharded.sweep(per, _core.rng_seed(SEED), draw_base=s * N)
+            if rank in spec.get("peekers", ()):
+                # a look at the state between two passes settles this rank's
+                # run; its peers go on with theirs
+                groups_seen.append(len(gpu))
+            if rank == spec.get("offender", -1) and s == 0:
+                # ... but CHANGING the engine is against the rules
+                gpu.set_option("kernel_timing", 1)
+    except RuntimeError as e:
+        failure = str(e)
+    with open(os.path.join(out, "failure_%d.txt" % rank), "w") as f:
+        f.write(failure)
+    if failure:
+        dist.destroy_process_group()
+        return
+    torch.cuda.synchronize()
+    dbg = gpu.core.debug_counts()
+    vol = gpu.core.comm_volume()
+    np.save(os.path.join(out, "meta_%d.npy" % rank), np.array(
+        [dbg["resumed_runs"], dbg["device_normalised"], vol["collectives"],
+         vol["words"], vol["words_max"], len(gpu)], np.int64))
+    if spec.get("placement") == "value":
+        # whole groups cannot be read from a value-partitioned replica ...
+        with pytest.raises(RuntimeError, match="gather_cells"):
+            gpu.get_group(0, 0)
+        sharded.gather_cells()   # ... until the ranks made them whole again
+    np.save(os.path.join(out, "assign_%d.npy" % rank), gpu.assignments())
+    np.save(os.path.join(out, "counts_%d.npy" % rank), gpu.counts())
+    np.save(os.path.join(out, "groups_%d.npy" % rank), np.stack([
+        np.concatenate([gpu.get_group(f, g) for f in range(len(gsh))])
+        for g in range(len(gpu))]))
+    dist.destroy_process_group()
+
+
+def run(tmp_path, world, spec):
+    mp.spawn(worker, args=(world, free_port(), str(tmp_path), spec),
+             nprocs=world, join=True)
+    return [open(tmp_path / ("failure_%d.txt" % r)).read()
+            for r in range(world)]
+
+
+def oracle_run(spec, world):
+    """one process, the same batch composition: batch b = the union over
+    ranks of local rows [b * per, (b + 1) * per) of each shard"""
+    import oracle_lib as ol
+    osh, gsh, vals, assign, bounds = place(
+        spec["config"], spec["N"], world, spec.get("placement", "block"),
+        spec.get("dim"), spec.get("K", K))
+    m = ol.OracleMixture(spec.get("alpha", 1.0), 0.2, osh)
+    m.init_from_assignments(vals, assign, spec.get("K", K), 2)
+    L = ol.oracle()
+    ol._phase_sigs(L)
+    st = L.orc_rng_seed(SEED)
+    per = spec["per"]
+    longest = max(hi - lo for lo, hi in bounds)
+    most = 0
+    for s in range(spec["sweeps"]):
+        for b in range(0, longest, per):
+            snap = m.counts().copy()
+            most = max(most, len(snap))
+            moves = []
+            for lo, hi in bounds:
+                r0, r1 = min(hi, lo + b), min(hi, lo + b + per)
+                old = np.zeros(r1 - r0 + 1, np.uint32)
+                new = np.zeros(r1 - r0 + 1, np.uint32)
+                L.orc_mix_batch_sample(m.h, r0, r1, m._vals, m.assign, st,
+                                       s * spec["N"], 0, old, new)
+                moves.append((r0, r1, old, new))
+            for r0, r1, old, new in moves:
+                L.orc_mix_apply_moves(m.h, r0, r1, m._vals, m.assign, old, new)
+            L.orc_mix_batch_finish(m.h, np.ascontiguousarray(snap, np.int32))
+    return m, osh, most
+
+
+def check_equal(tmp_path, world, spec):
+    m, osh, most = oracle_run(spec, world)
+    got = np.concatenate([np.load(tmp_path / ("assign_%d.npy" % r))
+                          for r in range(world)])
+    counts = [np.load(tmp_path / ("counts_%d.npy" % r)) for r in range(world)]
+    groups = [np.load(tmp_path / ("groups_%d.npy" % r)) for r in range(world)]
+    for r in range(1, world):
+        assert np.array_equal(counts[0], counts[r])   # replicas agree ...
+        assert np.array_equal(groups[0], groups[r])   # ... bit for bit
+    assert np.array_equal(m.counts(), counts[0])
+    assert np.array_equal(got, m.assign)
+    want = np.stack([np.concatenate([m.get_group(f, g)
+                                     for f in range(len(osh))])
+                     for g in range(len(m))])
+    assert np.array_equal(want, groups[0])
+    meta = [np.load(tmp_path / ("meta_%d.npy" % r)) for r in range(world)]
+    return m, most, meta
+
+
+@pytest.mark.parametrize("world,N,per,peekers", [
+    (2, 9001, 750, (1,)), (8, 20003, 500, (2, 5))])
+def test_ranks_with_a_peeker_equal_one_process(tmp_path, world, N, per,
+                                               peekers):
+    """DirichletDiscrete, the device-normalised run: 2 and 8 real peers;
+    some ranks look at their engine after every pass (their run is settled and
+    taken up again), the others never do; shards are ragged (N is prime-ish:
+    the last batches are short or empty)."""
+    spec = dict(config="dd", N=N, per=per, sweeps=4, peekers=peekers)
+    assert run(tmp_path, world, spec) == [""] * world
+    m, most, meta = check_equal(tmp_path, world, spec)
+    for r in range(world):
+        resumed, on_device = meta[r][0], meta[r][1]
+        assert on_device > 0
+        # resumed_runs differs between the ranks: nobody told anybody
+        assert resumed == (spec["sweeps"] - 1 if r in peekers else 0)
+    # the exchange is the live part of the group set: 4 header words +
+    # (3 + dim) words per group that can exist at that batch -- never the
+    # run's bound (thousands of groups)
+    dim = 16
+    batches = spec["sweeps"] * -(-max(-(-N // world), 1) // per)
+    assert meta[0][2] >= batches
+    assert meta[0][4] <= 4 + (K + 2 + 2 * batches) * (3 + dim)
+    assert meta[0][4] < 4 + 4 * most * (3 + dim)
+
+
+def test_a_run_that_is_used_up_and_group_churn(tmp_path):
+    """Short runs (debug.run_batches_cap: two passes each) under a prior that
+    founds and empties groups all the time: the ranks' runs end at the same
+    call on every rank -- peekers included -- and they agree on the next."""
+    world = 2
+    spec = dict(config="dd", N=6000, per=250, sweeps=7, peekers=(0,),
+                run_cap=24, alpha=30.0, K=6)
+    assert run(tmp_path, world, spec) == [""] * world
+    m, most, meta = check_equal(tmp_path, world, spec)
+    assert most > spec["K"] + 2          # groups were founded
+    for r in range(world):
+        assert meta[r][1] > 0
+    # rank 0 took its run up again only where the run went on (every other
+    # pass: the passes in between opened a new one, agreed by all ranks)
+    assert 0 < meta[0][0] < spec["sweeps"] - 1
+    assert meta[1][0] == 0
+
+
+def test_merged_float_statistics_with_real_peers(tmp_path):
+    """BASELINE configs[2]'s feature list with float_stats = 1 on 2 ranks: the
+    native loop exchanges the integer image and the binary64 sums; replicas
+    stay bit-identical"""
+    world = 2
+    spec = dict(config="gp_nich", N=6000, per=750, sweeps=2, mode=1,
+                float_stats=1)
+    assert run(tmp_path, world, spec) == [""] * world
+    counts = [np.load(tmp_path / ("counts_%d.npy" % r)) for r in range(world)]
+    groups = [np.load(tmp_path / ("groups_%d.npy" % r)) for r in range(world)]
+    assert np.array_equal(counts[0], counts[1])
+    assert np.array_equal(groups[0], groups[1])
+    assign = np.concatenate([np.load(tmp_path / ("assign_%d.npy" % r))
+                             for r in range(world)])
+    assert assign.size == spec["N"] and counts[0].sum() == spec["N"]
+    live = np.flatnonzero(counts[0])
+    assert np.array_equal(np.sort(np.bincount(assign)[np.bincount(assign) > 0]),
+                          np.sort(counts[0][live]))
+
+
+@pytest.mark.parametrize("config,dim,world,N,per,k", [
+    ("dd", 256, 2, 12000, 1000, 24),      # C2's feature
+    ("dd", 256, 8, 24000, 600, 24),       # ... on 8 ranks: config 4's shape
+    ("dpd", 1000, 2, 12000, 1000, 300)])  # C5's feature: wide table, many groups
+def test_value_partitioned_ranks(tmp_path, config, dim, world, N, per, k):
+    """Rows placed by value: the cells never travel -- 3 words per group and
+    sub-sweep instead of 3 + dim -- and the result is the oracle's, bit for
+    bit, once gather_cells made the replicas whole ("C5 ... use
+    sparse delta lists / reduce-scatter by value range")."""
+    spec = dict(config=config, dim=dim, N=N, per=per, sweeps=3, K=k,
+                placement="value", peekers=(world - 1,))
+    assert run(tmp_path, world, spec) == [""] * world
+    m, most, meta = check_equal(tmp_path, world, spec)
+    bounds = place(config, N, world, "value", dim, k)[4]
+    batches = spec["sweeps"] * -(-max(hi - lo for lo, hi in bounds) // per)
+    for r in range(world):
+        assert meta[r][2] >= batches
+        # in-run words <= 3 * (bound on the live group count) + header
+        assert meta[r][4] <= 4 + 3 * (k + 2 + 2 * batches)
+        assert meta[r][4] <= 4 + 3 * (most + 2 * batches)
+
+
+def test_a_rank_that_changes_its_engine_is_told(tmp_path):
+    """Between two passes rank 1 sets an option (a state-changing entry point:
+    it forgets the run it could have taken up).  Its next pass asks for a new
+    run while rank 0 goes on with the old one: collectives that do not match.
+    Every rank gets an error that says so -- nobody hangs."""
+    world = 2
+    spec = dict(config="dd", N=6000, per=750, sweeps=3, offender=1)
+    failures = run(tmp_path, world, spec)
+    assert all("ranks diverged" in f for f in failures), failures
