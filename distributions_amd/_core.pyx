@@ -210,6 +210,8 @@ cdef extern from "distributions_hip.h" nogil:
     int dist_gibbs_sweep(dist_gibbs_t *, size_t, size_t, size_t, uint32_t,
                          uint64_t)
     int dist_gibbs_sweep_sequential(dist_gibbs_t *, size_t, size_t, uint32_t *)
+    int dist_gibbs_sweep_sequential_many(dist_gibbs_t * const *, size_t,
+                                         size_t, size_t, uint32_t *) nogil
     int dist_gibbs_batch_sample(dist_gibbs_t *, size_t, size_t, uint32_t,
                                 uint64_t)
     int dist_gibbs_batch_delta_dev(dist_gibbs_t *, int32_t *)
@@ -1347,8 +1349,8 @@ cdef class GibbsEngine:
 
     def debug_counts(self):
         """dict of the engine's path diagnostics (dist_gibbs_debug_counts)"""
-        cdef uint64_t out[15]
-        check(dist_gibbs_debug_counts(self.ptr, out, 15))
+        cdef uint64_t out[16]
+        check(dist_gibbs_debug_counts(self.ptr, out, 16))
         return {"value_sorted_batches": out[0], "other_batches": out[1],
                 "band_launches": out[2], "running_sum_launches": out[3],
                 "band_values_last": out[4], "handed_over_last": out[5],
@@ -1356,7 +1358,11 @@ cdef class GibbsEngine:
                 "narrow_batches": out[8], "scratch_batches": out[9],
                 "fold_batches": out[10], "scan_batches": out[11],
                 "merged_batches": out[12], "fused_batches": out[13],
-                "resumed_runs": out[14]}
+                "resumed_runs": out[14], "chain_launches": out[15]}
+
+    def chain_launches(self):
+        """launches of the exact-chain kernel this engine issued"""
+        return self.debug_counts()["chain_launches"]
 
     def set_option(self, name, int value):
         check(dist_gibbs_set_option(self.ptr, name.encode(), value))
@@ -1409,3 +1415,32 @@ cdef class GibbsEngine:
         check(dist_gibbs_kernel_stats(self.ptr, &ms, &launches, &rows,
                                       1 if reset else 0))
         return ms, launches, rows
+
+
+def sweep_sequential_many(engines, size_t row_begin, size_t row_end,
+                          rng_states):
+    """M independent exact chains in one launch (dist_gibbs_sweep_sequential_
+    many): engines = GibbsEngine objects, rng_states = their engine states.
+    -> the new states (numpy uint32)."""
+    cdef size_t m = len(engines)
+    cdef cnp.ndarray[cnp.uint32_t, ndim=1] st = np.ascontiguousarray(
+        rng_states, dtype=np.uint32).copy()
+    if <size_t> st.shape[0] != m:
+        raise ValueError("one rng state per engine")
+    cdef dist_gibbs_t ** ptrs = <dist_gibbs_t **> malloc(
+        (m if m else 1) * sizeof(dist_gibbs_t *))
+    cdef size_t i
+    cdef int rc
+    cdef GibbsEngine e
+    try:
+        for i in range(m):
+            e = engines[i]
+            ptrs[i] = e.ptr
+        with nogil:
+            rc = dist_gibbs_sweep_sequential_many(
+                <dist_gibbs_t * const *> ptrs, m, row_begin, row_end,
+                <uint32_t *> st.data)
+    finally:
+        free(ptrs)
+    check(rc)
+    return st

@@ -1165,7 +1165,9 @@ struct Gibbs {
         return *fold_cache.back();
     }
     uint64_t scratch_batches = 0;
-    int sequential_mode = 1;   // 0: every row as a batch of one (diagnostic)
+    // 2: k_chains (structural steps on the device); 1: round 3's kernel, back
+    // to the host at every structural step; 0: every row as a batch of one
+    int sequential_mode = 2;
     DeviceBuf<int> vsArg;
     DeviceBuf<uint32_t> deferred, deferred_count;
     int value_sorted_mode = 1;   // 0 off, 1 auto, 2 always (when eligible)
@@ -4202,6 +4204,106 @@ struct Gibbs {
         batch_finish();
         *rng_state = lcg_mulmod(*rng_state, 16807u);
     }
+    // ---- the exact chain, device-resident with its structural steps -----
+    // (k_chains: one workgroup per chain; dist_gibbs_sweep_sequential_many
+    // launches M engines' chains together)
+    static constexpr int kChainRoom = 256;   // groups a launch may found
+    static constexpr uint32_t kChainIds = 4096;   // ... and ids it may issue
+    bool chain_fits() const {
+        return sequential_mode == 2 && (size_t)K() + kChainRoom <= 8192;
+    }
+    size_t chain_lds_bytes() const {
+        return (size_t)((K() + kChainRoom + 63) & ~63) * 8;
+    }
+    // everything the launch may grow into is reserved, the state the kernel
+    // reads is put on the device
+    ChainArgs chain_prepare(size_t r0, size_t r1, uint32_t rng) {
+        DIST_REQUIRE(!batch_open, "previous batch not finished");
+        DIST_REQUIRE(r0 <= r1 && r1 <= n_rows, "bad row range");
+        DIST_REQUIRE(r1 <= assigned_rows || r0 == r1,
+                     "rows without a group yet: init_sequential first");
+        drop_overlapping_caches(r0, r1, false);
+        flush_assign_pos();
+        const int room = K() + kChainRoom;
+        py.reserve(room);
+        for (auto & s : feats) s->reserve(room);
+        if ((size_t)room > base.cap || (size_t)room > base_single.cap) {
+            base.reserve(grow_capacity((size_t)room), 0);
+            base_single.reserve(grow_capacity((size_t)room), 0);
+            base_valid = false;   // (the new buffers are empty)
+        }
+        upload_maps((size_t)room, tracker.g2p.size() + kChainIds);
+        SweepParams P = params(r0, r1, 0, 0);
+        prepare(P, false);
+        DevState st;
+        memset(&st, 0, sizeof(st));
+        st.K = K();
+        st.k_new = K();
+        st.global_size = (uint32_t)tracker.g2p.size();
+        st.first_new_global = st.global_size;
+        st.nonempty = K() - py.n_empty;
+        dev_state.upload(&st, 1);
+        chain_result.reserve(1, 0);
+        ChainArgs A;
+        memset(&A, 0, sizeof(A));
+        A.P = P;
+        A.base = base.p;
+        A.counts = py.d_counts.p;
+        A.assign = assign;
+        A.p2g = d_maps.p;
+        A.g2p = reinterpret_cast<int32_t *>(d_maps.p + maps_pcap);
+        A.dev = dev_state.p;
+        A.result = chain_result.p;
+        A.rng_state = rng;
+        A.k_room = room;
+        A.g_room = (uint32_t)std::min<size_t>(d_maps.cap - maps_pcap,
+                                              0x7FFFFFFFu);
+        return A;
+    }
+    // the host's mirrors after a launch: group sizes, group count, id maps
+    ChainResult chain_collect() {
+        ChainResult res;
+        chain_result.download(&res, 1);
+        DevState st;
+        dev_state.download(&st, 1);
+        const size_t Kn = (size_t)st.K;
+        const bool structural = Kn != (size_t)K()
+                                || st.global_size != tracker.g2p.size();
+        py.counts.resize(Kn);
+        py.d_counts.download(py.counts.data(), Kn);
+        for (auto & s : feats) s->K = (int)Kn;
+        if (structural) {
+            std::vector<uint32_t> maps(maps_pcap + st.global_size);
+            d_maps.download(maps.data(), maps.size());
+            tracker.p2g.assign(maps.begin(), maps.begin() + (long)Kn);
+            tracker.g2p.resize(st.global_size);
+            for (size_t i = 0; i < st.global_size; ++i)
+                tracker.g2p[i] = (int32_t)maps[maps_pcap + i];
+            tracker.repacked += 1;   // (recorded offsets: not to be trusted)
+            maps_dirty = false;      // the device's copy IS the state
+        }
+        py.rebuild(alpha, d);        // sample size, empty groups, shifted[]
+        base_valid = false;
+        cells_fresh = false;
+        return res;
+    }
+    struct ChainsLaunch {
+        const ChainArgs * args;
+        unsigned chains;
+        size_t lds;
+        template <int A, int B, int NF>
+        void run() {
+            (void)hipFuncSetAttribute(
+                reinterpret_cast<const void *>(&k_chains<A, B, NF>),
+                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipGetLastError();
+            hipLaunchKernelGGL((k_chains<A, B, NF>), dim3(chains), dim3(kBlock),
+                               lds, stream(), args);
+            HIP_CHECK(hipGetLastError());
+        }
+    };
+    DeviceBuf<ChainArgs> chain_args;
+    uint64_t chain_launches = 0;
     void sweep_sequential(size_t r0, size_t r1, uint32_t * rng_state) {
         DIST_REQUIRE(!batch_open, "previous batch not finished");
         resume_bound = resume_left = 0;
@@ -4210,13 +4312,27 @@ struct Gibbs {
                      "rows without a group yet: init_sequential first");
         size_t r = r0;
         while (r < r1) {
+            if (chain_fits()) {
+                // the whole range on the device, structural steps included
+                const ChainArgs A = chain_prepare(r, r1, *rng_state);
+                chain_args.upload(&A, 1);
+                ChainsLaunch L{chain_args.p, 1u, chain_lds_bytes()};
+                dispatch(L);
+                chain_launches += 1;
+                const ChainResult res = chain_collect();
+                DIST_REQUIRE(res.rows_done > 0 || res.event != 3,
+                             "internal: the chain kernel found no room");
+                *rng_state = res.rng_state;
+                r += res.rows_done;
+                continue;
+            }
             if ((size_t)((K() + 63) & ~63) * sizeof(float) > 60 * 1024
                 || sequential_mode == 0) {   // scores do not fit one LDS strip
                 sequential_row_as_batch(r, rng_state);
                 r += 1;
                 continue;
             }
-            // the device-resident chain, up to its first structural step
+            // round 3's chain kernel: up to its first structural step
             drop_overlapping_caches(r, r1, false);
             flush_assign_pos();
             upload_maps();
@@ -5501,6 +5617,73 @@ int dist_gibbs_sweep_sequential(dist_gibbs_t * g, size_t row_begin,
     return guarded(
         [&] { g->impl->sweep_sequential(row_begin, row_end, rng_state); });
 }
+int dist_gibbs_sweep_sequential_many(dist_gibbs_t * const * engines, size_t m,
+                                     size_t row_begin, size_t row_end,
+                                     uint32_t * rng_states) {
+    return guarded([&] {
+        DIST_REQUIRE(m == 0 || (engines && rng_states), "null argument");
+        if (!m) return;
+        std::vector<Gibbs *> e(m);
+        for (size_t i = 0; i < m; ++i) {
+            DIST_REQUIRE(engines[i], "null engine");
+            e[i] = &*engines[i]->impl;   // (settles, forgets a sharded run)
+            for (size_t j = 0; j < i; ++j)
+                DIST_REQUIRE(e[j] != e[i], "the same engine twice");
+            DIST_REQUIRE(e[i]->F() == e[0]->F(), "engines of one feature list");
+            for (int f = 0; f < e[0]->F(); ++f)
+                DIST_REQUIRE(e[i]->feats[f]->sh.kind == e[0]->feats[f]->sh.kind,
+                             "engines of one feature list");
+        }
+        // chains whose group count is beyond the kernel's strips (or with the
+        // kernel switched off) take their own path, one after the other
+        std::vector<size_t> at(m, row_begin);
+        std::vector<size_t> todo;
+        for (size_t i = 0; i < m; ++i) {
+            if (e[i]->chain_fits()) {
+                todo.push_back(i);
+            } else {
+                e[i]->sweep_sequential(row_begin, row_end, &rng_states[i]);
+                at[i] = row_end;
+            }
+        }
+        std::vector<ChainArgs> args;
+        while (!todo.empty()) {
+            args.clear();
+            size_t lds = 0;
+            for (size_t i : todo) {
+                args.push_back(e[i]->chain_prepare(at[i], row_end,
+                                                   rng_states[i]));
+                lds = std::max(lds, e[i]->chain_lds_bytes());
+            }
+            Gibbs & first = *e[todo[0]];
+            first.chain_args.upload(args.data(), args.size());
+            Gibbs::ChainsLaunch L{first.chain_args.p, (unsigned)todo.size(),
+                                  lds};
+            first.dispatch(L);
+            first.chain_launches += 1;
+            std::vector<size_t> again;
+            for (size_t i : todo) {
+                const ChainResult res = e[i]->chain_collect();
+                DIST_REQUIRE(res.rows_done > 0 || res.event != 3
+                                 || at[i] >= row_end,
+                             "internal: the chain kernel found no room");
+                rng_states[i] = res.rng_state;
+                at[i] += res.rows_done;
+                // (out of room, or a group count beyond the strips now)
+                if (at[i] < row_end) {
+                    if (e[i]->chain_fits()) {
+                        again.push_back(i);
+                    } else {
+                        e[i]->sweep_sequential(at[i], row_end, &rng_states[i]);
+                        at[i] = row_end;
+                    }
+                }
+            }
+            todo.swap(again);
+        }
+        dist::sync();
+    });
+}
 int dist_gibbs_batch_sample(dist_gibbs_t * g, size_t row_begin, size_t row_end,
                             uint32_t seed_state, uint64_t draw_base) {
     return guarded([&] {
@@ -5812,9 +5995,10 @@ int dist_gibbs_set_option(dist_gibbs_t * g, const char * name, int value) {
             DIST_REQUIRE(value == 0 || value == 1, "fused_tables: 0 or 1");
             g->impl->fused_tables_mode = value;
         } else if (key == "sequential_chain") {
-            // 1 (default): the device-resident chain kernel; 0: every row
-            // as a batch of one
-            DIST_REQUIRE(value == 0 || value == 1, "sequential_chain: 0 or 1");
+            // 2 (default): k_chains, structural steps on the device; 1:
+            // round 3's kernel (back to the host at every structural step);
+            // 0: every row as a batch of one
+            DIST_REQUIRE(value >= 0 && value <= 2, "sequential_chain: 0, 1 or 2");
             g->impl->sequential_mode = value;
         } else {
             throw Error("unknown option: " + key);
@@ -5831,11 +6015,12 @@ int dist_gibbs_path_counts(const dist_gibbs_t * g, uint64_t * value_sorted,
 int dist_gibbs_debug_counts(dist_gibbs_t * g, uint64_t * out, size_t n) {
     return guarded([&] {
         Gibbs & e = *g->impl.read();
-        uint64_t v[15] = {e.vs_batches, e.generic_batches, e.band_batches,
+        uint64_t v[16] = {e.vs_batches, e.generic_batches, e.band_batches,
                           e.prefix_batches, 0, 0, e.stream_batches,
                           e.async_batches, e.narrow_batches,
                           e.scratch_batches, e.fold_batches, e.scan_batches,
-                          e.merged_batches, e.fused_batches, e.resumed_runs};
+                          e.merged_batches, e.fused_batches, e.resumed_runs,
+                          e.chain_launches};
         if (e.last_bands && !e.batch_open && e.vsBandMode.p) {
             // values whose arg-max group's rows had a tile of their own in
             // the last value-sorted launch
@@ -5848,7 +6033,7 @@ int dist_gibbs_debug_counts(dist_gibbs_t * g, uint64_t * out, size_t n) {
             e.deferred_count.download(&d, 1);
             v[5] = d;
         }
-        for (size_t i = 0; i < n && i < 15; ++i) out[i] = v[i];
+        for (size_t i = 0; i < n && i < 16; ++i) out[i] = v[i];
     });
 }
 int dist_gibbs_phase_stats(dist_gibbs_t * g, double ms_out[5],

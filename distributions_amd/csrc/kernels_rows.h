@@ -1545,6 +1545,309 @@ __global__ __launch_bounds__(kBlock) void k_chain_rows(
     }
 }
 
+// ---------------------------------------------------------------------------
+// M exact chains in one launch (BASELINE configs[3] read literally: "8
+// independent chains"; examples/mixture/main.py:236-244 per chain).  Workgroup
+// m runs the reference's sequential chain of engine m -- its own rows,
+// statistics, caches, id maps and entropy -- from the arguments in all[m].
+// Unlike k_chain_rows the kernel takes the STRUCTURAL steps itself, so a chain
+// never goes back to the host inside its range:
+//   a row that is alone in its group: the group vanishes as
+//     MixtureDriver::remove_value does it (mixture.hpp:108-119: the last
+//     group moves into its slot), MixtureSlave::remove_group for every feature
+//     (mixture.hpp:370-375), MixtureIdTracker::remove_group (:489-499), and
+//     the empty groups' prior follows the count of non-empty ones
+//     (clustering.hpp:221-230);
+//   a row that fills an empty group: a fresh empty group is appended
+//     (mixture.hpp:84-89, 361-368, 481-487; clustering.hpp:163-176).
+// Per row the critical path is the two order-sensitive recurrences (total in
+// index order, subtractive scan: 2 K dependent adds in the worst case, on one
+// wave); everything around them is kept off it: the group sizes live in LDS,
+// the next row's words are fetched under this row's recurrences, and this
+// row's add_value runs beside the next row's remove_value on two waves (they
+// touch different groups; the same group: one thread, in order).
+struct ChainArgs {
+    SweepParams P;         // the engine's views; rows [row_begin, row_end)
+    float * base;          // the driver's score with one row out, per slot
+    int32_t * counts;
+    uint32_t * assign;
+    uint32_t * p2g;
+    int32_t * g2p;
+    DevState * dev;        // in/out: K, nonempty, global_size
+    ChainResult * result;
+    uint32_t rng_state;
+    int k_room;            // slots the arrays and the LDS strips hold
+    uint32_t g_room;       // global ids the map holds
+};
+
+template <class T>
+__device__ __forceinline__ T chain_peek(const T * p) {
+    // (written by this workgroup's own vector stores: never a scalar load)
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+template <int KIND0, int KIND1, int NF>
+__global__ __launch_bounds__(kBlock) void k_chains(
+        const ChainArgs * __restrict__ all) {
+    const ChainArgs & A = all[blockIdx.x];
+    const SweepParams & P = A.P;
+    extern __shared__ float chain_lds[];   // [room] scores, [room] group sizes
+    __shared__ uint32_t s_exp[1024];
+    __shared__ uint32_t s_log[16384];      // FastLog's table
+    __shared__ float s_red[kBlock / 64];
+    __shared__ int s_g2;
+    for (int i = threadIdx.x; i < 1024; i += kBlock)
+        s_exp[i] = g_tables_dev.exp_table[i];
+    for (int i = threadIdx.x; i < 16384; i += kBlock)
+        s_log[i] = g_tables_dev.log_table[i];
+    const float ea = u2f(g_tables_dev.exp_ab[0]);
+    const float eb = u2f(g_tables_dev.exp_ab[1]);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int room = (A.k_room + 63) & ~63;
+    float * sc = chain_lds;
+    int * size_l = reinterpret_cast<int *>(chain_lds + room);
+    int K = A.dev->K, nonempty = A.dev->nonempty;
+    uint32_t gsz = A.dev->global_size;
+    const int nf = NF > 0 ? NF : P.F;
+    const float shift = P.scalars->shift;
+    float * base = A.base;
+    uint32_t rng_state = A.rng_state;
+    for (int k = tid; k < K; k += kBlock) size_l[k] = A.counts[k];
+    __syncthreads();
+
+    int kind[kMaxF];
+#pragma unroll
+    for (int f = 0; f < (NF > 0 ? NF : kMaxF); ++f) {
+        if (f >= nf) break;
+        kind[f] = f == 0 && KIND0 >= 0 ? KIND0
+                : f == 1 && KIND1 >= 0 ? KIND1 : P.feat[f].kind;
+    }
+    // the driver's score of a group that keeps n >= 1 members
+    auto own_score = [&](int n) {
+        return P.cluster == 0 ? fast_log_t((float)n - P.d, s_log) + shift
+                              : cluster_own_score(P, n, shift);
+    };
+    // clustering.hpp:221-230 with the row out: every empty group's score
+    auto rescore_empties = [&]() {
+        if (P.cluster != 0) return;
+        const float es =
+            py_empty_score(P.alpha, P.d, nonempty, P.n_empty) + shift;
+        for (int k = tid; k < K; k += kBlock)
+            if (size_l[k] == 0) base[k] = es;
+    };
+    // remove_value for a group that stays (one thread)
+    auto remove_from = [&](int g, const uint32_t * x) {
+        const int n = size_l[g] - 1;
+        size_l[g] = n;
+        base[g] = own_score(n);
+        for (int f = 0; f < nf; ++f) {
+            SlaveView v = P.feat[f];
+            v.kind = kind[f];
+            chain_value_op(v, g, x[f], false, s_log);
+        }
+    };
+    auto add_to = [&](int g2, const uint32_t * x, size_t row) {
+        const int n = size_l[g2] + 1;
+        size_l[g2] = n;
+        base[g2] = own_score(n);
+        for (int f = 0; f < nf; ++f) {
+            SlaveView v = P.feat[f];
+            v.kind = kind[f];
+            chain_value_op(v, g2, x[f], true, s_log);
+        }
+        A.assign[row] = chain_peek(A.p2g + g2);
+    };
+    // remove_value of the next row, by all threads (between two barriers):
+    // the group stays, or vanishes with its last member
+    auto remove_row = [&](int g, const uint32_t * x) {
+        const int members = size_l[g];
+        __syncthreads();   // (everybody has read it before anybody writes)
+        if (members != 1) {
+            if (tid == 0) remove_from(g, x);
+            return;
+        }
+        const int last = K - 1;
+        if (tid == 0) {
+            const uint32_t gid = chain_peek(A.p2g + g);
+            A.g2p[gid] = -1;
+            if (g != last) {
+                const uint32_t moved = chain_peek(A.p2g + last);
+                A.p2g[g] = moved;
+                A.g2p[moved] = g;
+                size_l[g] = size_l[last];
+                base[g] = base[last];
+            }
+        }
+        if (g != last)
+            for (int f = 0; f < nf; ++f) {
+                const SlaveView & v = P.feat[f];
+                if (tid == 0) {
+                    v.i0[g] = v.i0[last]; v.i1[g] = v.i1[last];
+                    v.f0[g] = v.f0[last]; v.f1[g] = v.f1[last];
+                    v.c0[g] = v.c0[last]; v.c1[g] = v.c1[last];
+                    v.c2[g] = v.c2[last]; v.c3[g] = v.c3[last];
+                }
+                if (is_cat(kind[f]))
+                    for (int vv = tid; vv < v.dim; vv += kBlock) {
+                        v.cnt[(size_t)g * v.dim + vv] =
+                            v.cnt[(size_t)last * v.dim + vv];
+                        v.S[(size_t)vv * v.cap + g] =
+                            v.S[(size_t)vv * v.cap + last];
+                    }
+            }
+        K = last;
+        nonempty -= 1;
+        __threadfence_block();
+        __syncthreads();
+        rescore_empties();
+    };
+    // a fresh empty group behind the others, by all threads
+    auto append_group = [&]() {
+        const int kn = K;
+        for (int f = 0; f < nf; ++f) {
+            SlaveView v = P.feat[f];
+            v.kind = kind[f];
+            if (is_cat(kind[f])) {
+                for (int vv = tid; vv < v.dim; vv += kBlock) {
+                    v.cnt[(size_t)kn * v.dim + vv] = 0;
+                    v.S[(size_t)vv * v.cap + kn] =
+                        fast_log_t(v.prior[vv] + 0.f, s_log);
+                }
+                if (tid == 0) {
+                    v.i0[kn] = 0; v.i1[kn] = 0; v.f0[kn] = 0.f; v.f1[kn] = 0.f;
+                    v.c0[kn] = fast_log_t(v.alpha_sum + 0.f, s_log);
+                }
+            } else if (tid == 0) {
+                const Stats zero = {0, 0, 0.f, 0.f};
+                store_stats(v, kn, zero);
+                refresh_scalar_entry(v, kn);
+            }
+        }
+        if (tid == 0) {
+            size_l[kn] = 0;
+            A.p2g[kn] = gsz;
+            A.g2p[gsz] = kn;
+            if (P.cluster != 0)
+                base[kn] = le_score_add_value(P.dataset_size, 0,
+                                              (int)P.sample_size - 1,
+                                              P.n_empty);
+        }
+        K += 1;
+        nonempty += 1;
+        gsz += 1;
+        __threadfence_block();
+        __syncthreads();
+        rescore_empties();
+    };
+
+    uint32_t done = 0;
+    int event = 0;
+    size_t row = P.row_begin;
+    uint32_t x[kMaxF], xn[kMaxF];
+    if (row < P.row_end) {
+        if (K + 1 > A.k_room || gsz + 1 > A.g_room) {
+            event = 3;
+        } else {
+            for (int f = 0; f < nf; ++f) x[f] = P.values[f][row];
+            remove_row(chain_peek(A.g2p + A.assign[row]), x);
+        }
+    }
+    while (event == 0 && row < P.row_end) {
+        // the next row's words, under this row's work
+        const bool has_next = row + 1 < P.row_end;
+        uint32_t a_next = 0;
+        if (has_next) {
+            a_next = A.assign[row + 1];
+            for (int f = 0; f < nf; ++f) xn[f] = P.values[f][row + 1];
+        }
+        float lf[kMaxF];
+        for (int f = 0; f < nf; ++f)
+            lf[f] = kind[f] == DIST_GP ? fast_log_factorial(x[f]) : 0.f;
+        __threadfence_block();
+        __syncthreads();
+        // (no step of this row moves a group: the map is stable until then)
+        const int gn = has_next ? chain_peek(A.g2p + a_next) : -1;
+        // score_value: driver, then every feature accumulates
+        float m = -INFINITY;
+        for (int k = tid; k < K; k += kBlock) {
+            float s = base[k];
+#pragma unroll
+            for (int f = 0; f < (NF > 0 ? NF : kMaxF); ++f) {
+                if (f >= nf) break;
+                SlaveView v = P.feat[f];
+                v.kind = kind[f];
+                s = accumulate(kind[f], s, load_entry(v, k, x[f]), x[f],
+                               lf[f], v.p);
+            }
+            sc[k] = s;
+            m = s > m ? s : m;
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            const float o = __shfl_xor(m, off);
+            m = o > m ? o : m;
+        }
+        if (lane == 0) s_red[wave] = m;
+        __syncthreads();
+        m = s_red[0];
+#pragma unroll
+        for (int w = 1; w < kBlock / 64; ++w) m = s_red[w] > m ? s_red[w] : m;
+        // scores_to_likelihoods (random.cc:94-106): exponentials in parallel
+        for (int k = tid; k < ((K + 63) & ~63); k += kBlock)
+            sc[k] = k < K ? fast_exp_nonpos(sc[k] - m, s_exp, ea, eb) : 0.f;
+        __syncthreads();
+        if (wave == 0) {
+            const float total = strip_total(sc, K);
+            rng_state = lcg_mulmod(rng_state, 16807u);
+            const int g2 = strip_sample(sc, K, total * lcg_unif01(rng_state));
+            if (lane == 0) s_g2 = g2;
+        }
+        __syncthreads();
+        const int g2 = s_g2;
+        const int n2 = size_l[g2];
+        const bool room_ok = K + 1 <= A.k_room && gsz + 1 <= A.g_room;
+        const bool fast = n2 > 0 && has_next && room_ok
+                          && (gn == g2 || size_l[gn] > 1);
+        __syncthreads();   // (size_l is read above, written below)
+        if (fast) {
+            // add_value beside the next row's remove_value: different
+            // groups on two waves, the same group in order on one thread
+            if (tid == 0) {
+                add_to(g2, x, row);
+                if (gn == g2) remove_from(gn, xn);
+            } else if (tid == 64 && gn != g2) {
+                remove_from(gn, xn);
+            }
+        } else {
+            if (tid == 0) add_to(g2, x, row);
+            __threadfence_block();
+            __syncthreads();
+            if (n2 == 0) append_group();
+            if (has_next) {
+                if (K + 1 > A.k_room || gsz + 1 > A.g_room) {
+                    event = 3;   // (the next row is untouched)
+                } else {
+                    __syncthreads();
+                    remove_row(gn, xn);
+                }
+            }
+        }
+        done += 1;
+        row += 1;
+        for (int f = 0; f < nf; ++f) x[f] = xn[f];
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (int k = tid; k < K; k += kBlock) A.counts[k] = size_l[k];
+    if (tid == 0) {
+        A.dev->K = K;
+        A.dev->nonempty = nonempty;
+        A.dev->global_size = gsz;
+        A.result->rng_state = rng_state;
+        A.result->rows_done = done;
+        A.result->event = event;
+    }
+}
+
 // batch-semantics scores of one row, for tolerance tests of the scores
 template <int KIND0, int KIND1, int NF>
 __global__ void k_row_scores(SweepParams P, size_t row, float * out,

@@ -399,10 +399,22 @@ int dist_gibbs_import_stats_dev(dist_gibbs_t * g, const int32_t * stats_dev);
 int dist_gibbs_sweep(dist_gibbs_t * g, size_t row_begin, size_t row_end,
                      size_t batch_rows, uint32_t seed_state,
                      uint64_t draw_base);
-/* the reference's sequential chain (batch of one row), advancing *rng_state
- * one step per row */
+/* the reference's sequential chain (examples/mixture/main.py:236-244 over
+ * mixture.hpp:73-122, 361-398: remove the row, score, sample, add -- a batch
+ * of one row), advancing *rng_state one step per row.  Device-resident: one
+ * workgroup walks the range, group creation and removal included. */
 int dist_gibbs_sweep_sequential(dist_gibbs_t * g, size_t row_begin,
                                 size_t row_end, uint32_t * rng_state);
+/* M independent exact chains in ONE launch (BASELINE configs[3]: "8
+ * independent chains"): engine i -- its own rows, statistics, id maps --
+ * runs dist_gibbs_sweep_sequential over ITS rows [row_begin, row_end) with
+ * rng_states[i], one workgroup per chain, side by side on the GPU; each
+ * chain's result is exactly that of its own sequential call.  The engines
+ * share one feature list (same kinds, any hyper-parameters) and are distinct;
+ * up to two chains fit a compute unit (512 on an MI355X run concurrently). */
+int dist_gibbs_sweep_sequential_many(dist_gibbs_t * const * engines, size_t m,
+                                     size_t row_begin, size_t row_end,
+                                     uint32_t * rng_states);
 /* the same pass in phases, for callers that exchange statistics between
  * GPUs: sample -> delta -> [all-reduce delta] -> apply_delta ->
  * (ordered statistics: moves -> [all-gather] -> replay_ordered) -> finish.
@@ -670,7 +682,7 @@ int dist_gibbs_set_option(dist_gibbs_t * g, const char * name, int value);
 /* how many batches each score+sample kernel has served */
 int dist_gibbs_path_counts(const dist_gibbs_t * g, uint64_t * value_sorted,
                            uint64_t * generic);
-/* diagnostics for the tests: out[0..14] = batches through the value-sorted
+/* diagnostics for the tests: out[0..15] = batches through the value-sorted
  * kernel, through the other kernels, launches with band tiles on, launches
  * with running sums on, values whose arg-max rows had their own tile in the
  * last value-sorted launch, rows that launch handed to the wave-per-row
@@ -680,7 +692,8 @@ int dist_gibbs_path_counts(const dist_gibbs_t * g, uint64_t * value_sorted,
  * folded leading features, batches sampled in scan mode, batches with merged
  * float statistics, batches whose group set, caches and tables came from the
  * one fused launch, sharded runs this rank closed between two passes and took
- * up again (first min(n, 15) entries are written) */
+ * up again, launches of the exact-chain kernel k_chains this engine issued
+ * (first min(n, 16) entries are written) */
 int dist_gibbs_debug_counts(dist_gibbs_t * g, uint64_t * out, size_t n);
 /* "phase_timing" = 1 (a diagnostic: six events per sub-sweep): HIP-event time
  * (ms, summed) of the five phases of the device-normalised value-sorted

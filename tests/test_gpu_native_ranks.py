@@ -97,7 +97,10 @@ def worker(rank, world, port, out, spec):
     groups_seen = []
     try:
         for s in range(spec["sweeps"]):
-            sharded.sweep(per, _core.rng_seed(SEED), draw_base=s * N)
+            # (a rank that tiles its shard differently: same collectives,
+            # same sizes, another run -- only the exchange's header can tell)
+            mine = per + 1 if rank == spec.get("odd_tiling", -1) else per
+            sharded.sweep(mine, _core.rng_seed(SEED), draw_base=s * N)
             if rank in spec.get("peekers", ()):
                 # a look at the state between two passes settles this rank's
                 # run; its peers go on with theirs
@@ -105,6 +108,8 @@ def worker(rank, world, port, out, spec):
             if rank == spec.get("offender", -1) and s == 0:
                 # ... but CHANGING the engine is against the rules
                 gpu.set_option("kernel_timing", 1)
+        if spec.get("odd_tiling") is not None:
+            len(gpu)   # (settles the run: the device's verdict is in by then)
     except RuntimeError as e:
         failure = str(e)
     with open(os.path.join(out, "failure_%d.txt" % rank), "w") as f:
@@ -285,3 +290,16 @@ def test_a_rank_that_changes_its_engine_is_told(tmp_path):
     spec = dict(config="dd", N=6000, per=750, sweeps=3, offender=1)
     failures = run(tmp_path, world, spec)
     assert all("ranks diverged" in f for f in failures), failures
+
+
+def test_ranks_that_tile_differently_are_told_by_the_header(tmp_path):
+    """Both ranks issue collectives of the same sizes, but rank 1 samples its
+    shard in batches of another size: no transport can see that.  The
+    exchange's header can (two signatures of the run's position and tiling,
+    summed with their squares: kernels_apply.h, CommCheck) -- the kernel that
+    consumes the sum raises a flag and the engines' next entry point fails on
+    EVERY rank."""
+    world = 2
+    spec = dict(config="dd", N=6000, per=750, sweeps=2, odd_tiling=1)
+    failures = run(tmp_path, world, spec)
+    assert all("ranks diverged: the header" in f for f in failures), failures
