@@ -42,7 +42,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s
 SIMDS = 1024            # 256 CUs x 4 SIMDs
 CLOCK_GHZ = 2.4         # MI355X_MICROARCH.md: max clock
-COUNTERS_FILE = "r5_counters.json"   # tools/counters.py, this round's sources
+COUNTERS_FILE = "r6_counters.json"   # tools/counters.py, this round's sources
 # what one wave64 vector instruction costs its SIMD when issued back to back,
 # by class (tools/microbench/valu_issue.hip, profiles/r2_final_valu_issue.txt)
 ISSUE_CYCLES_PACKED = 4.19   # v_pk_*, also shifts and compares
@@ -123,6 +123,25 @@ def parse():
                          "deltas + RCCL all-reduce) with a single rank")
     ap.add_argument("--no-strong", action="store_true",
                     help="N > 1: skip the strong-scaling leg")
+    ap.add_argument("--placement", default="auto",
+                    choices=["auto", "block", "value"],
+                    help="N > 1: how rows are placed on the ranks.  value = "
+                         "a rank holds the rows of ITS range of values of "
+                         "the (one, categorical) feature, so the cells never "
+                         "travel and a sub-sweep exchanges 3 words per group "
+                         "(dist_gibbs_partition_by_value); block = any rows "
+                         "anywhere, 3 + dim words per group; auto = value "
+                         "where the feature list allows it")
+    ap.add_argument("--sustained-seconds", type=float, default=2.0,
+                    help="N = 1: after the timed region the same job runs on "
+                         "for at least this long (`sustained_value`: the "
+                         "group count keeps creeping up; 0 = skip)")
+    ap.add_argument("--exact-chains", type=int, default=512,
+                    help="N = 1: independent exact chains (the reference's "
+                         "own sampler) run concurrently for "
+                         "`exact_chains_value`; 0 = skip")
+    ap.add_argument("--exact-rows", type=int, default=4000,
+                    help="rows each exact chain walks in its timed call")
     return ap.parse_args()
 
 
@@ -415,7 +434,9 @@ def cpu_c1(args, ol):
                     "CPU), BASELINE.md section 2"}
 
 
-def make_columns(args, torch, engine, dev, gen, n, k):
+def make_columns(args, torch, engine, dev, gen, n, k, value_range=None):
+    """value_range = (rank, world): the categorical column takes values of
+    this rank's share of the domain only (value-partitioned placement)"""
     def poisson(mean):
         return torch.poisson(torch.full((n,), mean, device=dev),
                              generator=gen).to(torch.int32)
@@ -425,15 +446,20 @@ def make_columns(args, torch, engine, dev, gen, n, k):
                            dtype=torch.float32)
 
     def categorical(dim):
+        lo, hi = 0, dim
+        if value_range is not None:
+            r, w_ = value_range
+            lo, hi = r * dim // w_, (r + 1) * dim // w_
         if args.values == "zipf":
             # Zipf(s = 1.1) over the dim values, by inversion
-            w = 1.0 / torch.arange(1, dim + 1, device=dev,
+            # (a rank's share of the domain: the law restricted to it)
+            w = 1.0 / torch.arange(lo + 1, hi + 1, device=dev,
                                    dtype=torch.float64) ** 1.1
             cdf = torch.cumsum(w / w.sum(), 0).to(torch.float32)
             u = torch.rand((n,), generator=gen, device=dev)
-            return torch.searchsorted(cdf, u).clamp_(max=dim - 1).to(
-                torch.int32)
-        return torch.randint(0, dim, (n,), generator=gen, device=dev,
+            return (torch.searchsorted(cdf, u).clamp_(max=hi - lo - 1)
+                    + lo).to(torch.int32)
+        return torch.randint(lo, hi, (n,), generator=gen, device=dev,
                              dtype=torch.int32)
 
     if args.config in ("dd", "dd16"):
@@ -512,6 +538,16 @@ def run_rank(args):
     k = args.groups
     seed_state = _core.rng_seed(args.seed)
 
+    by_value = (sharded_collective(world, args)
+                and not args.torch_collectives
+                and args.config in ("dd", "dd16", "dpd")
+                and args.placement in ("auto", "value"))
+    if args.placement == "value" and not by_value:
+        sys.stderr.write("bench.py: --placement value needs N > 1 (or "
+                         "--force-collective), the library's communicator "
+                         "and one categorical feature\n")
+        return 2
+
     def build_job(n, row_offset, args=args):
         k = args.groups   # (a sub-job may have its own: C5 runs at K = 8192)
         gen = torch.Generator(device=dev)
@@ -519,7 +555,8 @@ def run_rank(args):
         assign = (torch.arange(n, device=dev, dtype=torch.int64)
                   + row_offset).remainder(k).to(torch.int32)
         columns, shareds, bytes_per_row, name = make_columns(
-            args, torch, engine, dev, gen, n, k)
+            args, torch, engine, dev, gen, n, k,
+            (rank, world) if by_value else None)
         g = engine.Gibbs(args.alpha, args.d, shareds)
         g.set_option("value_sorted", args.value_sorted)
         g.set_option("value_stream", args.value_stream)
@@ -552,6 +589,7 @@ def run_rank(args):
             dist.barrier()
         torch.cuda.synchronize()
         g.kernel_stats(reset=True)
+        g.core.comm_volume(reset=True)   # (counters only: the run stays open)
         t0 = time.perf_counter()
         for i in range(steps):
             step(warmup + i)
@@ -574,6 +612,12 @@ def run_rank(args):
     n = args.rows
     g, sharded, columns, bytes_per_row, name = build_job(n, rank * n)
     native_comm = (not args.torch_collectives) and sharded.use_native_comm()
+    if by_value:
+        if not native_comm:
+            sys.stderr.write("bench.py: value placement without the "
+                             "library's communicator\n")
+            return 2
+        sharded.partition_by_value()
     column_host = None
     if (rank == 0 and world == 1 and args.cpu_rows > 0
             and args.config in ("dd", "dd16")):
@@ -586,7 +630,9 @@ def run_rank(args):
     # what the engine that ran the timed region says about itself (read
     # here: `g` is rebuilt further down)
     timed_counts = g.core.debug_counts()
-    timed_words = g.core.stat_words()
+    # (what the exchanges of the timed region really sent: the counters of
+    # dist_gibbs_sweep_sharded, not the size of a closed run's image)
+    volume = g.core.comm_volume() if native_comm else None
     streamed = timed_counts["stream_batches"]
     narrow = timed_counts["narrow_batches"]
     scratched = timed_counts["scratch_batches"]
@@ -640,6 +686,23 @@ def run_rank(args):
             "host_enqueue_ms_per_step": 1e3 * timed.host_enqueue_s / steps_b,
             "kernel": took[0] if took else "k_sweep_sample",
             "kernel_avg_launch_ms": ms_b / max(launches_b, 1)})
+
+    # (after the variants: they are quoted at the group count the timed region
+    # left)
+    # the same job running on (N = 1): the line's `value` is 20 sweeps, 22 ms
+    # of device time; this is the rate over seconds of them, with the group
+    # count the chain has reached by then (every kernel's work follows it)
+    sustained = None
+    if (world == 1 and not args.force_collective
+            and args.sustained_seconds > 0 and dt > 0):
+        steps_s = max(args.steps,
+                      int(args.sustained_seconds / (dt / args.steps)) + 1)
+        dt_s = timed(sharded, g, n, args.batch, steps_s, 0, draws)
+        draws += steps_s
+        sustained = {"value": float(n) * steps_s / dt_s,
+                     "unit": "row-updates/s", "steps": steps_s,
+                     "seconds": dt_s, "ms_per_step": 1e3 * dt_s / steps_s,
+                     "groups_at_end": len(g)}
 
     # the general-row configurations (any feature list the value-sorted
     # kernels do not take), exact and with scan sampling
@@ -698,6 +761,64 @@ def run_rank(args):
             torch.cuda.empty_cache()
             g, sharded, columns, _, _ = build_job(n, rank * n)
 
+    # the reference's OWN sampler (one row at a time, examples/mixture/main.py:
+    # 236-244) on the device: one chain, and --exact-chains independent ones in
+    # one launch (BASELINE configs[3]: "independent chains"), same model and
+    # group count as the headline
+    exact = None
+    if (world == 1 and not args.force_collective and args.exact_chains > 0
+            and args.config in ("dd", "dd16")):
+        m = args.exact_chains
+        rows_c = args.exact_rows
+        n_c = max(rows_c + 200, 8 * k)
+        dim_c = 16 if args.config == "dd16" else args.dim
+        chains = []
+        for i in range(m):
+            gen = torch.Generator(device=dev)
+            gen.manual_seed(args.seed + 1000 + i)
+            col = torch.randint(0, dim_c, (n_c,), generator=gen, device=dev,
+                                dtype=torch.int32)
+            asg = torch.arange(n_c, device=dev,
+                               dtype=torch.int64).remainder(k).to(torch.int32)
+            c = engine.Gibbs(args.alpha, args.d,
+                             [engine.dd_shared([0.5] * dim_c)])
+            c.load_rows_torch([col], asg, k, 1)
+            chains.append(c)
+        cores_ = [c.core for c in chains]
+        import numpy as np
+        st = np.array([_core.rng_seed(args.seed + 7 * i) for i in range(m)],
+                      np.uint32)
+        st1 = chains[0].sweep_sequential(0, 100, int(st[0]))   # warm, one
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        chains[0].sweep_sequential(100, 100 + rows_c, st1)
+        torch.cuda.synchronize()
+        dt_one = time.perf_counter() - t0
+        st = _core.sweep_sequential_many(cores_, 100 + rows_c,
+                                         200 + rows_c, st)    # warm, all
+        torch.cuda.synchronize()
+        first = 200 + rows_c
+        rows_m = min(rows_c, n_c - first)
+        t0 = time.perf_counter()
+        _core.sweep_sequential_many(cores_, first, first + rows_m, st)
+        torch.cuda.synchronize()
+        dt_many = time.perf_counter() - t0
+        exact = {"sequential_value": rows_c / dt_one,
+                 "sequential_us_per_row": 1e6 * dt_one / rows_c,
+                 "sequential_cycles_per_row": CLOCK_GHZ * 1e9 * dt_one / rows_c,
+                 "exact_chains_value": m * rows_m / dt_many,
+                 "chains": m, "rows_per_chain": rows_m,
+                 "us_per_row_and_chain": 1e6 * dt_many / rows_m,
+                 "unit": "row-updates/s",
+                 "note": "the reference's sequential sampler itself, "
+                         "bit-exact per chain against the oracle "
+                         "(tests/test_gpu_chains.py): k_chains, one "
+                         "workgroup per chain, group creation and removal "
+                         "on the device; %s K=%d+1, %d rows per chain"
+                         % (name, k, n_c)}
+        del chains, cores_
+        torch.cuda.empty_cache()
+
     strong = None
     if world > 1 and not args.no_strong:
         # strong scaling: the SAME N rows in total, split over the ranks
@@ -708,6 +829,8 @@ def run_rank(args):
         g2, sharded2, _, _, _ = build_job(n_s, rank * n_s)
         if native_comm:
             sharded2.use_native_comm(comm)
+        if by_value:
+            sharded2.partition_by_value()
         steps_s = max(1, min(args.steps, 10))
         batch_s = max(1, min(args.batch, n_s))
         dt_s = timed(sharded2, g2, n_s, batch_s, steps_s, args.warmup, 0)
@@ -806,6 +929,14 @@ def run_rank(args):
                          {"file": "profiles/" + COUNTERS_FILE,
                           "stale": ctr["stale"],
                           "rows_per_launch": ctr["rows_per_launch"]}),
+            # non-null: why `frac` is missing -- never silently
+            "stale_reason": (
+                None if usable else
+                "no counters for %s in profiles/%s" % (kernel, COUNTERS_FILE)
+                if ctr is None else
+                "the kernel sources changed since profiles/%s was taken "
+                "(hash %s): run tools/profile_round.sh on a GPU box"
+                % (COUNTERS_FILE, source_hash())),
             "timed_every": args.kernel_timing,
             "note": "avg_launch_ms: HIP events on the launch stream around "
                     "every `timed_every`-th launch of the timed region, this "
@@ -820,6 +951,9 @@ def run_rank(args):
                     "likelihood vector serves 128 rows), so it is not a "
                     "fraction of any roof: DESIGN.md section 4",
         })
+        if roof.get("stale_reason"):
+            sys.stderr.write("bench.py: WARNING roofline.frac is missing: %s\n"
+                             % roof["stale_reason"])
         out = {
             "metric": METRIC,
             "value": total_rows / dt,
@@ -873,6 +1007,14 @@ def run_rank(args):
                                      if o["config"] == "mixed"
                                      and o["sampling"] == "exact"), None),
             },
+            # the job running on for seconds (see --sustained-seconds)
+            "sustained_value": sustained["value"] if sustained else None,
+            "sustained": sustained,
+            # the reference's own sampler on the device (see --exact-chains)
+            "sequential_value": exact["sequential_value"] if exact else None,
+            "exact_chains_value": (exact["exact_chains_value"]
+                                   if exact else None),
+            "exact_chains": exact,
             "roofline": roof,
             "step_breakdown": breakdown,
             "batch_variants": variants,
@@ -909,10 +1051,25 @@ def run_rank(args):
                         (step_us - avg_us * sub_sweeps) / sub_sweeps / 3.0
                         if avg_us is not None else None)},
                 "timed": comm_count,
-                "words_per_all_reduce": timed_words,
+                # counted by dist_gibbs_sweep_sharded over the timed region
+                # itself (4 header words included): the live part of the
+                # group set, or 3 words per group on value-partitioned ranks
+                "placement": "value" if by_value else "block",
+                "all_reduces_in_run": volume["collectives"] if volume else None,
+                "words_in_run": volume["words"] if volume else None,
+                "words_per_all_reduce": (
+                    volume["words"] / max(volume["collectives"], 1)
+                    if volume else None),
+                "words_largest_all_reduce": (volume["words_max"]
+                                             if volume else None),
+                "bytes_per_all_reduce": (
+                    4.0 * volume["words"] / max(volume["collectives"], 1)
+                    if volume else None),
                 "note": "HIP events around the library's in-place all-reduce "
                         "of the int32 delta image, every `timed_every`-th "
-                        "sub-sweep of the timed region and the variants"}
+                        "sub-sweep of the timed region and the variants; "
+                        "words_*: what those all-reduces carried, counted "
+                        "by the library"}
         if strong is not None:
             out["strong_scaling"] = strong
         if column_host is not None:

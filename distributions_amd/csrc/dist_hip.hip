@@ -4258,12 +4258,27 @@ struct Gibbs {
         A.k_room = room;
         A.g_room = (uint32_t)std::min<size_t>(d_maps.cap - maps_pcap,
                                               0x7FFFFFFFu);
+        static const bool stamps = getenv("DIST_CHAIN_STAMPS");
+        if (stamps) {
+            chain_stamps.reserve(8, 0);
+            A.stamps = chain_stamps.p;
+        }
         return A;
     }
     // the host's mirrors after a launch: group sizes, group count, id maps
+    DeviceBuf<unsigned long long> chain_stamps;
     ChainResult chain_collect() {
         ChainResult res;
         chain_result.download(&res, 1);
+        if (chain_stamps.p) {   // (diagnostic: DIST_CHAIN_STAMPS)
+            unsigned long long t[5];
+            chain_stamps.download(t, 5);
+            const double n = res.rows_done ? (double)res.rows_done : 1.0;
+            fprintf(stderr, "[dist] chain: %u rows; cycles per row: scores+max "
+                    "%.0f, exp %.0f, recurrences %.0f, update %.0f; slow "
+                    "path total %.0f\n", res.rows_done, t[0] / n, t[1] / n,
+                    t[2] / n, t[3] / n, (double)t[4]);
+        }
         DevState st;
         dev_state.download(&st, 1);
         const size_t Kn = (size_t)st.K;

@@ -1326,7 +1326,7 @@ __device__ __forceinline__ void wave_row_update(
 // dependent gather round trips to ~2K LDS-fed adds.
 template <int KIND0, int KIND1, int NF>
 __global__ __launch_bounds__(kBlock) void k_rows_wave(SweepParams P) {
-    extern __shared__ float wave_lds[];
+    extern __shared__ __attribute__((aligned(16))) float wave_lds[];
     __shared__ uint32_t s_exp[1024];
     {   // most launches find few rows or none: workgroups without one leave
         const size_t n = P.row_list ? (size_t)*P.row_list_count
@@ -1422,7 +1422,7 @@ __global__ __launch_bounds__(kBlock) void k_chain_rows(
         SweepParams P, float * __restrict__ base, int32_t * counts,
         uint32_t * assign, const uint32_t * __restrict__ p2g,
         uint32_t rng_state, ChainResult * result) {
-    extern __shared__ float chain_lds[];   // [K] scores, then likelihoods
+    extern __shared__ __attribute__((aligned(16))) float chain_lds[];   // [K] scores, then likelihoods
     __shared__ uint32_t s_exp[1024];
     __shared__ uint32_t s_log[16384];      // FastLog table: the per-row cache
     __shared__ float s_red[kBlock / 64];   // refreshes run on one thread
@@ -1578,6 +1578,9 @@ struct ChainArgs {
     uint32_t rng_state;
     int k_room;            // slots the arrays and the LDS strips hold
     uint32_t g_room;       // global ids the map holds
+    // DIST_CHAIN_STAMPS: wave 0's cycles by phase (scores + max | exp |
+    // recurrences | update | slow path), summed over the rows; else null
+    unsigned long long * stamps;
 };
 
 template <class T>
@@ -1586,16 +1589,64 @@ __device__ __forceinline__ T chain_peek(const T * p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+// chain_value_op that also hands back the group's NEW cache entry as a row of
+// value `next_value` will see it (the next row's score of this slot is
+// patched from it, see k_chains): one round trip to memory for everything.
+__device__ __forceinline__ Entry chain_value_op_next(
+        const SlaveView & s, int k, uint32_t value, bool add,
+        const uint32_t * log_tab, uint32_t next_value) {
+    Entry e = {0.f, 0.f, 0.f, 0.f};
+    if (is_cat(s.kind)) {
+        const size_t cell = (size_t)k * s.dim + value;
+        const bool same = next_value == value;
+        const bool other = s.kind == DIST_DPD && next_value == DIST_DPD_OTHER;
+        const int c_in = s.cnt[cell];
+        const int n_in = s.i0[k];
+        const float prior = s.prior[value];
+        const float s_next =
+            (same || other) ? 0.f : s.S[(size_t)next_value * s.cap + k];
+        const int c2 = c_in + (add ? 1 : -1);
+        const int n2 = n_in + (add ? 1 : -1);
+        s.cnt[cell] = c2;
+        s.i0[k] = n2;
+        // dd.hpp:458-467 / dpd.hpp:458-470
+        const float s_new = fast_log_t(prior + (float)c2, log_tab);
+        e.c0 = fast_log_t(s.alpha_sum + (float)n2, log_tab);
+        s.S[(size_t)value * s.cap + k] = s_new;
+        s.c0[k] = e.c0;
+        e.c1 = other ? s.other : same ? s_new : s_next;
+        return e;
+    }
+    Stats st = load_stats(s, k);
+    if (add) stats_add(s.kind, st, value); else stats_remove(s.kind, st, value);
+    store_stats(s, k, st);
+    e = scorer_init(s.kind, s.p, st);
+    s.c0[k] = e.c0;
+    s.c1[k] = e.c1;
+    s.c2[k] = e.c2;
+    s.c3[k] = e.c3;
+    return e;
+}
+
+// a barrier for data that lives in LDS only: __syncthreads() also waits for
+// the wave's outstanding global loads and stores (vmcnt), which here would
+// put a trip to memory on the chain's critical path at every phase
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 template <int KIND0, int KIND1, int NF>
 __global__ __launch_bounds__(kBlock) void k_chains(
         const ChainArgs * __restrict__ all) {
     const ChainArgs & A = all[blockIdx.x];
     const SweepParams & P = A.P;
-    extern __shared__ float chain_lds[];   // [room] scores, [room] group sizes
+    extern __shared__ __attribute__((aligned(16))) float chain_lds[];   // [room] scores, [room] group sizes
     __shared__ uint32_t s_exp[1024];
     __shared__ uint32_t s_log[16384];      // FastLog's table
     __shared__ float s_red[kBlock / 64];
     __shared__ int s_g2;
+    __shared__ int s_patch_slot[2];
+    __shared__ float s_patch_score[2];
     for (int i = threadIdx.x; i < 1024; i += kBlock)
         s_exp[i] = g_tables_dev.exp_table[i];
     for (int i = threadIdx.x; i < 16384; i += kBlock)
@@ -1635,35 +1686,45 @@ __global__ __launch_bounds__(kBlock) void k_chains(
         for (int k = tid; k < K; k += kBlock)
             if (size_l[k] == 0) base[k] = es;
     };
-    // remove_value for a group that stays (one thread)
-    auto remove_from = [&](int g, const uint32_t * x) {
-        const int n = size_l[g] - 1;
-        size_l[g] = n;
-        base[g] = own_score(n);
-        for (int f = 0; f < nf; ++f) {
+    // score_value of slot k for a row (driver, then every feature accumulates)
+    auto score_slot = [&](int k, const uint32_t * xx, const float * lff) {
+        float sk = base[k];
+#pragma unroll
+        for (int f = 0; f < (NF > 0 ? NF : kMaxF); ++f) {
+            if (f >= nf) break;
             SlaveView v = P.feat[f];
             v.kind = kind[f];
-            chain_value_op(v, g, x[f], false, s_log);
+            sk = accumulate(kind[f], sk, load_entry(v, k, xx[f]), xx[f],
+                            lff[f], v.p);
         }
+        return sk;
     };
-    auto add_to = [&](int g2, const uint32_t * x, size_t row) {
-        const int n = size_l[g2] + 1;
-        size_l[g2] = n;
-        base[g2] = own_score(n);
+    // add_value / remove_value on slot g for a group that stays (one thread);
+    // returns the slot's score for the NEXT row (values xq, log-factorials lq)
+    auto change = [&](int g, const uint32_t * xv, bool add,
+                      const uint32_t * xq, const float * lq) {
+        const int n = size_l[g] + (add ? 1 : -1);
+        size_l[g] = n;
+        float sk = own_score(n);
+        base[g] = sk;
         for (int f = 0; f < nf; ++f) {
             SlaveView v = P.feat[f];
             v.kind = kind[f];
-            chain_value_op(v, g2, x[f], true, s_log);
+            const Entry e = chain_value_op_next(v, g, xv[f], add, s_log, xq[f]);
+            sk = accumulate(kind[f], sk, e, xq[f], lq[f], v.p);
         }
-        A.assign[row] = chain_peek(A.p2g + g2);
+        return sk;
     };
     // remove_value of the next row, by all threads (between two barriers):
     // the group stays, or vanishes with its last member
-    auto remove_row = [&](int g, const uint32_t * x) {
+    auto remove_row = [&](int g, const uint32_t * xv) {
         const int members = size_l[g];
         __syncthreads();   // (everybody has read it before anybody writes)
         if (members != 1) {
-            if (tid == 0) remove_from(g, x);
+            if (tid == 0) {
+                const float none[kMaxF] = {};
+                (void)change(g, xv, false, xv, none);
+            }
             return;
         }
         const int last = K - 1;
@@ -1740,19 +1801,39 @@ __global__ __launch_bounds__(kBlock) void k_chains(
         rescore_empties();
     };
 
+    // The NEXT row's scores are made by waves 1..3 while wave 0 runs this
+    // row's recurrences (the trips to memory of a row's K gathers are then
+    // nobody's wait), kept in registers -- slot (tid - 64) + 192 j -- and
+    // written to the strip once the recurrences are done; the two slots this
+    // row's add_value and the next row's remove_value change are patched from
+    // the values the updating threads hold anyway.
+    constexpr int kPre = 12;
+    constexpr int kPreLanes = kBlock - 64;
+    float sn[kPre];
+#pragma unroll
+    for (int j = 0; j < kPre; ++j) sn[j] = 0.f;
+    bool pre_ok = false;   // (uniform) sn[] holds this row's scores
+
     uint32_t done = 0;
     int event = 0;
     size_t row = P.row_begin;
     uint32_t x[kMaxF], xn[kMaxF];
+    float lf[kMaxF], lfn[kMaxF];
+    for (int f = 0; f < kMaxF; ++f) { x[f] = xn[f] = 0; lf[f] = lfn[f] = 0.f; }
     if (row < P.row_end) {
         if (K + 1 > A.k_room || gsz + 1 > A.g_room) {
             event = 3;
         } else {
-            for (int f = 0; f < nf; ++f) x[f] = P.values[f][row];
+            for (int f = 0; f < nf; ++f) {
+                x[f] = P.values[f][row];
+                lf[f] = kind[f] == DIST_GP ? fast_log_factorial(x[f]) : 0.f;
+            }
             remove_row(chain_peek(A.g2p + A.assign[row]), x);
         }
     }
+    unsigned long long acc[5] = {0, 0, 0, 0, 0};
     while (event == 0 && row < P.row_end) {
+        const unsigned long long t_a = A.stamps ? clock64() : 0;
         // the next row's words, under this row's work
         const bool has_next = row + 1 < P.row_end;
         uint32_t a_next = 0;
@@ -1760,65 +1841,98 @@ __global__ __launch_bounds__(kBlock) void k_chains(
             a_next = A.assign[row + 1];
             for (int f = 0; f < nf; ++f) xn[f] = P.values[f][row + 1];
         }
-        float lf[kMaxF];
-        for (int f = 0; f < nf; ++f)
-            lf[f] = kind[f] == DIST_GP ? fast_log_factorial(x[f]) : 0.f;
-        __threadfence_block();
-        __syncthreads();
-        // (no step of this row moves a group: the map is stable until then)
-        const int gn = has_next ? chain_peek(A.g2p + a_next) : -1;
-        // score_value: driver, then every feature accumulates
         float m = -INFINITY;
-        for (int k = tid; k < K; k += kBlock) {
-            float s = base[k];
+        if (pre_ok) {
+            if (wave != 0) {
+                const int s0 = s_patch_slot[0], s1 = s_patch_slot[1];
 #pragma unroll
-            for (int f = 0; f < (NF > 0 ? NF : kMaxF); ++f) {
-                if (f >= nf) break;
-                SlaveView v = P.feat[f];
-                v.kind = kind[f];
-                s = accumulate(kind[f], s, load_entry(v, k, x[f]), x[f],
-                               lf[f], v.p);
+                for (int j = 0; j < kPre; ++j) {
+                    const int k = (tid - 64) + kPreLanes * j;
+                    if (k < K) {
+                        float sk = sn[j];
+                        if (k == s0) sk = s_patch_score[0];
+                        if (k == s1) sk = s_patch_score[1];
+                        sc[k] = sk;
+                        m = sk > m ? sk : m;
+                    }
+                }
             }
-            sc[k] = s;
-            m = s > m ? s : m;
+        } else {
+            __threadfence_block();
+            __syncthreads();
+            for (int k = tid; k < K; k += kBlock) {
+                const float sk = score_slot(k, x, lf);
+                sc[k] = sk;
+                m = sk > m ? sk : m;
+            }
         }
         for (int off = 32; off > 0; off >>= 1) {
             const float o = __shfl_xor(m, off);
             m = o > m ? o : m;
         }
         if (lane == 0) s_red[wave] = m;
-        __syncthreads();
+        lds_barrier();
+        const unsigned long long t_b = A.stamps ? clock64() : 0;
         m = s_red[0];
 #pragma unroll
         for (int w = 1; w < kBlock / 64; ++w) m = s_red[w] > m ? s_red[w] : m;
         // scores_to_likelihoods (random.cc:94-106): exponentials in parallel
         for (int k = tid; k < ((K + 63) & ~63); k += kBlock)
             sc[k] = k < K ? fast_exp_nonpos(sc[k] - m, s_exp, ea, eb) : 0.f;
+        // (the statistics the last update wrote are everybody's from here on:
+        // the stores are a phase old, waiting for them costs nothing)
+        __threadfence_block();
         __syncthreads();
+        const unsigned long long t_c = A.stamps ? clock64() : 0;
+        // (no step of this row moves a group: the map is stable until then)
+        const int gn = has_next ? chain_peek(A.g2p + a_next) : -1;
+        const bool can_pre = has_next && K <= kPreLanes * kPre;
+        if (has_next)
+            for (int f = 0; f < nf; ++f)
+                lfn[f] = kind[f] == DIST_GP ? fast_log_factorial(xn[f]) : 0.f;
         if (wave == 0) {
             const float total = strip_total(sc, K);
             rng_state = lcg_mulmod(rng_state, 16807u);
             const int g2 = strip_sample(sc, K, total * lcg_unif01(rng_state));
             if (lane == 0) s_g2 = g2;
+        } else if (can_pre) {
+#pragma unroll
+            for (int j = 0; j < kPre; ++j) {
+                const int k = (tid - 64) + kPreLanes * j;
+                if (k < K) sn[j] = score_slot(k, xn, lfn);
+            }
         }
-        __syncthreads();
+        lds_barrier();
+        const unsigned long long t_d = A.stamps ? clock64() : 0;
         const int g2 = s_g2;
         const int n2 = size_l[g2];
         const bool room_ok = K + 1 <= A.k_room && gsz + 1 <= A.g_room;
         const bool fast = n2 > 0 && has_next && room_ok
                           && (gn == g2 || size_l[gn] > 1);
-        __syncthreads();   // (size_l is read above, written below)
+        lds_barrier();   // (size_l is read above, written below)
         if (fast) {
             // add_value beside the next row's remove_value: different
             // groups on two waves, the same group in order on one thread
             if (tid == 0) {
-                add_to(g2, x, row);
-                if (gn == g2) remove_from(gn, xn);
+                // (asked for first: one trip to memory for all of it)
+                const uint32_t gid = chain_peek(A.p2g + g2);
+                float sk = change(g2, x, true, xn, lfn);
+                if (gn == g2) sk = change(gn, xn, false, xn, lfn);
+                A.assign[row] = gid;
+                s_patch_slot[0] = g2;
+                s_patch_score[0] = sk;
+                if (gn == g2) s_patch_slot[1] = -1;
             } else if (tid == 64 && gn != g2) {
-                remove_from(gn, xn);
+                s_patch_score[1] = change(gn, xn, false, xn, lfn);
+                s_patch_slot[1] = gn;
             }
+            pre_ok = can_pre;
+            lds_barrier();
         } else {
-            if (tid == 0) add_to(g2, x, row);
+            if (tid == 0) {
+                (void)change(g2, x, true, x, lf);
+                A.assign[row] = chain_peek(A.p2g + g2);
+            }
             __threadfence_block();
             __syncthreads();
             if (n2 == 0) append_group();
@@ -1830,14 +1944,24 @@ __global__ __launch_bounds__(kBlock) void k_chains(
                     remove_row(gn, xn);
                 }
             }
+            pre_ok = false;
+        }
+        if (A.stamps) {
+            const unsigned long long t_e = clock64();
+            acc[0] += t_b - t_a;
+            acc[1] += t_c - t_b;
+            acc[2] += t_d - t_c;
+            acc[fast ? 3 : 4] += t_e - t_d;
         }
         done += 1;
         row += 1;
-        for (int f = 0; f < nf; ++f) x[f] = xn[f];
+        for (int f = 0; f < nf; ++f) { x[f] = xn[f]; lf[f] = lfn[f]; }
     }
     __threadfence_block();
     __syncthreads();
     for (int k = tid; k < K; k += kBlock) A.counts[k] = size_l[k];
+    if (tid == 0 && A.stamps)
+        for (int i = 0; i < 5; ++i) A.stamps[i] = acc[i];
     if (tid == 0) {
         A.dev->K = K;
         A.dev->nonempty = nonempty;

@@ -146,7 +146,7 @@ __global__ __launch_bounds__(kBlock) void k_vs_prepare(
     __shared__ float sh_M, sh_mB;
     __shared__ uint32_t sh_lo, sh_hi, sh_n;
     __shared__ int sh_amax;
-    extern __shared__ float s_l[];   // [2][Kpad] when the running sums are built
+    extern __shared__ __attribute__((aligned(16))) float s_l[];   // [2][Kpad] when the running sums are built
     const uint32_t x = blockIdx.x;
     SlaveView v = P.feat[0];
     v.kind = KIND;
@@ -404,7 +404,7 @@ __global__ __launch_bounds__(kTablesBlock) void k_vs_tables(TablesParams A,
     // [Kpad] LA | [Kpad] LB for the running sums | the plan of a batch that
     // swap-removes groups: [Kpad + 2] vanished-before | [Kpad] the slot each
     // slot's group comes from
-    extern __shared__ float tb_lds[];
+    extern __shared__ __attribute__((aligned(16))) float tb_lds[];
     constexpr int kWaves = kTablesBlock / 64;
     __shared__ float r_m1[kWaves], r_m2[kWaves];
     __shared__ int r_i1[kWaves];
@@ -1264,7 +1264,7 @@ __global__ __launch_bounds__(kVsScanBlock) void k_vs_scan_prepare(
     __shared__ float r_m[kVsScanBlock / 64];
     __shared__ float r_sum[kVsScanBlock / 64];
     __shared__ float sh_M, sh_carry;
-    extern __shared__ float s_scores[];   // [Kpad] when T.lds_scores
+    extern __shared__ __attribute__((aligned(16))) float s_scores[];   // [Kpad] when T.lds_scores
     constexpr float kLog2e = 1.44269504088896341f;
     const uint32_t x = blockIdx.x;
     SlaveView v = P.feat[0];
