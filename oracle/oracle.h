@@ -42,10 +42,17 @@
  *     sizes, empty set, add/remove flags)                           template)
  *   orc_mix_tracker_*, orc_mix_packed_    mixture.hpp:460-521       _ref
  *     to_global / global_to_packed
- *   orc_scores_to_likelihoods,            random.cc:94-106,         UNPINNED
+ *   orc_scores_to_likelihoods,            random.cc:94-106,         bits UNPINNED
  *     orc_sample_from_likelihoods,        random.hpp:316-333,       (probe: one
  *     orc_sample_from_scores_*,           361-392; random.cc:77-92  vector, 8
- *     orc_log_sum_exp, orc_sample_discrete                          draws)
+ *     orc_log_sum_exp, orc_sample_discrete                          draws);
+ *                                                                   WHAT IT
+ *     SAMPLES: the reference's own softmax (distributions/util.py:33-38
+ *     scores_to_probs, run where it lies by tests/golden/
+ *     make_sampler_goldens.py -> sampler_probs.json.gz): likelihoods / total
+ *     within 5e-6 relative, 40 000 - 150 000 draws per vector chi-squared
+ *     against it, K = 1 ... 1024 (tests/test_sampler_goldens.py, oracle and
+ *     HIP library; the two agree draw for draw)
  *   orc_py_score_add_value/remove_value,  clustering.hpp:81-123,    UNPINNED
  *     orc_mix_driver_score_value and the  195-230                   (probe:
  *     shifted-score cache, orc_py_score_  clustering.cc:37-63,      score_counts
