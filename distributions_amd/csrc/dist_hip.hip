@@ -114,11 +114,28 @@ struct UploadRing {
         }
         hipStream_t now = stream();
         if (now != on) {
-            // copies of another stream may still read the ring: drain it
-            if (recorded[0] || recorded[1] || head)
-                HIP_CHECK(hipStreamSynchronize(on));
-            recorded[0] = recorded[1] = false;
+            // copies of another stream may still read the ring: drain it.
+            // By an event of its own recorded on that stream -- or, when the
+            // caller has destroyed the stream meanwhile (dist_set_stream with
+            // a temporary one: the handle is invalid, and whatever it queued
+            // went with it), by the device -- never by a throw that would
+            // leave `on` stale and fail every later upload of this thread.
+            const hipStream_t before = on;
             on = now;
+            if (recorded[0] || recorded[1] || head) {
+                bool drained = hipEventRecord(left[0], before) == hipSuccess
+                               && hipEventSynchronize(left[0]) == hipSuccess;
+                if (!drained) {
+                    (void)hipGetLastError();
+                    drained = hipDeviceSynchronize() == hipSuccess;
+                }
+                if (!drained) {
+                    (void)hipGetLastError();
+                    return host;   // (the synchronous copy, this once)
+                }
+            }
+            recorded[0] = recorded[1] = false;
+            head = 0;
         }
         const size_t need = (bytes + 255) & ~(size_t)255;
         // the half written last, and what is left of it
@@ -1512,9 +1529,9 @@ struct Gibbs {
         DeviceBuf<uint32_t> packed;
         packed.reserve(std::max<size_t>(rows, 1), 0);
         DeviceBuf<unsigned long long> out;
-        out.reserve(2, 0);
-        const unsigned long long init[2] = {~0ull, 0ull};
-        out.upload(init, 2);
+        out.reserve(4, 0);
+        const unsigned long long init[4] = {~0ull, 0ull, ~0ull, ~0ull};
+        out.upload(init, 4);
         SweepParams P = params(0, rows, 1, 0);
         StatImage recount = word_image(words.p);
         if (rows)
@@ -1528,8 +1545,8 @@ struct Gibbs {
             LAUNCH(k_validate_compare, Kn * width, P, live, recount, f,
                    Kn * width, out.p);
         }
-        unsigned long long got[2];
-        out.download(got, 2);
+        unsigned long long got[4];
+        out.download(got, 4);
         rep->rows_assigned = (long long)got[1];
         if (got[0] == ~0ull) {
             if ((long long)got[1] != total)
@@ -1541,6 +1558,31 @@ struct Gibbs {
         rep->feature = (int)((got[0] >> 56) & 15);
         rep->group = (long long)((got[0] >> 28) & 0xFFFFFFFull);
         rep->detail = (long long)(got[0] & 0xFFFFFFFull);
+        // (a row check: the offending row whole, not its low 28 bits, and
+        // what it carries read back from the row itself)
+        if (rep->code == VALIDATE_DEAD_ID && got[2] != ~0ull) {
+            rep->group = (long long)got[2];
+            uint32_t id = 0;
+            HIP_CHECK(hipMemcpyAsync(&id, assign + got[2], 4,
+                                     hipMemcpyDeviceToHost, stream()));
+            sync();
+            rep->detail = (long long)id;
+        } else if (rep->code == VALIDATE_VALUE_RANGE && got[3] != ~0ull
+                   && got[3] >= (1ull << 28)) {
+            rep->group = (long long)got[3];
+            for (int f = 0; f < F(); ++f) {
+                if (!is_cat(feats[f]->sh.kind)) continue;
+                uint32_t x = 0;
+                HIP_CHECK(hipMemcpyAsync(&x, values[f] + got[3], 4,
+                                         hipMemcpyDeviceToHost, stream()));
+                sync();
+                if (x >= (uint32_t)feats[f]->dim()) {
+                    rep->feature = f;
+                    rep->detail = (long long)x;
+                    break;
+                }
+            }
+        }
         static const char * names[] = {
             "", "a row carries a group id that is not live",
             "a row's value is outside the feature's domain",

@@ -796,7 +796,10 @@ enum ValidateCode {
     VALIDATE_HOST = 7           // the host's mirror of the group set
 };
 
-// code:4 | feature:4 | group:28 | detail:28 -- the lowest key wins
+// code:4 | feature:4 | group:28 | detail:28 -- the lowest key wins.  (A ROW
+// does not fit 28 bits in a data set of 2^28 rows or more: the lowest
+// offending row of either row check also goes, whole, to first_bad[2] /
+// first_bad[3], and the host reports that one.)
 __device__ __forceinline__ unsigned long long validate_key(
         int code, int feature, unsigned long long group,
         unsigned long long detail) {
@@ -818,6 +821,7 @@ __global__ void k_validate_rows(SweepParams P, StatImage img,
     const int32_t g = id < n_global ? g2p[id] : -1;
     if (g < 0 || g >= P.K) {
         atomicMin(first_bad, validate_key(VALIDATE_DEAD_ID, 0, row, id));
+        atomicMin(first_bad + 2, (unsigned long long)row);
         return;
     }
     packed_out[row] = (uint32_t)g;
@@ -832,6 +836,7 @@ __global__ void k_validate_rows(SweepParams P, StatImage img,
             if (x >= (uint32_t)s.dim) {
                 atomicMin(first_bad,
                           validate_key(VALIDATE_VALUE_RANGE, f, row, x));
+                atomicMin(first_bad + 3, (unsigned long long)row);
                 break;
             }
             atomicAdd(&img.i0[f][g], 1);

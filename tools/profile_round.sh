@@ -11,7 +11,7 @@ out=gpurun_out/$tag
 mkdir -p $out
 repo=$PWD
 cd /tmp && export TMPDIR=/tmp && cd $repo
-B="bench.py --cpu-rows 0 --other-batches= --other-configs= --no-breakdown"
+B="bench.py --cpu-rows 0 --other-batches= --other-configs= --no-breakdown --exact-chains 0 --sustained-seconds 0"
 SQ="SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY"
 
 # one configuration: trace (+ timeline of a sub-sweep), SQ / FETCH / WRITE
@@ -80,5 +80,11 @@ python3 $B --steps 10 --values zipf 2>/dev/null | tail -1 >> $out/bench_other_co
 python3 $B --steps 10 --d 0 2>/dev/null | tail -1 >> $out/bench_other_configs.jsonl
 python3 $B --steps 10 --opt sampling=1 2>/dev/null | tail -1 >> $out/bench_other_configs.jsonl
 python3 $B --steps 10 --batch 65536 --opt sampling=1 2>/dev/null | tail -1 >> $out/bench_other_configs.jsonl
+# the N > 1 code path on one rank: value-partitioned ranks (3 words per group
+# and sub-sweep) and block placement (3 + dim words per live group)
 python3 $B --steps 20 --warmup 5 --force-collective 2>/dev/null | tail -1 > $out/bench_collective_one_rank.json
+python3 $B --steps 20 --warmup 5 --force-collective --placement block 2>/dev/null | tail -1 > $out/bench_collective_one_rank_block.json
+python3 $B --steps 3 --warmup 2 --config dpd --groups 8192 --dim 10000 --force-collective 2>/dev/null | tail -1 > $out/bench_collective_one_rank_c5.json
+# the exact chains (the reference's own sampler on the device)
+python3 tools/exact_chains.py 20000 1 8 64 256 512 1024 > $out/exact_chains.txt 2>&1
 ls -la $out
