@@ -136,7 +136,7 @@ def parse():
                     help="N = 1: after the timed region the same job runs on "
                          "for at least this long (`sustained_value`: the "
                          "group count keeps creeping up; 0 = skip)")
-    ap.add_argument("--exact-chains", type=int, default=512,
+    ap.add_argument("--exact-chains", type=int, default=1024,
                     help="N = 1: independent exact chains (the reference's "
                          "own sampler) run concurrently for "
                          "`exact_chains_value`; 0 = skip")
@@ -770,7 +770,7 @@ def run_rank(args):
             and args.config in ("dd", "dd16")):
         m = args.exact_chains
         rows_c = args.exact_rows
-        n_c = max(rows_c + 200, 8 * k)
+        n_c = max(3 * rows_c + 200, 8 * k)
         dim_c = 16 if args.config == "dd16" else args.dim
         chains = []
         for i in range(m):
@@ -798,9 +798,18 @@ def run_rank(args):
                                          200 + rows_c, st)    # warm, all
         torch.cuda.synchronize()
         first = 200 + rows_c
-        rows_m = min(rows_c, n_c - first)
+        rows_m = min(rows_c, (n_c - first) // 2)
+        # two chains per compute unit (FastLog's table in LDS) ...
+        m_half = min(m, 512)
         t0 = time.perf_counter()
-        _core.sweep_sequential_many(cores_, first, first + rows_m, st)
+        st[:m_half] = _core.sweep_sequential_many(
+            cores_[:m_half], first, first + rows_m, st[:m_half])
+        torch.cuda.synchronize()
+        dt_half = time.perf_counter() - t0
+        # ... and all of them (beyond 512: four per CU, the table in L2)
+        t0 = time.perf_counter()
+        _core.sweep_sequential_many(cores_, first + rows_m,
+                                    first + 2 * rows_m, st)
         torch.cuda.synchronize()
         dt_many = time.perf_counter() - t0
         exact = {"sequential_value": rows_c / dt_one,
@@ -809,6 +818,7 @@ def run_rank(args):
                  "exact_chains_value": m * rows_m / dt_many,
                  "chains": m, "rows_per_chain": rows_m,
                  "us_per_row_and_chain": 1e6 * dt_many / rows_m,
+                 "exact_chains_512_value": m_half * rows_m / dt_half,
                  "unit": "row-updates/s",
                  "note": "the reference's sequential sampler itself, "
                          "bit-exact per chain against the oracle "

@@ -4348,15 +4348,29 @@ struct Gibbs {
         const ChainArgs * args;
         unsigned chains;
         size_t lds;
-        template <int A, int B, int NF>
-        void run() {
+        template <int A, int B, int NF, bool LOGL>
+        void go() {
             (void)hipFuncSetAttribute(
-                reinterpret_cast<const void *>(&k_chains<A, B, NF>),
+                reinterpret_cast<const void *>(&k_chains<A, B, NF, LOGL>),
                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             (void)hipGetLastError();
-            hipLaunchKernelGGL((k_chains<A, B, NF>), dim3(chains), dim3(kBlock),
-                               lds, stream(), args);
+            hipLaunchKernelGGL((k_chains<A, B, NF, LOGL>), dim3(chains),
+                               dim3(kBlock), lds, stream(), args);
             HIP_CHECK(hipGetLastError());
+        }
+        template <int A, int B, int NF>
+        void run() {
+            // more than two chains per compute unit: the instance that
+            // leaves FastLog's table where it lies (four fit a CU)
+            int device = 0, cus = 256;
+            if (hipGetDevice(&device) == hipSuccess)
+                (void)hipDeviceGetAttribute(
+                    &cus, hipDeviceAttributeMultiprocessorCount, device);
+            static const char * force = getenv("DIST_CHAIN_LOG_TABLE");
+            const bool in_lds = force ? atoi(force) != 0
+                                      : chains <= 2u * (unsigned)cus;
+            if (in_lds) go<A, B, NF, true>();
+            else go<A, B, NF, false>();
         }
     };
     DeviceBuf<ChainArgs> chain_args;

@@ -1635,22 +1635,30 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <int KIND0, int KIND1, int NF>
-__global__ __launch_bounds__(kBlock) void k_chains(
-        const ChainArgs * __restrict__ all) {
+// LOGL: FastLog's 64 KiB table in LDS (two chains fit a compute unit: the
+// fastest single chain) or read where it lies (L2; the three logarithms of
+// an update then cost it a second trip to memory, but four chains fit a CU:
+// launches of more than two chains per CU take this instance)
+template <int KIND0, int KIND1, int NF, bool LOGL>
+__global__ __launch_bounds__(kBlock)
+__attribute__((amdgpu_waves_per_eu(LOGL ? 2 : 4, LOGL ? 2 : 4)))
+void k_chains(const ChainArgs * __restrict__ all) {
     const ChainArgs & A = all[blockIdx.x];
     const SweepParams & P = A.P;
     extern __shared__ __attribute__((aligned(16))) float chain_lds[];   // [room] scores, [room] group sizes
     __shared__ uint32_t s_exp[1024];
-    __shared__ uint32_t s_log[16384];      // FastLog's table
+    __shared__ uint32_t s_log_lds[LOGL ? 16384 : 1];   // FastLog's table
     __shared__ float s_red[kBlock / 64];
     __shared__ int s_g2;
     __shared__ int s_patch_slot[2];
     __shared__ float s_patch_score[2];
     for (int i = threadIdx.x; i < 1024; i += kBlock)
         s_exp[i] = g_tables_dev.exp_table[i];
-    for (int i = threadIdx.x; i < 16384; i += kBlock)
-        s_log[i] = g_tables_dev.log_table[i];
+    if (LOGL)
+        for (int i = threadIdx.x; i < 16384; i += kBlock)
+            s_log_lds[i] = g_tables_dev.log_table[i];
+    const uint32_t * const s_log =
+        LOGL ? s_log_lds : g_tables_dev.log_table;
     const float ea = u2f(g_tables_dev.exp_ab[0]);
     const float eb = u2f(g_tables_dev.exp_ab[1]);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;

@@ -135,3 +135,29 @@ def test_many_chains_of_mixed_rows():
             assert int(got[i]) == orc.gibbs_sequential(0, n, int(states[i]))
             assert_same(orc, gpu, "chain %d sweep %d" % (i, sweep))
         states = got
+
+
+@pytest.mark.parametrize("config", ["dd", "gp_nich"])
+def test_chain_under_low_entropy_clustering_with_churn(config):
+    """Clustering::LowEntropy through the generic MixtureDriver
+    (clustering.hpp:245-331, mixture.hpp:124-141): the structural steps of the
+    device chain under the other clustering model"""
+    import ctypes
+    from distributions_amd import engine
+    L = ol.oracle()
+    L.orc_mix_set_low_entropy.restype = None
+    L.orc_mix_set_low_entropy.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    n, k = 400, 150
+    osh, gsh, vals, assign = workloads.make(config, n, k, seed=23)
+    orc = ol.OracleMixture(1.0, 0.0, osh)
+    L.orc_mix_set_low_entropy(orc.h, n + 50)
+    orc.init_from_assignments(vals, assign, k, 2)
+    gpu = engine.Gibbs(0.0, 0.0, gsh, dataset_size=n + 50)
+    gpu.load_rows(vals, assign, k, 2)
+    st = 991
+    for sweep in range(3):
+        want = orc.gibbs_sequential(0, n, st)
+        assert gpu.sweep_sequential(0, n, st) == want
+        st = want
+        assert_same(orc, gpu, "low entropy %s sweep %d" % (config, sweep))
+    assert gpu.core.chain_launches() == 3
