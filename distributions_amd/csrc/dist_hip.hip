@@ -2916,7 +2916,18 @@ struct Gibbs {
         batch_open = true;
         batch_value_sorted = false;
         moves_in_row_order = false;
-        if (r0 == r1) return;
+        if (r0 == r1) {
+            // A rank whose shard is exhausted takes part with empty batches:
+            // its peers' deltas arrive in slots numbered AFTER the last
+            // batch's normalisation, so whatever a fused batch left to "the
+            // next k_vs_tables" is normalised here and now -- there is no
+            // such launch for an empty batch -- and this batch closes with
+            // the separate kernels (found by tools/fuzz_ranks.py: ragged
+            // value-partitioned shards under group churn diverged).
+            run_pending_finish();
+            batch_fused = false;
+            return;
+        }
         timing_this_batch =
             kernel_timing > 0 && timing_tick++ % (uint64_t)kernel_timing == 0;
         // (a host-driven batch: whatever sharded run was closed before it is
