@@ -144,6 +144,17 @@ class Gibbs(object):
         return self.core.path_counts()
 
 
+def sweep_sequential_many(engines, row_begin, row_end, rng_states):
+    """M independent exact chains in ONE launch (BASELINE configs[3]:
+    "independent chains"): engine i -- a `Gibbs` with its own rows -- runs the
+    reference's sequential chain (examples/mixture/main.py:236-244) over its
+    rows [row_begin, row_end) with rng_states[i]; one workgroup per chain,
+    group creation and removal on the device.  The engines share one feature
+    list.  -> the new rng states (numpy uint32)."""
+    return _core.sweep_sequential_many([g.core for g in engines], row_begin,
+                                       row_end, rng_states)
+
+
 class ShardedGibbs(object):
     """Row-sharded Gibbs over the ranks of a torch.distributed process group.
 
