@@ -140,8 +140,11 @@ def parse():
                     help="N = 1: independent exact chains (the reference's "
                          "own sampler) run concurrently for "
                          "`exact_chains_value`; 0 = skip")
-    ap.add_argument("--exact-rows", type=int, default=4000,
-                    help="rows each exact chain walks in its timed call")
+    ap.add_argument("--exact-rows", type=int, default=20000,
+                    help="rows each exact chain walks in its timed call "
+                         "(a call costs the host some 80 us per engine -- "
+                         "mirrors pulled, buffers reserved -- beside 9-20 us "
+                         "per row on the device)")
     return ap.parse_args()
 
 
@@ -766,8 +769,11 @@ def run_rank(args):
     # one launch (BASELINE configs[3]: "independent chains"), same model and
     # group count as the headline
     exact = None
-    if (world == 1 and not args.force_collective and args.exact_chains > 0
+    if (not args.force_collective and args.exact_chains > 0
             and args.config in ("dd", "dd16")):
+        # (N > 1: every rank runs its own chains -- "independent chains
+        # sharded 1/GPU", no exchange at all: replicas only -- and the line
+        # carries the sum over ranks, timed between two barriers)
         m = args.exact_chains
         rows_c = args.exact_rows
         n_c = max(3 * rows_c + 200, 8 * k)
@@ -775,7 +781,7 @@ def run_rank(args):
         chains = []
         for i in range(m):
             gen = torch.Generator(device=dev)
-            gen.manual_seed(args.seed + 1000 + i)
+            gen.manual_seed(args.seed + 1000 + i + 100000 * rank)
             col = torch.randint(0, dim_c, (n_c,), generator=gen, device=dev,
                                 dtype=torch.int32)
             asg = torch.arange(n_c, device=dev,
@@ -786,39 +792,49 @@ def run_rank(args):
             chains.append(c)
         cores_ = [c.core for c in chains]
         import numpy as np
-        st = np.array([_core.rng_seed(args.seed + 7 * i) for i in range(m)],
-                      np.uint32)
+        st = np.array([_core.rng_seed(args.seed + 7 * i + 70001 * rank)
+                       for i in range(m)], np.uint32)
+
+        def between_barriers(fn):
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            t0 = time.perf_counter()
+            out = fn()
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            dt = time.perf_counter() - t0
+            if world > 1:
+                t = torch.tensor([dt], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt = float(t.item())
+            return out, dt
         st1 = chains[0].sweep_sequential(0, 100, int(st[0]))   # warm, one
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        chains[0].sweep_sequential(100, 100 + rows_c, st1)
-        torch.cuda.synchronize()
-        dt_one = time.perf_counter() - t0
+        _, dt_one = between_barriers(
+            lambda: chains[0].sweep_sequential(100, 100 + rows_c, st1))
         st = _core.sweep_sequential_many(cores_, 100 + rows_c,
                                          200 + rows_c, st)    # warm, all
-        torch.cuda.synchronize()
         first = 200 + rows_c
         rows_m = min(rows_c, (n_c - first) // 2)
         # two chains per compute unit (FastLog's table in LDS) ...
         m_half = min(m, 512)
-        t0 = time.perf_counter()
-        st[:m_half] = _core.sweep_sequential_many(
-            cores_[:m_half], first, first + rows_m, st[:m_half])
-        torch.cuda.synchronize()
-        dt_half = time.perf_counter() - t0
+        head, dt_half = between_barriers(
+            lambda: _core.sweep_sequential_many(
+                cores_[:m_half], first, first + rows_m, st[:m_half]))
+        st[:m_half] = head
         # ... and all of them (beyond 512: four per CU, the table in L2)
-        t0 = time.perf_counter()
-        _core.sweep_sequential_many(cores_, first + rows_m,
-                                    first + 2 * rows_m, st)
-        torch.cuda.synchronize()
-        dt_many = time.perf_counter() - t0
-        exact = {"sequential_value": rows_c / dt_one,
+        _, dt_many = between_barriers(
+            lambda: _core.sweep_sequential_many(
+                cores_, first + rows_m, first + 2 * rows_m, st))
+        exact = {"sequential_value": world * rows_c / dt_one,
                  "sequential_us_per_row": 1e6 * dt_one / rows_c,
                  "sequential_cycles_per_row": CLOCK_GHZ * 1e9 * dt_one / rows_c,
-                 "exact_chains_value": m * rows_m / dt_many,
-                 "chains": m, "rows_per_chain": rows_m,
+                 "exact_chains_value": world * m * rows_m / dt_many,
+                 "chains": world * m, "chains_per_gpu": m,
+                 "rows_per_chain": rows_m,
                  "us_per_row_and_chain": 1e6 * dt_many / rows_m,
-                 "exact_chains_512_value": m_half * rows_m / dt_half,
+                 "exact_chains_512_value": world * m_half * rows_m / dt_half,
                  "unit": "row-updates/s",
                  "note": "the reference's sequential sampler itself, "
                          "bit-exact per chain against the oracle "
