@@ -1108,6 +1108,7 @@ struct Gibbs {
     // never travel; cells_partial: the OTHER values' cells here are stale
     // (dist_gibbs_gather_cells makes the replicas whole again)
     bool value_partitioned = false, cells_partial = false;
+    size_t present_values = 0;              // values with rows on this rank
     DeviceBuf<int32_t> owned_values;        // [dim] 1: this rank's
     void require_whole(const char * what) const {
         DIST_REQUIRE(!cells_partial,
@@ -2273,7 +2274,12 @@ struct Gibbs {
             && kind != DIST_GP && kind != DIST_BNB)
             return false;
         if (value_sorted_mode == 2) return true;
-        return rows >= (size_t)16 * vs_nvals() && rows >= 4096;
+        // (a value-partitioned rank meets only ITS values: what counts is
+        // the rows per value that is there, not per value of the domain)
+        const size_t nv = value_partitioned && present_values
+                              ? std::min<size_t>(present_values, vs_nvals())
+                              : (size_t)vs_nvals();
+        return rows >= (size_t)16 * nv && rows >= 4096;
     }
 
     VsCache & vs_get(size_t r0, size_t r1) {
@@ -5646,7 +5652,9 @@ int dist_gibbs_partition_by_value(dist_gibbs_t * g, dist_comm_t * c) {
         std::vector<int32_t> h((size_t)dim * 2);
         has.download(h.data(), h.size());
         std::vector<int32_t> owned((size_t)dim);
+        e.present_values = 0;
         for (int x = 0; x < dim; ++x) {
+            e.present_values += h[x] ? 1 : 0;
             DIST_REQUIRE(h[(size_t)dim + x] <= 1,
                          "value " + std::to_string(x) + " has rows on "
                          + std::to_string(h[(size_t)dim + x])
