@@ -142,7 +142,7 @@ def parse():
                          "`exact_chains_value`; 0 = skip")
     ap.add_argument("--exact-rows", type=int, default=20000,
                     help="rows each exact chain walks in its timed call "
-                         "(a call costs the host some 80 us per engine -- "
+                         "(a call costs the host some 26 us per engine -- "
                          "mirrors pulled, buffers reserved -- beside 9-20 us "
                          "per row on the device)")
     return ap.parse_args()
