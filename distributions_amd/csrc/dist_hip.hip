@@ -636,16 +636,24 @@ struct Slave {
         std::vector<float> after[5] = {grab(c0, Kn), grab(c1, Kn), grab(c2, Kn),
                                        grab(c3, Kn), grab(S, width * cap)};
         static const char * names[5] = {"c0", "c1", "c2", "c3", "S"};
+        DeviceBuf<float> * const bufs[5] = {&c0, &c1, &c2, &c3, &S};
         for (int b = 0; b < 5; ++b)
             for (size_t i = 0; i < before[b].size(); ++i) {
                 if (b == 4 && i % cap >= Kn) continue;   // slots beyond K
                 uint32_t x, y;
                 memcpy(&x, &before[b][i], 4);
                 memcpy(&y, &after[b][i], 4);
-                DIST_REQUIRE(x == y,
-                             std::string("validate: the value scorer's cache ")
-                                 + names[b] + " is stale at "
-                                 + std::to_string(b == 4 ? i % cap : i));
+                if (x == y) continue;
+                // (a check must not repair what it reports: the cache goes
+                // back to what it was, so that the failure can be seen again)
+                for (int r = 0; r < 5; ++r)
+                    if (!before[r].empty())
+                        bufs[r]->upload(before[r].data(), before[r].size());
+                dist::sync();
+                throw Error(std::string("ERROR validate: the value scorer's "
+                                        "cache ")
+                            + names[b] + " is stale at "
+                            + std::to_string(b == 4 ? i % cap : i));
             }
     }
 
