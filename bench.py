@@ -674,6 +674,7 @@ def run_rank(args):
             continue
         steps_b = max(1, min(args.steps, 5))
         before = g.core.debug_counts()
+        groups_before = len(g)
         dt_b = timed(sharded, g, n, b, steps_b, 1, draws)
         draws += 1 + steps_b
         ms_b, launches_b, rows_b = g.kernel_stats()
@@ -683,12 +684,26 @@ def run_rank(args):
                                        ("stream_batches", "k_vs_stream"),
                                        ("value_sorted_batches", "k_vs_sample"))
                 if after[key] > before[key]]
-        variants.append({
+        rec = {
             "batch_rows": b, "value": float(n) * world * steps_b / dt_b,
             "ms_per_step": 1e3 * dt_b / steps_b, "steps": steps_b,
             "host_enqueue_ms_per_step": 1e3 * timed.host_enqueue_s / steps_b,
             "kernel": took[0] if took else "k_sweep_sample",
-            "kernel_avg_launch_ms": ms_b / max(launches_b, 1)})
+            "kernel_avg_launch_ms": ms_b / max(launches_b, 1),
+            # (the chain goes on from the timed region: smaller sub-sweeps
+            # found groups faster -- every one of them may fill the empty
+            # group -- and every kernel's work follows the group count)
+            "groups_at_start": groups_before, "groups_at_end": len(g)}
+        if world == 1 and not args.force_collective:
+            # ... and the same sub-sweep size on a chain of its own, from the
+            # initial assignment, with the headline's warm-up
+            g3, sh3, _, _, _ = build_job(n, 0)
+            dt_f = timed(sh3, g3, n, b, steps_b, args.warmup, 0)
+            rec["fresh_chain_value"] = float(n) * steps_b / dt_f
+            rec["fresh_chain_groups_at_end"] = len(g3)
+            del g3, sh3
+            torch.cuda.empty_cache()
+        variants.append(rec)
 
     # (after the variants: they are quoted at the group count the timed region
     # left)
@@ -1023,6 +1038,9 @@ def run_rank(args):
                 # `other_configs` / `batch_variants`)
                 "b65536_value": next((v["value"] for v in variants
                                       if v["batch_rows"] == 65536), None),
+                "b65536_fresh_chain_value": next(
+                    (v.get("fresh_chain_value") for v in variants
+                     if v["batch_rows"] == 65536), None),
                 "c3_value": next((o["value"] for o in others
                                   if o["config"] == "gp_nich"
                                   and o["sampling"] == "exact"), None),
