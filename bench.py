@@ -713,10 +713,18 @@ def run_rank(args):
     sustained = None
     if (world == 1 and not args.force_collective
             and args.sustained_seconds > 0 and dt > 0):
-        steps_s = max(args.steps,
-                      int(args.sustained_seconds / (dt / args.steps)) + 1)
-        dt_s = timed(sharded, g, n, args.batch, steps_s, 0, draws)
-        draws += steps_s
+        # (in stretches of what the timed region's rate predicts, until the
+        # clock says so: the estimate is off both ways -- a long run pulls
+        # the host's copy of the group set once, and slows as groups are
+        # founded)
+        chunk = max(args.steps,
+                    int(args.sustained_seconds / (dt / args.steps)) + 1)
+        steps_s, dt_s = 0, 0.0
+        while dt_s < args.sustained_seconds:
+            dt_s += timed(sharded, g, n, args.batch, chunk, 0, draws)
+            draws += chunk
+            steps_s += chunk
+            chunk = max(args.steps, chunk // 4)
         sustained = {"value": float(n) * steps_s / dt_s,
                      "unit": "row-updates/s", "steps": steps_s,
                      "seconds": dt_s, "ms_per_step": 1e3 * dt_s / steps_s,

@@ -44,11 +44,22 @@ def test_world_size_must_agree_with_gpus():
 def test_small_single_gpu_run_prints_one_json_line():
     r = run(["--rows", "400000", "--batch", "100000", "--steps", "2",
              "--warmup", "1", "--cpu-rows", "20000", "--other-batches",
-             "50000"])
+             "50000", "--exact-chains", "8", "--exact-rows", "500",
+             "--sustained-seconds", "0.2"])
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [x for x in r.stdout.splitlines() if x.startswith("{")]
     assert len(lines) == 1
     out = json.loads(lines[0])
+    # the job running on, and the reference's own sampler on the device
+    assert out["sustained_value"] > 0
+    assert out["sustained"]["seconds"] >= 0.2
+    assert out["sustained"]["groups_at_end"] > 0
+    assert out["sequential_value"] > 0 and out["exact_chains_value"] > 0
+    assert out["exact_chains"]["chains"] == 8
+    assert out["batch_variants"][0]["fresh_chain_value"] > 0
+    # a missing roofline fraction is never silent
+    assert (out["roofline"]["frac"] is not None
+            or out["roofline"]["stale_reason"])
     assert out["n_gpus"] == 1 and out["unit"] == "row-updates/s"
     assert out["value"] > 0 and out["cpu_baseline"]["value"] > 0
     assert out["cpu_baseline"]["cores"] == 1
@@ -96,6 +107,28 @@ def test_one_rank_collective_path_reports_its_all_reduce():
     assert out["config"]["collectives"] == "library RCCL communicator"
     assert out["comm"]["timed"] >= 1 and out["comm"]["all_reduce_avg_us"] > 0
     assert "normalised on the device" in out["config"]["group_set"]
+    # what the exchanges carried, counted by the library: value-partitioned
+    # ranks send 3 words per live group (+ the 4-word header)
+    comm = out["comm"]
+    assert comm["placement"] == "value"
+    assert comm["all_reduces_in_run"] == 3 * 4
+    assert 4 + 3 * 1025 <= comm["words_per_all_reduce"] <= 4 + 3 * 1200
+    assert comm["words_largest_all_reduce"] <= 4 + 3 * 1200
+
+
+@pytest.mark.gpu
+def test_one_rank_collective_path_block_placement():
+    r = run(["--rows", "400000", "--batch", "100000", "--steps", "2",
+             "--warmup", "1", "--cpu-rows", "0", "--other-batches", "",
+             "--force-collective", "--placement", "block"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([x for x in r.stdout.splitlines()
+                      if x.startswith("{")][-1])
+    comm = out["comm"]
+    assert comm["placement"] == "block"
+    # the LIVE part of the group set, never the run's bound (8128 groups)
+    assert (4 + 259 * 1025 <= comm["words_per_all_reduce"]
+            <= 4 + 259 * 1200)
 
 
 @pytest.mark.gpu
