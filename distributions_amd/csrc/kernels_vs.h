@@ -2643,14 +2643,27 @@ void k_vs_reduce(StatImage img, const int32_t * __restrict__ stage,
     // of the group set, Gibbs::exchange_K, has no room for them)
     (void)k_limit;
     if (k < K) {
-        for (uint32_t c = slice; c < n_chunks; c += kVsReduceSlices) {
-            const int d = stage[(size_t)c * stride + k];
-            const uint32_t x = chunks[c].x;
+        auto take = [&](int d, uint32_t x) {
             a += d;
             if (KIND == DIST_BB) b += x ? d : 0;
             if (KIND == DIST_GP || KIND == DIST_BNB)
                 b += x < nvals ? d * (int32_t)x : 0;
+        };
+        // (four chunks' words in flight per step)
+        uint32_t c = slice;
+        for (; c + 3 * kVsReduceSlices < n_chunks; c += 4 * kVsReduceSlices) {
+            int d[4];
+            uint32_t x[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                d[q] = stage[(size_t)(c + q * kVsReduceSlices) * stride + k];
+                x[q] = chunks[c + q * kVsReduceSlices].x;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) take(d[q], x[q]);
         }
+        for (; c < n_chunks; c += kVsReduceSlices)
+            take(stage[(size_t)c * stride + k], chunks[c].x);
     }
     // the cells k_vs_apply left to this kernel (a fused batch's values with
     // several chunks; multi[] = {value, first chunk, chunks} each): thread
@@ -2659,9 +2672,20 @@ void k_vs_reduce(StatImage img, const int32_t * __restrict__ stage,
         for (uint32_t m = slice; m < n_multi; m += kVsReduceSlices) {
             const uint32_t x = multi[3 * m], c0 = multi[3 * m + 1],
                            nc = multi[3 * m + 2];
+            // (eight loads in flight: a head value of Zipf data has some
+            // thirty chunks, and one dependent trip per chunk made this
+            // kernel 9.4 us where uniform values take 5.0)
             int d = 0;
-            for (uint32_t c = c0; c < c0 + nc; ++c)
-                d += stage[(size_t)c * stride + k];
+            uint32_t c = c0;
+            for (; c + 8 <= c0 + nc; c += 8) {
+                int v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    v[q] = stage[(size_t)(c + q) * stride + k];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) d += v[q];
+            }
+            for (; c < c0 + nc; ++c) d += stage[(size_t)c * stride + k];
             if (d) img.cnt[0][(size_t)k * dim + x] += d;
         }
     s_a[slice][kk] = a;
